@@ -1,0 +1,95 @@
+/* zmi355.h -- C ABI of the MI355X-native DEFLATE engine (libzmi355.so).
+ *
+ * Two layers, both plain C (pointers + sizes, no C++ / torch types):
+ *
+ *  1. The zlib stream ABI of the reference, unchanged: z_stream, deflateInit2_/deflate/deflateEnd,
+ *     inflateInit2_/inflate/inflateEnd, compress2/uncompress, adler32/crc32 (+_combine) ...
+ *     Declared in zmi355_zlib.h with the reference line each symbol replaces
+ *     (libz-rs-sys/src/lib.rs).  A caller of libz-rs-sys relinks against libzmi355.so.
+ *
+ *  2. The batch entry points below (new, additive).  The reference's ABI is one stream per call
+ *     (libz-rs-sys/src/lib.rs:1281 deflate, :636 inflate); the north-star workload is thousands of
+ *     independent 1 MiB shards, which need one launch per batch, not per stream.  Semantics per
+ *     shard are exactly those of
+ *         deflateInit2_(level, Z_DEFLATED, windowBits(wrap), 8, strategy) + deflate(Z_FINISH) + deflateEnd
+ *         (test-libz-rs-sys/examples/blogpost-compress.rs:43-122), and
+ *         inflateInit2_(windowBits(wrap)) + inflate(Z_FINISH) + inflateEnd
+ *         (test-libz-rs-sys/examples/blogpost-uncompress.rs:6-44)
+ *     with the per-shard return code reported in status[] using zlib's numbering
+ *     (zlib-rs/src/c_api.rs:140-148): 0 ok, -3 Z_DATA_ERROR, -5 Z_BUF_ERROR, 2 Z_NEED_DICT.
+ *
+ * Every function here requires a gfx950 device; there is no CPU fallback (ZMI_E_NODEVICE).
+ */
+#ifndef ZMI355_H
+#define ZMI355_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zmi_ctx zmi_ctx;
+
+/* wrapper selection (windowBits of the reference: -15 raw, 15 zlib, 31 gzip, 47 auto-detect) */
+#define ZMI_WRAP_RAW 0
+#define ZMI_WRAP_ZLIB 1
+#define ZMI_WRAP_GZIP 2
+#define ZMI_WRAP_AUTO 3 /* inflate only */
+
+/* library-level return codes (per-shard codes use zlib numbering, see above) */
+#define ZMI_E_OK 0
+#define ZMI_E_NODEVICE (-101)
+#define ZMI_E_HIP (-102)
+#define ZMI_E_ARG (-103)
+#define ZMI_E_NOMEM (-104)
+
+const char* zmi_version(void);
+const char* zmi_last_error(void);
+
+int zmi_ctx_create(zmi_ctx** ctx, int device);
+int zmi_ctx_destroy(zmi_ctx* ctx);
+/* upper bound of scratch the context may allocate on the device (default 8 GiB; env ZMI_SCRATCH_MB) */
+int zmi_ctx_set_scratch_limit(zmi_ctx* ctx, uint64_t bytes);
+
+/* worst-case compressed size of an n-byte shard; same formula as the reference's compress_bound
+ * (zlib-rs/src/deflate.rs:2975-2991) with the wrapper overhead of `wrap`, rounded up to 16. */
+uint64_t zmi_deflate_bound(uint64_t n, int wrap);
+
+/* ---- device-resident batch API (all d_* pointers are device memory; stream is a hipStream_t) ---- */
+
+/* shard i = d_in[d_in_off[i] .. + d_in_len[i]); compressed stream i is written at
+ * d_out + i*out_stride (out_stride multiple of 16, >= zmi_deflate_bound(max_len, wrap)),
+ * its length to d_out_len[i], its zlib return code to d_status[i].
+ * level 0..9 or -1, strategy 0..4 as deflateInit2_ (libz-rs-sys/src/lib.rs:2005-2041). */
+int zmi_deflate_batch_dev(zmi_ctx* ctx, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                          uint32_t n_shards, uint32_t max_len, int level, int strategy, int wrap, void* d_out,
+                          uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream);
+
+/* stream i = d_in[d_in_off[i] .. + d_in_len[i]); output i is written at d_out + d_out_off[i]
+ * (capacity d_out_cap[i]); d_out_len[i] receives the number of bytes produced, d_status[i] the
+ * zlib return code (0 = stream complete and check value correct). */
+int zmi_inflate_batch_dev(zmi_ctx* ctx, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                          uint32_t n_streams, int wrap, void* d_out, const uint64_t* d_out_off,
+                          const uint32_t* d_out_cap, uint32_t* d_out_len, int32_t* d_status, void* stream);
+
+/* Adler-32 (kind bit 0) and/or CRC-32 (kind bit 1) of every shard (zlib-rs/src/adler32.rs:19, crc32.rs:19) */
+int zmi_checksum_batch_dev(zmi_ctx* ctx, const void* d_data, const uint64_t* d_off, const uint32_t* d_len,
+                           uint32_t n_shards, int kind, uint32_t* d_adler, uint32_t* d_crc, void* stream);
+
+/* synthetic Silesia-like benchmark shards (csrc/shardgen.h): shard first_shard+i at d_out + i*shard_bytes */
+int zmi_gen_shards_dev(zmi_ctx* ctx, void* d_out, uint64_t seed, uint32_t first_shard, uint32_t n_shards,
+                       uint32_t shard_bytes, void* stream);
+
+/* ---- host-buffer convenience wrappers: copy in, run the batch on the GPU, copy back ---- */
+int zmi_deflate_batch(zmi_ctx* ctx, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n_shards,
+                      int level, int strategy, int wrap, uint8_t* out, uint64_t out_stride, uint32_t* out_len,
+                      int32_t* status);
+int zmi_inflate_batch(zmi_ctx* ctx, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n_streams,
+                      int wrap, uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len,
+                      int32_t* status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,97 @@
+"""ctypes binding of the batch C ABI (include/zmi355.h) used by the tests.
+
+Loads either the product library (zlib_rs_amd/libzmi355.so, needs an MI355X) or the CPU SIMT
+emulator build of the same kernels (tests/emu/libzmi355_emu.so, test infrastructure only).
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bind(lib):
+    u8p, u32p, u64p, i32p = C.POINTER(C.c_uint8), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)
+    lib.zmi_version.restype = C.c_char_p
+    lib.zmi_last_error.restype = C.c_char_p
+    lib.zmi_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.zmi_ctx_destroy.argtypes = [C.c_void_p]
+    lib.zmi_deflate_bound.restype = C.c_uint64
+    lib.zmi_deflate_bound.argtypes = [C.c_uint64, C.c_int]
+    lib.zmi_deflate_batch.argtypes = [C.c_void_p, C.c_void_p, u64p, u32p, C.c_uint32, C.c_int, C.c_int, C.c_int,
+                                      C.c_void_p, C.c_uint64, u32p, i32p]
+    lib.zmi_inflate_batch.argtypes = [C.c_void_p, C.c_void_p, u64p, u32p, C.c_uint32, C.c_int, C.c_void_p, u64p, u32p,
+                                      u32p, i32p]
+    return lib
+
+
+def load_emu(rebuild=True):
+    d = os.path.join(ROOT, "tests", "emu")
+    if rebuild:
+        subprocess.run(["make", "-s", "-C", d], check=True)
+    return _bind(C.CDLL(os.path.join(d, "libzmi355_emu.so")))
+
+
+def load_product():
+    return _bind(C.CDLL(os.path.join(ROOT, "zlib_rs_amd", "libzmi355.so")))
+
+
+class Engine:
+    """Host-buffer view of the batch API (works for both the product and the emulator build)."""
+
+    def __init__(self, lib, device=0):
+        self.lib = lib
+        self.ctx = C.c_void_p()
+        rc = lib.zmi_ctx_create(C.byref(self.ctx), device)
+        if rc != 0:
+            raise RuntimeError("zmi_ctx_create failed: %d %s" % (rc, lib.zmi_last_error().decode()))
+
+    def close(self):
+        if self.ctx:
+            self.lib.zmi_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def deflate(self, shards, level=6, strategy=0, wrap=1):
+        """shards: list of bytes -> (list of compressed bytes, list of status)"""
+        n = len(shards)
+        lens = np.array([len(s) for s in shards], dtype=np.uint32)
+        offs = np.zeros(n, dtype=np.uint64)
+        if n:
+            offs[1:] = np.cumsum(lens[:-1].astype(np.uint64))
+        blob = np.frombuffer(b"".join(shards) + b"\0", dtype=np.uint8).copy()
+        stride = int(self.lib.zmi_deflate_bound(int(lens.max()) if n else 0, wrap))
+        out = np.zeros(max(1, n * stride), dtype=np.uint8)
+        olen = np.zeros(max(1, n), dtype=np.uint32)
+        st = np.zeros(max(1, n), dtype=np.int32)
+        rc = self.lib.zmi_deflate_batch(self.ctx, blob.ctypes.data, offs.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                        lens.ctypes.data_as(C.POINTER(C.c_uint32)), n, level, strategy, wrap,
+                                        out.ctypes.data, stride, olen.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                        st.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc != 0:
+            raise RuntimeError("zmi_deflate_batch failed: %d %s" % (rc, self.lib.zmi_last_error().decode()))
+        return [bytes(out[i * stride:i * stride + int(olen[i])]) for i in range(n)], [int(x) for x in st[:n]]
+
+    def inflate(self, streams, caps, wrap=1):
+        """streams: list of bytes, caps: list of output capacities -> (list of bytes, list of status)"""
+        n = len(streams)
+        lens = np.array([len(s) for s in streams], dtype=np.uint32)
+        offs = np.zeros(n, dtype=np.uint64)
+        if n:
+            offs[1:] = np.cumsum(lens[:-1].astype(np.uint64))
+        blob = np.frombuffer(b"".join(streams) + b"\0", dtype=np.uint8).copy()
+        ocap = np.array(caps, dtype=np.uint32)
+        ooff = np.zeros(n, dtype=np.uint64)
+        if n:
+            ooff[1:] = np.cumsum(ocap[:-1].astype(np.uint64))
+        out = np.zeros(max(1, int(ocap.astype(np.uint64).sum())), dtype=np.uint8)
+        olen = np.zeros(max(1, n), dtype=np.uint32)
+        st = np.zeros(max(1, n), dtype=np.int32)
+        rc = self.lib.zmi_inflate_batch(self.ctx, blob.ctypes.data, offs.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                        lens.ctypes.data_as(C.POINTER(C.c_uint32)), n, wrap, out.ctypes.data,
+                                        ooff.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                        ocap.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                        olen.ctypes.data_as(C.POINTER(C.c_uint32)), st.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc != 0:
+            raise RuntimeError("zmi_inflate_batch failed: %d %s" % (rc, self.lib.zmi_last_error().decode()))
+        return [bytes(out[int(ooff[i]):int(ooff[i]) + min(int(olen[i]), int(ocap[i]))]) for i in range(n)], [int(x) for x in st[:n]]

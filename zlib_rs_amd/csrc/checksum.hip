@@ -1,0 +1,144 @@
+// checksum.hip -- Adler-32 and CRC-32 of every shard of a batch, one workgroup per shard.
+//
+// These are the RFC 1950 / RFC 1952 trailer checksums; the reference computes them in
+// zlib-rs/src/adler32.rs:19-47 (BASE 65521, NMAX 5552) + adler32/generic.rs and
+// zlib-rs/src/crc32.rs:19-29 + crc32/braid.rs (reflected polynomial 0xEDB88320), fused into
+// fill_window / Window::extend.  On the GPU both are restructured around linearity instead of a
+// serial fold:
+//   Adler-32:  s1 = 1 + sum(b_i),  s2 = n + sum((n - i) * b_i)   (mod 65521)
+//              -> every thread takes 16-byte stripes (coalesced), no sequential dependency.
+//   CRC-32:    thread t owns one contiguous segment, computes the zero-init raw CRC with a
+//              slice-by-4 table in LDS, multiplies it by x^(8 * bytes_after_segment) mod P
+//              (the crc32_combine algebra of crc32/combine.rs:26-61 applied per thread) and the
+//              workgroup XOR-reduces.  Pre/post conditioning is folded in at the end.
+// HBM-bound by construction: 1 byte read per input byte, 4 bytes written per shard.
+#include "zmi_device.h"
+
+#define ZMI_ADLER_BASE 65521u
+#define ZMI_CRC_POLY 0xEDB88320u
+
+// a(x) * b(x) mod P, reflected bit order (bit 31 = x^0)
+static __device__ __forceinline__ uint32_t zmi_gf2_mulmod(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 31; i >= 0; --i) {
+        if ((a >> i) & 1u) p ^= b;
+        b = (b >> 1) ^ ((b & 1u) ? ZMI_CRC_POLY : 0u);
+    }
+    return p;
+}
+// x^(8*nbytes) mod P
+static __device__ __forceinline__ uint32_t zmi_gf2_xpow8(uint64_t nbytes) {
+    uint32_t r = 0x80000000u;   // x^0
+    uint32_t pw = 0x00800000u;  // x^8
+    while (nbytes) {
+        if (nbytes & 1u) r = zmi_gf2_mulmod(r, pw);
+        pw = zmi_gf2_mulmod(pw, pw);
+        nbytes >>= 1;
+    }
+    return r;
+}
+
+// kind: bit0 = adler32 wanted, bit1 = crc32 wanted.  out_adler/out_crc indexed by shard.
+__global__ void __launch_bounds__(256) zmi_checksum_kernel(const uint8_t* __restrict__ data,
+                                                           const uint64_t* __restrict__ off,
+                                                           const uint32_t* __restrict__ len, uint32_t kind,
+                                                           uint32_t* __restrict__ out_adler,
+                                                           uint32_t* __restrict__ out_crc) {
+    __shared__ uint32_t tab[4][256];
+    __shared__ uint32_t red[3][4];
+    const uint32_t s = blockIdx.x;
+    const uint32_t t = threadIdx.x;
+    const uint8_t* src = data + off[s];
+    const uint32_t n = len[s];
+    const bool aligned = (((uintptr_t)src) & 15u) == 0;
+
+    if (kind & 1u) {
+        uint32_t A = 0;
+        uint64_t B = 0;
+        for (uint32_t i0 = t * 16u; i0 < n; i0 += 256u * 16u) {
+            uint32_t nv = n - i0;
+            zmi_b16 v = zmi_ld16(src + i0, nv, aligned);
+            uint32_t sb = 0, sjb = 0;
+#pragma unroll
+            for (uint32_t j = 0; j < 16u; ++j) {
+                uint32_t b = (v.w[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
+                sb += b;
+                sjb += j * b;
+            }
+            A += sb;
+            // weight of byte i is (n - i); bytes past n were read as zero so they add nothing
+            B += (uint64_t)((n - i0) % ZMI_ADLER_BASE) * sb + (uint64_t)(16u * ZMI_ADLER_BASE) - sjb;
+        }
+        uint32_t a = A % ZMI_ADLER_BASE;
+        uint32_t b = (uint32_t)(B % ZMI_ADLER_BASE);
+        a = zmi_wave_sum(a);
+        b = zmi_wave_sum(b);
+        if (zmi_lane() == 0) { red[0][zmi_wave()] = a % ZMI_ADLER_BASE; red[1][zmi_wave()] = b % ZMI_ADLER_BASE; }
+    }
+    if (kind & 2u) {
+        // slice-by-4 tables
+        uint32_t c = t;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? ZMI_CRC_POLY : 0u);
+        tab[0][t] = c;
+        __syncthreads();
+        uint32_t c1 = (c >> 8) ^ tab[0][c & 0xFFu];
+        uint32_t c2 = (c1 >> 8) ^ tab[0][c1 & 0xFFu];
+        uint32_t c3 = (c2 >> 8) ^ tab[0][c2 & 0xFFu];
+        tab[1][t] = c1; tab[2][t] = c2; tab[3][t] = c3;
+        __syncthreads();
+        // contiguous segment per thread, length multiple of 16
+        uint32_t seg = ((n + 255u) / 256u + 15u) & ~15u;
+        uint64_t beg = (uint64_t)t * seg;
+        uint32_t crc = 0;
+        uint64_t after = 0;
+        if (beg < n) {
+            uint32_t end = (beg + seg < n) ? (uint32_t)(beg + seg) : n;
+            after = n - end;
+            for (uint32_t i0 = (uint32_t)beg; i0 < end; i0 += 16u) {
+                uint32_t nv = end - i0;
+                zmi_b16 v = zmi_ld16(src + i0, nv, aligned);
+                if (nv >= 16u) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint32_t x = crc ^ v.w[q];
+                        crc = tab[3][x & 0xFFu] ^ tab[2][(x >> 8) & 0xFFu] ^ tab[1][(x >> 16) & 0xFFu] ^ tab[0][x >> 24];
+                    }
+                } else {
+                    for (uint32_t j = 0; j < nv; ++j) {
+                        uint32_t b = (v.w[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
+                        crc = tab[0][(crc ^ b) & 0xFFu] ^ (crc >> 8);
+                    }
+                }
+            }
+            crc = zmi_gf2_mulmod(crc, zmi_gf2_xpow8(after));
+        }
+        // xor-reduce
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) crc ^= __shfl_xor(crc, d);
+        if (zmi_lane() == 0) red[2][zmi_wave()] = crc;
+    }
+    __syncthreads();
+    if (t == 0) {
+        if (kind & 1u) {
+            uint32_t a = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) % ZMI_ADLER_BASE;
+            uint32_t b = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) % ZMI_ADLER_BASE;
+            uint32_t s1 = (1u + a) % ZMI_ADLER_BASE;
+            uint32_t s2 = (n % ZMI_ADLER_BASE + b) % ZMI_ADLER_BASE;
+            out_adler[s] = (s2 << 16) | s1;
+        }
+        if (kind & 2u) {
+            uint32_t raw = red[2][0] ^ red[2][1] ^ red[2][2] ^ red[2][3];
+            // init 0xFFFFFFFF travels through n bytes, then final inversion
+            uint32_t init = zmi_gf2_mulmod(0xFFFFFFFFu, zmi_gf2_xpow8(n));
+            out_crc[s] = raw ^ init ^ 0xFFFFFFFFu;
+        }
+    }
+}
+
+extern "C" int zmi_launch_checksum(const uint8_t* d_data, const uint64_t* d_off, const uint32_t* d_len,
+                                   uint32_t n_shards, uint32_t kind, uint32_t* d_adler, uint32_t* d_crc,
+                                   hipStream_t stream) {
+    if (n_shards == 0 || (kind & 3u) == 0) return 0;
+    ZMI_LAUNCH(zmi_checksum_kernel, dim3(n_shards), dim3(256), 0, stream, d_data, d_off, d_len, kind, d_adler, d_crc);
+    return 0;
+}

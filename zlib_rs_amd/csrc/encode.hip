@@ -1,0 +1,620 @@
+// encode.hip -- deflate stage 2: parse selection, Huffman code construction and bit packing.
+//
+// Reference semantics being reproduced (format, not structure):
+//   lazy match selection        zlib-rs/src/deflate/algorithm/{medium,slow}.rs
+//   tally_lit / tally_dist      zlib-rs/src/deflate.rs:1464-1521
+//   build_tree / gen_bitlen /
+//   gen_codes                   zlib-rs/src/deflate.rs:1945-2160   (any valid <=15-bit prefix code is acceptable)
+//   scan_tree / send_tree /
+//   send_all_trees              zlib-rs/src/deflate.rs:2171-2314,1177-1260
+//   zng_tr_flush_block          zlib-rs/src/deflate.rs:2316-2434   (stored / static / dynamic by cost)
+//   BitWriter / compress_block  zlib-rs/src/deflate.rs:907-1175
+//   header / trailer            zlib-rs/src/deflate.rs:1572-1601,2574-2627,2772-2789
+//
+// MI355X design: ONE WAVE PER SHARD (64-thread workgroups, ~9 KiB LDS, 16+ shards resident per CU),
+// no workgroup barriers at all.  The batch supplies the parallelism (thousands of shards); inside a
+// shard the wave walks 64 positions per step:
+//   * parse: every lane owns one position and knows its best match (from lz77.hip).  The greedy/lazy
+//     rule gives each position a local "next token" pointer; six rounds of wave-wide pointer doubling
+//     (ds_bpermute) turn the pointers into the 64-bit set of positions reachable from the segment's
+//     entry point -- the serial token walk of the CPU parse becomes log2(64) shuffles.
+//   * tokens are compacted with mbcnt and overwrite the match scratch in place (token index <=
+//     position index), histogrammed with LDS atomics.
+//   * per block (64 KiB of input): lane-parallel rank sort of the symbol frequencies, a two-queue
+//     Huffman merge + length limiting on lane 0, canonical codes, RFC 1951 header.
+//   * bit packing: a wave prefix-sum over the code lengths gives every token its output bit
+//     position; codes are OR-ed into an LDS staging window with ds_or and whole dwords are stored
+//     coalesced.  No serial bit writer on the token path.
+// Bound: instruction issue (integer VALU/LDS), not HBM: 4 B/position scratch read + <=4 B written
+// back + 1/ratio B of output per input byte.
+#include "zmi_device.h"
+#include "zmi_kernels.h"
+
+#define ENC_NL 288u
+#define ENC_ND 32u
+#define ENC_NBL 19u
+#define ENC_STG 128u
+
+struct EncShared {
+    uint32_t lfreq[ENC_NL];
+    uint32_t dfreq[ENC_ND];
+    uint32_t lcode[ENC_NL];  // bit-reversed code | len << 16
+    uint32_t dcode[ENC_ND];
+    uint32_t stg[ENC_STG];
+    uint32_t nfreq[ENC_NL];
+    uint16_t order[ENC_NL];
+    uint16_t lpar[ENC_NL];
+    uint16_t ipar[ENC_NL];
+    uint16_t idep[ENC_NL];
+    uint8_t llen[ENC_NL];
+    uint8_t dlen[ENC_ND];
+    uint8_t bllen[32];
+    uint32_t blfreq[32];
+    uint32_t blcode[32];
+    uint8_t hsym[ENC_NL + ENC_ND];
+    uint8_t hext[ENC_NL + ENC_ND];
+    uint32_t cnt[16];
+    uint32_t next[16];
+    uint32_t misc[16];
+};
+#define M_NNZ 0
+#define M_REL 1
+#define M_CHOICE 2
+
+// ---- symbol mapping (RFC 1951 3.2.5), computed instead of table-driven ----
+// length 3..258 -> (code index 0..28, extra bit count, extra value)
+static __device__ __forceinline__ void enc_len_sym(uint32_t len, uint32_t& idx, uint32_t& eb, uint32_t& ev) {
+    uint32_t l = len - 3u;
+    if (l < 8u) { idx = l; eb = 0; ev = 0; }
+    else if (l == 255u) { idx = 28u; eb = 0; ev = 0; }
+    else {
+        uint32_t k = 31u - (uint32_t)__clz(l);  // >= 3
+        eb = k - 2u;
+        idx = 4u * (k - 1u) + ((l >> eb) & 3u);
+        ev = l & ((1u << eb) - 1u);
+    }
+}
+// distance 1..32768 -> (code 0..29, extra bit count, extra value)
+static __device__ __forceinline__ void enc_dist_sym(uint32_t dist, uint32_t& idx, uint32_t& eb, uint32_t& ev) {
+    uint32_t d = dist - 1u;
+    if (d < 4u) { idx = d; eb = 0; ev = 0; }
+    else {
+        uint32_t k = 31u - (uint32_t)__clz(d);  // >= 2
+        eb = k - 1u;
+        idx = 2u * k + ((d >> eb) & 1u);
+        ev = d & ((1u << eb) - 1u);
+    }
+}
+static __device__ __forceinline__ uint32_t enc_lext(uint32_t idx) { return (idx < 8u || idx == 28u) ? 0u : (idx >> 2) - 1u; }
+static __device__ __forceinline__ uint32_t enc_dext(uint32_t idx) { return idx < 4u ? 0u : (idx >> 1) - 1u; }
+static __device__ __forceinline__ uint32_t enc_static_llen(uint32_t s) {
+    return s < 144u ? 8u : (s < 256u ? 9u : (s < 280u ? 7u : 8u));
+}
+
+// ---- bit writer over the LDS staging window ----
+struct EncWriter {
+    uint32_t* outw;   // shard output, 4-byte aligned
+    uint32_t cap_w;   // capacity in dwords
+    uint32_t wbase;   // dwords already stored
+    uint32_t rel;     // valid bits in stg[]
+    uint32_t err;
+};
+
+// lane 0 only: append nbits (<= 32) of val
+static __device__ __forceinline__ void enc_put0(EncShared* S, uint32_t& rel, uint32_t val, uint32_t nbits) {
+    uint32_t w = rel >> 5, sh = rel & 31u;
+    uint64_t v = (uint64_t)val << sh;
+    S->stg[w] |= (uint32_t)v;
+    if (sh + nbits > 32u) S->stg[w + 1u] |= (uint32_t)(v >> 32);
+    rel += nbits;
+}
+
+// all lanes: store the complete dwords of the staging window, keep the partial one
+static __device__ __forceinline__ void enc_flush(EncShared* S, EncWriter& W) {
+    const uint32_t lane = zmi_lane();
+    uint32_t nfull = W.rel >> 5;
+    if (nfull == 0) return;
+    if (W.wbase + nfull > W.cap_w) W.err = 1u;
+    if (!W.err)
+        for (uint32_t i = lane; i < nfull; i += 64u) W.outw[W.wbase + i] = S->stg[i];
+    uint32_t carry = S->stg[nfull];
+    zmi_wave_sync();
+    for (uint32_t i = lane; i <= nfull; i += 64u) S->stg[i] = (i == 0u) ? carry : 0u;
+    zmi_wave_sync();
+    W.wbase += nfull;
+    W.rel &= 31u;
+}
+
+// all lanes: lane i appends nbits (<= 48) of bits; lanes are concatenated in lane order
+static __device__ __forceinline__ void enc_emit_group(EncShared* S, EncWriter& W, uint64_t bits, uint32_t nbits) {
+    uint32_t incl = zmi_wave_incl_scan(nbits);
+    uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    if (nbits) {
+        uint32_t o = W.rel + incl - nbits;
+        uint32_t w = o >> 5, sh = o & 31u;
+        uint64_t v = bits << sh;
+        atomicOr(&S->stg[w], (uint32_t)v);
+        uint32_t w1 = (uint32_t)(v >> 32);
+        if (w1) atomicOr(&S->stg[w + 1u], w1);
+        if (sh) {
+            uint32_t w2 = (uint32_t)(bits >> (64u - sh));
+            if (w2) atomicOr(&S->stg[w + 2u], w2);
+        }
+    }
+    W.rel += total;
+    zmi_wave_sync();
+    enc_flush(S, W);
+}
+
+// ---- lane-parallel rank sort of the symbols with non-zero frequency (ascending freq, then index) ----
+static __device__ void enc_rank_sort(EncShared* S, const uint32_t* freq, uint32_t nsym) {
+    const uint32_t lane = zmi_lane();
+    uint32_t fi[5], rk[5];
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 5u; ++k) {
+        uint32_t i = lane + 64u * k;
+        fi[k] = i < nsym ? freq[i] : 0u;
+        rk[k] = 0;
+        mine += fi[k] != 0u;
+    }
+    for (uint32_t j = 0; j < nsym; ++j) {
+        uint32_t fj = freq[j];
+        if (fj == 0u) continue;  // uniform branch
+#pragma unroll
+        for (uint32_t k = 0; k < 5u; ++k) {
+            uint32_t i = lane + 64u * k;
+            rk[k] += (fj < fi[k]) || (fj == fi[k] && j < i);
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < 5u; ++k) {
+        uint32_t i = lane + 64u * k;
+        if (i < nsym && fi[k] != 0u) S->order[rk[k]] = (uint16_t)i;
+    }
+    uint32_t nnz = zmi_wave_sum(mine);
+    if (lane == 0) S->misc[M_NNZ] = nnz;
+    zmi_wave_sync();
+}
+
+// ---- lane 0: optimal code lengths (<= maxbits) for the symbols listed in S->order[0..nnz) ----
+static __device__ void enc_huff_lengths(EncShared* S, const uint32_t* freq, uint32_t nsym, uint32_t nnz, uint32_t maxbits,
+                                        uint8_t* lens) {
+    for (uint32_t i = 0; i < nsym; ++i) lens[i] = 0;
+    if (nnz == 0u) { lens[0] = 1; lens[1] = 1; return; }
+    if (nnz == 1u) {
+        uint32_t s = S->order[0];
+        lens[s] = 1;
+        lens[s == 0u ? 1u : 0u] = 1;  // a second, unused code keeps the set complete (cf. deflate.rs:1957-1977)
+        return;
+    }
+    // two-queue merge: leaves ascending in order[], internal nodes are created in ascending weight
+    uint32_t li = 0, ii = 0;
+    for (uint32_t ni = 0; ni + 1u < nnz; ++ni) {
+        uint32_t w = 0;
+        for (int pick = 0; pick < 2; ++pick) {
+            bool leaf;
+            if (li >= nnz) leaf = false;
+            else if (ii >= ni) leaf = true;
+            else leaf = freq[S->order[li]] <= S->nfreq[ii];
+            if (leaf) { w += freq[S->order[li]]; S->lpar[li] = (uint16_t)ni; ++li; }
+            else { w += S->nfreq[ii]; S->ipar[ii] = (uint16_t)ni; ++ii; }
+        }
+        S->nfreq[ni] = w;
+    }
+    const uint32_t root = nnz - 2u;
+    S->idep[root] = 0;
+    for (uint32_t k = root; k-- > 0u;) S->idep[k] = (uint16_t)(S->idep[S->ipar[k]] + 1u);
+    for (uint32_t d = 0; d <= maxbits; ++d) S->cnt[d] = 0;
+    bool over = false;
+    for (uint32_t k = 0; k < nnz; ++k) {
+        uint32_t d = S->idep[S->lpar[k]] + 1u;
+        if (d > maxbits) { d = maxbits; over = true; }
+        S->cnt[d]++;
+    }
+    if (over) {
+        // Kraft sum in units of 2^-maxbits; every step below lowers it by exactly one unit:
+        // a leaf at the deepest non-full level d becomes an internal node whose children are that
+        // leaf and one leaf lifted from level maxbits.
+        uint32_t K = 0;
+        for (uint32_t d = 1; d <= maxbits; ++d) K += S->cnt[d] << (maxbits - d);
+        const uint32_t full = 1u << maxbits;
+        while (K > full) {
+            uint32_t d = maxbits - 1u;
+            while (S->cnt[d] == 0u) --d;
+            S->cnt[d]--;
+            S->cnt[d + 1u] += 2u;
+            S->cnt[maxbits]--;
+            --K;
+        }
+    }
+    // rarest symbols get the longest codes
+    uint32_t k = 0;
+    for (uint32_t d = maxbits; d >= 1u; --d)
+        for (uint32_t c = S->cnt[d]; c > 0u; --c) lens[S->order[k++]] = (uint8_t)d;
+}
+
+// ---- lane 0: canonical codes (bit-reversed for LSB-first emission), as gen_codes ----
+static __device__ void enc_gen_codes(EncShared* S, const uint8_t* lens, uint32_t nsym, uint32_t maxbits, uint32_t* table) {
+    for (uint32_t d = 0; d <= maxbits; ++d) S->cnt[d] = 0;
+    for (uint32_t i = 0; i < nsym; ++i) S->cnt[lens[i]]++;
+    S->cnt[0] = 0;
+    uint32_t code = 0;
+    for (uint32_t d = 1; d <= maxbits; ++d) {
+        code = (code + S->cnt[d - 1u]) << 1;
+        S->next[d] = code;
+    }
+    for (uint32_t i = 0; i < nsym; ++i) {
+        uint32_t l = lens[i];
+        if (l) {
+            uint32_t c = S->next[l]++;
+            table[i] = (__brev(c) >> (32u - l)) | (l << 16);
+        } else {
+            table[i] = 0;
+        }
+    }
+}
+
+// ---- lane 0: decide the block type, write its header into the staging window ----
+// returns (in misc) choice: 0 stored, 1 static, 2 dynamic; updates rel for choices 1/2
+static __device__ void enc_block_header(EncShared* S, uint32_t rel, uint32_t is_final, uint32_t stored_bits, uint32_t strategy) {
+    // code-length sequence
+    uint32_t hlit = 286u;
+    while (hlit > 257u && S->llen[hlit - 1u] == 0) --hlit;
+    uint32_t hdist = 30u;
+    while (hdist > 1u && S->dlen[hdist - 1u] == 0) --hdist;
+    const uint32_t total = hlit + hdist;
+    for (uint32_t i = 0; i < ENC_NBL; ++i) S->blfreq[i] = 0;
+    uint32_t hc = 0;
+    uint32_t i = 0;
+    while (i < total) {
+        uint32_t v = i < hlit ? S->llen[i] : S->dlen[i - hlit];
+        uint32_t run = 1;
+        while (i + run < total) {
+            uint32_t u = (i + run) < hlit ? S->llen[i + run] : S->dlen[i + run - hlit];
+            if (u != v) break;
+            ++run;
+        }
+        i += run;
+        if (v == 0u) {
+            while (run >= 11u) { uint32_t r = run > 138u ? 138u : run; S->hsym[hc] = 18; S->hext[hc++] = (uint8_t)(r - 11u); S->blfreq[18]++; run -= r; }
+            if (run >= 3u) { S->hsym[hc] = 17; S->hext[hc++] = (uint8_t)(run - 3u); S->blfreq[17]++; run = 0; }
+            while (run > 0u) { S->hsym[hc] = 0; S->hext[hc++] = 0; S->blfreq[0]++; --run; }
+        } else {
+            S->hsym[hc] = (uint8_t)v; S->hext[hc++] = 0; S->blfreq[v]++; --run;
+            while (run >= 3u) { uint32_t r = run > 6u ? 6u : run; S->hsym[hc] = 16; S->hext[hc++] = (uint8_t)(r - 3u); S->blfreq[16]++; run -= r; }
+            while (run > 0u) { S->hsym[hc] = (uint8_t)v; S->hext[hc++] = 0; S->blfreq[v]++; --run; }
+        }
+    }
+    // code-length code: insertion sort of <= 19 symbols, then the same length builder (limit 7)
+    uint32_t nnz = 0;
+    for (uint32_t s = 0; s < ENC_NBL; ++s) {
+        uint32_t f = S->blfreq[s];
+        if (!f) continue;
+        uint32_t k = nnz++;
+        while (k > 0u && S->blfreq[S->order[k - 1u]] > f) { S->order[k] = S->order[k - 1u]; --k; }
+        S->order[k] = (uint16_t)s;
+    }
+    enc_huff_lengths(S, S->blfreq, ENC_NBL, nnz, 7u, S->bllen);
+    enc_gen_codes(S, S->bllen, ENC_NBL, 7u, S->blcode);
+    const uint8_t blorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint32_t hclen = 19u;
+    while (hclen > 4u && S->bllen[blorder[hclen - 1u]] == 0) --hclen;
+
+    // costs in bits
+    uint32_t dyn = 3u + 14u + 3u * hclen;
+    for (uint32_t s = 0; s < ENC_NBL; ++s) dyn += S->blfreq[s] * S->bllen[s];
+    dyn += S->blfreq[16] * 2u + S->blfreq[17] * 3u + S->blfreq[18] * 7u;
+    uint32_t stat = 3u;
+    for (uint32_t s = 0; s < 286u; ++s) {
+        uint32_t f = S->lfreq[s];
+        if (!f) continue;
+        uint32_t eb = s > 256u ? enc_lext(s - 257u) : 0u;
+        dyn += f * (S->llen[s] + eb);
+        stat += f * (enc_static_llen(s) + eb);
+    }
+    for (uint32_t d = 0; d < 30u; ++d) {
+        uint32_t f = S->dfreq[d];
+        if (!f) continue;
+        uint32_t eb = enc_dext(d);
+        dyn += f * (S->dlen[d] + eb);
+        stat += f * (5u + eb);
+    }
+    uint32_t choice;
+    if (strategy == 100u) choice = 0u;  // level 0: stored blocks only
+    else if (strategy == 4u) choice = (stored_bits < stat) ? 0u : 1u;
+    else if (stored_bits <= dyn && stored_bits <= stat) choice = 0u;
+    else choice = (stat <= dyn) ? 1u : 2u;
+    S->misc[M_CHOICE] = choice;
+    if (choice == 2u) {
+        enc_put0(S, rel, is_final | (2u << 1), 3u);
+        enc_put0(S, rel, hlit - 257u, 5u);
+        enc_put0(S, rel, hdist - 1u, 5u);
+        enc_put0(S, rel, hclen - 4u, 4u);
+        for (uint32_t k = 0; k < hclen; ++k) enc_put0(S, rel, S->bllen[blorder[k]], 3u);
+        for (uint32_t k = 0; k < hc; ++k) {
+            uint32_t s = S->hsym[k];
+            uint32_t c = S->blcode[s];
+            enc_put0(S, rel, c & 0xFFFFu, c >> 16);
+            if (s == 16u) enc_put0(S, rel, S->hext[k], 2u);
+            else if (s == 17u) enc_put0(S, rel, S->hext[k], 3u);
+            else if (s == 18u) enc_put0(S, rel, S->hext[k], 7u);
+        }
+        enc_gen_codes(S, S->llen, 286u, 15u, S->lcode);
+        enc_gen_codes(S, S->dlen, 30u, 15u, S->dcode);
+    } else if (choice == 1u) {
+        enc_put0(S, rel, is_final | (1u << 1), 3u);
+        for (uint32_t s = 0; s < ENC_NL; ++s) S->llen[s] = (uint8_t)enc_static_llen(s);
+        for (uint32_t d = 0; d < ENC_ND; ++d) S->dlen[d] = 5;
+        enc_gen_codes(S, S->llen, ENC_NL, 15u, S->lcode);
+        enc_gen_codes(S, S->dlen, 30u, 15u, S->dcode);
+    }
+    S->misc[M_REL] = rel;
+}
+
+// all lanes: emit one deflate block for tokens [tok, tok+ntok) / raw bytes [bstart, bend)
+static __device__ void enc_flush_block(EncShared* S, EncWriter& W, const uint32_t* tok, uint32_t ntok, const uint8_t* src,
+                                       uint32_t bstart, uint32_t bend, uint32_t is_final, const zmi_enc_params& prm) {
+    const uint32_t lane = zmi_lane();
+    if (lane == 0) S->lfreq[256] += 1u;  // end-of-block
+    zmi_wave_sync();
+    enc_rank_sort(S, S->lfreq, 286u);
+    if (lane == 0) enc_huff_lengths(S, S->lfreq, ENC_NL, S->misc[M_NNZ], 15u, S->llen);
+    zmi_wave_sync();
+    enc_rank_sort(S, S->dfreq, 30u);
+    const uint32_t blen = bend - bstart;
+    const uint32_t nsub = blen ? (blen + 32767u) / 32768u : 1u;
+    if (lane == 0) {
+        enc_huff_lengths(S, S->dfreq, ENC_ND, S->misc[M_NNZ], 15u, S->dlen);
+        enc_block_header(S, W.rel, is_final, 8u * blen + 42u * nsub, prm.strategy);
+    }
+    zmi_wave_sync();
+    const uint32_t choice = S->misc[M_CHOICE];
+    if (choice != 0u) {
+        W.rel = S->misc[M_REL];
+        enc_flush(S, W);
+        // tokens + the end-of-block symbol as virtual token index ntok
+        for (uint32_t base = 0; base <= ntok; base += 64u) {
+            uint32_t i = base + lane;
+            uint64_t bits = 0;
+            uint32_t nb = 0;
+            if (i < ntok) {
+                uint32_t tk = tok[i];
+                uint32_t len = (tk >> 8) & 0x1FFu;
+                if (len == 0u) {
+                    uint32_t c = S->lcode[tk & 0xFFu];
+                    bits = c & 0xFFFFu;
+                    nb = c >> 16;
+                } else {
+                    uint32_t li, leb, lev, di, deb, dev;
+                    enc_len_sym(len, li, leb, lev);
+                    enc_dist_sym((tk >> 17) + 1u, di, deb, dev);
+                    uint32_t lc = S->lcode[257u + li];
+                    uint32_t dc = S->dcode[di];
+                    bits = lc & 0xFFFFu;
+                    nb = lc >> 16;
+                    bits |= (uint64_t)lev << nb;
+                    nb += leb;
+                    bits |= (uint64_t)(dc & 0xFFFFu) << nb;
+                    nb += dc >> 16;
+                    bits |= (uint64_t)dev << nb;
+                    nb += deb;
+                }
+            } else if (i == ntok) {
+                uint32_t c = S->lcode[256];
+                bits = c & 0xFFFFu;
+                nb = c >> 16;
+            }
+            enc_emit_group(S, W, bits, nb);
+        }
+    } else {
+        // stored: sub-blocks of <= 32768 bytes, raw bytes go through the same staging window
+        uint32_t p = bstart;
+        for (uint32_t sb = 0; sb < nsub; ++sb) {
+            uint32_t l = bend - p;
+            if (l > 32768u) l = 32768u;
+            uint32_t fin = (is_final && sb + 1u == nsub) ? 1u : 0u;
+            if (lane == 0) {
+                uint32_t rel = W.rel;
+                enc_put0(S, rel, fin, 3u);
+                rel = (rel + 7u) & ~7u;
+                enc_put0(S, rel, l & 0xFFFFu, 16u);
+                enc_put0(S, rel, (~l) & 0xFFFFu, 16u);
+                S->misc[M_REL] = rel;
+            }
+            zmi_wave_sync();
+            W.rel = S->misc[M_REL];
+            enc_flush(S, W);
+            for (uint32_t base = 0; base < l; base += 256u) {
+                uint32_t o = base + lane * 4u;
+                uint32_t v = 0, nb = 0;
+                for (uint32_t j = 0; j < 4u; ++j)
+                    if (o + j < l) { v |= (uint32_t)src[p + o + j] << (8u * j); nb += 8u; }
+                enc_emit_group(S, W, v, nb);
+            }
+            p += l;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off,
+                                                        const uint32_t* __restrict__ len, uint32_t first_shard,
+                                                        uint32_t* match, uint64_t match_stride,
+                                                        const uint32_t* __restrict__ adler, const uint32_t* __restrict__ crc,
+                                                        uint8_t* __restrict__ out, uint64_t out_stride, uint32_t out_cap,
+                                                        uint32_t* __restrict__ out_len, int32_t* __restrict__ status,
+                                                        zmi_enc_params prm) {
+    __shared__ EncShared Sh;
+    EncShared* S = &Sh;
+    const uint32_t lane = zmi_lane();
+    const uint32_t s = first_shard + blockIdx.x;
+    const uint8_t* src = data + off[s];
+    const uint32_t n = len[s];
+    uint32_t* tokbuf = match + (uint64_t)blockIdx.x * match_stride;
+
+    EncWriter W;
+    W.outw = (uint32_t*)(out + (uint64_t)s * out_stride);
+    W.cap_w = out_cap >> 2;
+    W.wbase = 0;
+    W.rel = 0;
+    W.err = 0;
+
+    for (uint32_t i = lane; i < ENC_STG; i += 64u) S->stg[i] = 0;
+    for (uint32_t i = lane; i < ENC_NL; i += 64u) S->lfreq[i] = 0;
+    if (lane < ENC_ND) S->dfreq[lane] = 0;
+    zmi_wave_sync();
+
+    // stream header
+    if (lane == 0) {
+        uint32_t rel = 0;
+        if (prm.wrap == 1u) {
+            uint32_t lf = prm.level < 2u ? 0u : (prm.level < 6u ? 1u : (prm.level == 6u ? 2u : 3u));
+            uint32_t h = (0x78u << 8) | (lf << 6);
+            h += 31u - (h % 31u);
+            enc_put0(S, rel, h >> 8, 8u);
+            enc_put0(S, rel, h & 0xFFu, 8u);
+        } else if (prm.wrap == 2u) {
+            uint32_t xfl = prm.level == 9u ? 2u : (prm.level < 2u ? 4u : 0u);
+            enc_put0(S, rel, 0x00088B1Fu, 32u);
+            enc_put0(S, rel, 0u, 32u);
+            enc_put0(S, rel, xfl | (3u << 8), 16u);
+        }
+        S->misc[M_REL] = rel;
+    }
+    zmi_wave_sync();
+    W.rel = S->misc[M_REL];
+    enc_flush(S, W);
+
+    if (n == 0u) {
+        // empty input: a final static block holding only end-of-block (as the reference emits: 03 00)
+        if (lane == 0) {
+            uint32_t rel = W.rel;
+            enc_put0(S, rel, 1u | (1u << 1), 3u);
+            enc_put0(S, rel, 0u, 7u);
+            S->misc[M_REL] = rel;
+        }
+        zmi_wave_sync();
+        W.rel = S->misc[M_REL];
+    }
+
+    const uint32_t nseg = (n + 63u) / 64u;
+    uint32_t e = 0;        // entry offset into the current segment (>= 64: segment fully covered by a match)
+    uint32_t ntok = 0;     // tokens of the open block
+    uint32_t tok0 = 0;     // scratch index of the open block's first token (its first segment's position)
+    uint32_t bstart = 0;   // first input byte covered by the open block
+    uint32_t m_cur = (nseg > 0u && lane < n) ? tokbuf[lane] : 0u;
+    for (uint32_t seg = 0; seg < nseg; ++seg) {
+        const uint32_t pos = seg * 64u + lane;
+        uint32_t npos = pos + 64u;
+        uint32_t m_next = (npos < n) ? tokbuf[npos] : 0u;
+        uint32_t first_next = (uint32_t)__shfl((int)m_next, 0);
+        uint32_t m1 = __shfl_down(m_cur, 1u);
+        if (lane == 63u) m1 = first_next;
+        const bool valid = pos < n;
+        uint32_t mlen = (m_cur >> 8) & 0x1FFu;
+        uint32_t mlen1 = (m1 >> 8) & 0x1FFu;
+        uint32_t step = 1u;
+        if (valid && mlen >= 4u && !(mlen < prm.max_lazy && mlen1 > mlen)) step = mlen;
+        if (e < 64u) {
+            uint64_t mask;
+            uint32_t enext;
+            uint64_t anym = __ballot(step > 1u && lane >= e);
+            if (anym == 0ull) {
+                mask = ~0ull << e;
+                enext = 0u;
+            } else {
+                uint32_t J = lane + step;
+                uint32_t Rlo = lane < 32u ? (1u << lane) : 0u;
+                uint32_t Rhi = lane >= 32u ? (1u << (lane - 32u)) : 0u;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) {
+                    uint32_t srcl = J < 64u ? J : lane;
+                    uint32_t Jn = (uint32_t)__shfl((int)J, (int)srcl);
+                    uint32_t Ln = (uint32_t)__shfl((int)Rlo, (int)srcl);
+                    uint32_t Hn = (uint32_t)__shfl((int)Rhi, (int)srcl);
+                    if (J < 64u) { J = Jn; Rlo |= Ln; Rhi |= Hn; }
+                }
+                uint32_t ml = (uint32_t)__shfl((int)Rlo, (int)e);
+                uint32_t mh = (uint32_t)__shfl((int)Rhi, (int)e);
+                mask = ((uint64_t)mh << 32) | ml;
+                enext = (uint32_t)__shfl((int)J, (int)e) - 64u;
+            }
+            mask &= __ballot(valid);
+            const bool in = (mask >> lane) & 1ull;
+            if (in) {
+                uint32_t tk = step > 1u ? m_cur : (m_cur & 0xFFu);
+                tokbuf[tok0 + ntok + zmi_mbcnt(mask)] = tk;
+                if (step > 1u) {
+                    uint32_t li, leb, lev, di, deb, dev;
+                    enc_len_sym(mlen, li, leb, lev);
+                    enc_dist_sym((m_cur >> 17) + 1u, di, deb, dev);
+                    atomicAdd(&S->lfreq[257u + li], 1u);
+                    atomicAdd(&S->dfreq[di], 1u);
+                } else {
+                    atomicAdd(&S->lfreq[m_cur & 0xFFu], 1u);
+                }
+            }
+            ntok += (uint32_t)__popcll(mask);
+            e = enext;
+        } else {
+            e -= 64u;
+        }
+        m_cur = m_next;
+        const uint32_t done = (seg + 1u) * 64u;
+        if (done - tok0 >= prm.block_span || seg + 1u == nseg) {
+            uint32_t bend = done + e;
+            if (bend > n) bend = n;
+            const uint32_t is_final = (seg + 1u == nseg) ? 1u : 0u;
+            __threadfence_block();  // token stores of other lanes must be visible to the encode pass
+            zmi_wave_sync();
+            enc_flush_block(S, W, tokbuf + tok0, ntok, src, bstart, bend, is_final, prm);
+            bstart = bend;
+            tok0 = done;
+            ntok = 0;
+            for (uint32_t i = lane; i < ENC_NL; i += 64u) S->lfreq[i] = 0;
+            if (lane < ENC_ND) S->dfreq[lane] = 0;
+            zmi_wave_sync();
+        }
+    }
+
+    // trailer
+    if (lane == 0) {
+        uint32_t rel = (W.rel + 7u) & ~7u;
+        if (prm.wrap == 1u) {
+            uint32_t a = adler[s];
+            uint32_t be = (a >> 24) | ((a >> 8) & 0xFF00u) | ((a << 8) & 0xFF0000u) | (a << 24);
+            enc_put0(S, rel, be, 32u);
+        } else if (prm.wrap == 2u) {
+            enc_put0(S, rel, crc[s], 32u);
+            enc_put0(S, rel, n, 32u);
+        }
+        S->misc[M_REL] = rel;
+    }
+    zmi_wave_sync();
+    W.rel = S->misc[M_REL];
+    enc_flush(S, W);
+    uint32_t tail = W.rel >> 3;  // 0..3 bytes left in stg[0]
+    uint32_t total = W.wbase * 4u + tail;
+    if (total > out_cap) W.err = 1u;
+    if (lane == 0) {
+        if (!W.err) {
+            uint8_t* ob = (uint8_t*)(W.outw + W.wbase);
+            uint32_t v = S->stg[0];
+            for (uint32_t j = 0; j < tail; ++j) ob[j] = (uint8_t)(v >> (8u * j));
+        }
+        out_len[s] = W.err ? 0u : total;
+        status[s] = W.err ? ZMI_BUF_ERROR : ZMI_OK;
+    }
+}
+
+extern "C" int zmi_launch_encode(const uint8_t* d_data, const uint64_t* d_off, const uint32_t* d_len, uint32_t first_shard,
+                                 uint32_t n_shards, uint32_t* d_match, uint64_t match_stride, const uint32_t* d_adler,
+                                 const uint32_t* d_crc, uint8_t* d_out, uint64_t out_stride, uint32_t out_cap,
+                                 uint32_t* d_out_len, int32_t* d_status, zmi_enc_params prm, hipStream_t stream) {
+    if (n_shards == 0) return 0;
+    if (prm.block_span < 64u) prm.block_span = 64u;
+    prm.block_span &= ~63u;
+    ZMI_LAUNCH(zmi_encode_kernel, dim3(n_shards), dim3(64), 0, stream, d_data, d_off, d_len, first_shard, d_match,
+               match_stride, d_adler, d_crc, d_out, out_stride, out_cap, d_out_len, d_status, prm);
+    return 0;
+}

@@ -1,0 +1,317 @@
+// zmi_api.hip -- host side of the batch C ABI declared in include/zmi355.h.
+//
+// Orchestrates the kernel pipeline on the caller's HIP stream:
+//   deflate:  [checksum] -> lz77 (match per position) -> encode (parse + Huffman + bit pack)
+//   inflate:  inflate -> checksum of the produced bytes -> verify against the trailer
+// Device scratch (4 B per input byte for the match/token array) is owned by the context and the
+// batch is cut into groups that fit it.  No CPU fallback exists: without a HIP device every entry
+// point fails with ZMI_E_NODEVICE.
+#include "zmi_kernels.h"
+#include "../../include/zmi355.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+extern "C" int zmi_launch_inflate_verify(const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                         uint32_t n_streams, uint32_t wrap, const uint32_t* d_check, const uint32_t* d_adler,
+                                         const uint32_t* d_crc, int32_t* d_status, hipStream_t stream);
+
+static thread_local std::string g_err;
+static int zmi_fail(int code, const char* what, hipError_t e = hipSuccess) {
+    char buf[256];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    g_err = buf;
+    return code;
+}
+#define ZMI_HIP(call)                                              \
+    do {                                                           \
+        hipError_t e_ = (call);                                    \
+        if (e_ != hipSuccess) return zmi_fail(ZMI_E_HIP, #call, e_); \
+    } while (0)
+
+struct zmi_buf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct zmi_ctx {
+    int device = 0;
+    uint64_t scratch_limit = 8ull << 30;
+    zmi_buf match;    // u32 per position of the current group
+    zmi_buf sums;     // adler[n] crc[n]
+    zmi_buf inf_tmp;  // in_used[n] check[n] adler[n] crc[n]
+};
+
+static int zmi_reserve(zmi_buf& b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    if (b.p) { (void)hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = (bytes + 0xFFFFFull) & ~(size_t)0xFFFFFull;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) return zmi_fail(ZMI_E_NOMEM, "hipMalloc(scratch)", e);
+    b.cap = want;
+    return 0;
+}
+
+extern "C" const char* zmi_version(void) { return "zmi355 0.1.0 (gfx950; zlib ABI 1.3.0-zlib-rs-0.6.7 compatible)"; }
+extern "C" const char* zmi_last_error(void) { return g_err.c_str(); }
+
+extern "C" int zmi_ctx_create(zmi_ctx** out, int device) {
+    if (!out) return zmi_fail(ZMI_E_ARG, "zmi_ctx_create: null out pointer");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return zmi_fail(ZMI_E_NODEVICE, "no HIP device (this library has no CPU path)", e);
+    if (device < 0 || device >= ndev) return zmi_fail(ZMI_E_ARG, "zmi_ctx_create: device index out of range");
+    ZMI_HIP(hipSetDevice(device));
+    zmi_ctx* c = new zmi_ctx();
+    c->device = device;
+    const char* env = getenv("ZMI_SCRATCH_MB");
+    if (env && atoll(env) > 0) c->scratch_limit = (uint64_t)atoll(env) << 20;
+    *out = c;
+    return ZMI_E_OK;
+}
+
+extern "C" int zmi_ctx_destroy(zmi_ctx* c) {
+    if (!c) return ZMI_E_OK;
+    if (c->match.p) (void)hipFree(c->match.p);
+    if (c->sums.p) (void)hipFree(c->sums.p);
+    if (c->inf_tmp.p) (void)hipFree(c->inf_tmp.p);
+    delete c;
+    return ZMI_E_OK;
+}
+
+extern "C" int zmi_ctx_set_scratch_limit(zmi_ctx* c, uint64_t bytes) {
+    if (!c || bytes < (64ull << 20)) return zmi_fail(ZMI_E_ARG, "scratch limit must be >= 64 MiB");
+    c->scratch_limit = bytes;
+    return ZMI_E_OK;
+}
+
+extern "C" uint64_t zmi_deflate_bound(uint64_t n, int wrap) {
+    // zlib-rs/src/deflate.rs:2975-2991 (compress_bound_help) with wrap overhead 0 / 6 / 18
+    uint64_t w = wrap == ZMI_WRAP_ZLIB ? 6u : (wrap == ZMI_WRAP_GZIP ? 18u : 0u);
+    uint64_t b = n + (n == 0) + (n < 9) + ((n + 7) >> 3) + 3 + w;
+    // this engine's own worst case is a run of stored blocks (5 bytes per 32 KiB) -- far below the above
+    return (b + 15) & ~15ull;
+}
+
+// search / parse effort per level: the MI355X analogue of CONFIGURATION_TABLE
+// (zlib-rs/src/deflate/algorithm/mod.rs:69-82).  Every position is searched in parallel, so the
+// chain budget is what the slowest lane of a wave spends; see DESIGN.md for the measured trade-off.
+struct zmi_level_cfg {
+    uint32_t chain, nice, good, lazy;
+};
+static const zmi_level_cfg kLevels[10] = {
+    {0, 0, 0, 0},         // 0: stored
+    {4, 16, 8, 0},        // 1
+    {6, 32, 8, 0},        // 2
+    {8, 32, 8, 4},        // 3
+    {12, 64, 16, 8},      // 4
+    {16, 64, 16, 16},     // 5
+    {32, 128, 32, 16},    // 6
+    {64, 128, 32, 32},    // 7
+    {128, 258, 64, 128},  // 8
+    {256, 258, 128, 258}, // 9
+};
+
+extern "C" int zmi_checksum_batch_dev(zmi_ctx* c, const void* d_data, const uint64_t* d_off, const uint32_t* d_len,
+                                      uint32_t n, int kind, uint32_t* d_adler, uint32_t* d_crc, void* stream) {
+    if (!c) return zmi_fail(ZMI_E_ARG, "null context");
+    if (n == 0) return ZMI_E_OK;
+    zmi_launch_checksum((const uint8_t*)d_data, d_off, d_len, n, (uint32_t)kind, d_adler, d_crc, (hipStream_t)stream);
+    ZMI_HIP(hipGetLastError());
+    return ZMI_E_OK;
+}
+
+extern "C" int zmi_gen_shards_dev(zmi_ctx* c, void* d_out, uint64_t seed, uint32_t first_shard, uint32_t n_shards,
+                                  uint32_t shard_bytes, void* stream) {
+    if (!c) return zmi_fail(ZMI_E_ARG, "null context");
+    if (shard_bytes % 64u) return zmi_fail(ZMI_E_ARG, "shard_bytes must be a multiple of 64");
+    zmi_launch_gen((uint8_t*)d_out, seed, first_shard, n_shards, shard_bytes, (hipStream_t)stream);
+    ZMI_HIP(hipGetLastError());
+    return ZMI_E_OK;
+}
+
+extern "C" int zmi_deflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                     uint32_t n, uint32_t max_len, int level, int strategy, int wrap, void* d_out,
+                                     uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_) {
+    if (!c) return zmi_fail(ZMI_E_ARG, "null context");
+    if (level == -1) level = 6;
+    if (level < 0 || level > 9) return zmi_fail(ZMI_E_ARG, "level must be -1..9");
+    if (strategy < 0 || strategy > 4) return zmi_fail(ZMI_E_ARG, "strategy must be 0..4");
+    if (wrap < ZMI_WRAP_RAW || wrap > ZMI_WRAP_GZIP) return zmi_fail(ZMI_E_ARG, "wrap must be raw/zlib/gzip");
+    if (out_stride % 16u || out_stride < zmi_deflate_bound(max_len, wrap))
+        return zmi_fail(ZMI_E_ARG, "out_stride must be a multiple of 16 and >= zmi_deflate_bound(max_len)");
+    if (out_stride > 0xFFFFFFF0ull) return zmi_fail(ZMI_E_ARG, "shards larger than 3.5 GiB are not supported");
+    if (n == 0) return ZMI_E_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    ZMI_HIP(hipSetDevice(c->device));
+
+    // wrapper checksums
+    int rc = zmi_reserve(c->sums, (size_t)n * 8u);
+    if (rc) return rc;
+    uint32_t* d_adler = (uint32_t*)c->sums.p;
+    uint32_t* d_crc = d_adler + n;
+    uint32_t kind = wrap == ZMI_WRAP_ZLIB ? 1u : (wrap == ZMI_WRAP_GZIP ? 2u : 0u);
+    if (kind) zmi_launch_checksum((const uint8_t*)d_in, d_in_off, d_in_len, n, kind, d_adler, d_crc, stream);
+
+    const zmi_level_cfg& L = kLevels[level];
+    zmi_lz_params lp;
+    lp.max_chain = L.chain;
+    lp.nice_len = L.nice;
+    lp.good_len = L.good;
+    lp.max_dist = 32768u;  // clamped to the ring-buffer limit by the launcher
+    zmi_enc_params ep;
+    ep.max_lazy = L.lazy;
+    ep.wrap = (uint32_t)wrap;
+    ep.level = (uint32_t)level;
+    ep.block_span = 65536u;
+    ep.strategy = (uint32_t)strategy;
+    if (level == 0) ep.strategy = 100u;           // stored blocks only (deflate_stored)
+    if (strategy == 2) lp.max_chain = 0;          // Z_HUFFMAN_ONLY: literals only
+    if (strategy == 3) lp.max_dist = 1;           // Z_RLE: distance-1 matches only
+    const char* span_env = getenv("ZMI_BLOCK_SPAN");
+    if (span_env && atoi(span_env) >= 64) ep.block_span = (uint32_t)atoi(span_env);
+
+    // match/token scratch: one u32 per position, shards padded to a multiple of 64 positions
+    const uint64_t stride = ((uint64_t)max_len + 63u) & ~63ull;
+    uint64_t per_shard = (stride ? stride : 64u) * 4u;
+    uint64_t group = c->scratch_limit / per_shard;
+    if (group == 0) return zmi_fail(ZMI_E_NOMEM, "scratch limit too small for one shard");
+    if (group > n) group = n;
+    rc = zmi_reserve(c->match, (size_t)(group * per_shard));
+    if (rc) return rc;
+    for (uint64_t first = 0; first < n; first += group) {
+        uint32_t cnt = (uint32_t)((n - first < group) ? (n - first) : group);
+        zmi_launch_lz77((const uint8_t*)d_in, d_in_off, d_in_len, (uint32_t)first, cnt, (uint32_t*)c->match.p, per_shard / 4u,
+                        lp, stream);
+        zmi_launch_encode((const uint8_t*)d_in, d_in_off, d_in_len, (uint32_t)first, cnt, (uint32_t*)c->match.p,
+                          per_shard / 4u, d_adler, d_crc, (uint8_t*)d_out, out_stride, (uint32_t)out_stride, d_out_len,
+                          d_status, ep, stream);
+    }
+    ZMI_HIP(hipGetLastError());
+    return ZMI_E_OK;
+}
+
+extern "C" int zmi_inflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                     uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
+                                     uint32_t* d_out_len, int32_t* d_status, void* stream_) {
+    if (!c) return zmi_fail(ZMI_E_ARG, "null context");
+    if (wrap < ZMI_WRAP_RAW || wrap > ZMI_WRAP_AUTO) return zmi_fail(ZMI_E_ARG, "wrap must be raw/zlib/gzip/auto");
+    if (n == 0) return ZMI_E_OK;
+    hipStream_t stream = (hipStream_t)stream_;
+    ZMI_HIP(hipSetDevice(c->device));
+    int rc = zmi_reserve(c->inf_tmp, (size_t)n * 16u);
+    if (rc) return rc;
+    uint32_t* d_used = (uint32_t*)c->inf_tmp.p;
+    uint32_t* d_check = d_used + n;
+    uint32_t* d_adler = d_check + n;
+    uint32_t* d_crc = d_adler + n;
+    zmi_launch_inflate((const uint8_t*)d_in, d_in_off, d_in_len, n, (uint32_t)wrap, (uint8_t*)d_out, d_out_off, d_out_cap,
+                       d_out_len, d_used, d_check, d_status, stream);
+    if (wrap != ZMI_WRAP_RAW) {
+        uint32_t kind = wrap == ZMI_WRAP_ZLIB ? 1u : (wrap == ZMI_WRAP_GZIP ? 2u : 3u);
+        zmi_launch_checksum((const uint8_t*)d_out, d_out_off, d_out_len, n, kind, d_adler, d_crc, stream);
+        zmi_launch_inflate_verify((const uint8_t*)d_in, d_in_off, d_in_len, n, (uint32_t)wrap, d_check, d_adler, d_crc,
+                                  d_status, stream);
+    }
+    ZMI_HIP(hipGetLastError());
+    return ZMI_E_OK;
+}
+
+// ---------------- host-buffer wrappers ----------------
+struct zmi_dev_alloc {
+    std::vector<void*> ptrs;
+    ~zmi_dev_alloc() { for (void* p : ptrs) (void)hipFree(p); }
+    void* get(size_t bytes) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+        ptrs.push_back(p);
+        return p;
+    }
+};
+
+extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
+                                 int level, int strategy, int wrap, uint8_t* out, uint64_t out_stride, uint32_t* out_len,
+                                 int32_t* status) {
+    if (!c || (!in && n) || !in_off || !in_len || !out || !out_len || !status) return zmi_fail(ZMI_E_ARG, "null argument");
+    if (n == 0) return ZMI_E_OK;
+    ZMI_HIP(hipSetDevice(c->device));
+    // pack the shards back to back on the device, 16-byte aligned starts (fast load path)
+    std::vector<uint64_t> doff(n);
+    uint64_t total = 0;
+    uint32_t max_len = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        doff[i] = total;
+        total += ((uint64_t)in_len[i] + 15u) & ~15ull;
+        if (in_len[i] > max_len) max_len = in_len[i];
+    }
+    if (out_stride % 16u || out_stride < zmi_deflate_bound(max_len, wrap))
+        return zmi_fail(ZMI_E_ARG, "out_stride must be a multiple of 16 and >= zmi_deflate_bound(max_len)");
+    zmi_dev_alloc A;
+    uint8_t* d_in = (uint8_t*)A.get(total + 16);
+    uint64_t* d_off = (uint64_t*)A.get((size_t)n * 8);
+    uint32_t* d_len = (uint32_t*)A.get((size_t)n * 4);
+    uint8_t* d_out = (uint8_t*)A.get((size_t)n * out_stride);
+    uint32_t* d_olen = (uint32_t*)A.get((size_t)n * 4);
+    int32_t* d_st = (int32_t*)A.get((size_t)n * 4);
+    if (!d_in || !d_off || !d_len || !d_out || !d_olen || !d_st) return zmi_fail(ZMI_E_NOMEM, "hipMalloc(batch buffers)");
+    for (uint32_t i = 0; i < n; ++i)
+        if (in_len[i]) ZMI_HIP(hipMemcpy(d_in + doff[i], in + in_off[i], in_len[i], hipMemcpyHostToDevice));
+    ZMI_HIP(hipMemcpy(d_off, doff.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    ZMI_HIP(hipMemcpy(d_len, in_len, (size_t)n * 4, hipMemcpyHostToDevice));
+    int rc = zmi_deflate_batch_dev(c, d_in, d_off, d_len, n, max_len, level, strategy, wrap, d_out, out_stride, d_olen, d_st,
+                                   nullptr);
+    if (rc) return rc;
+    ZMI_HIP(hipDeviceSynchronize());
+    ZMI_HIP(hipMemcpy(out_len, d_olen, (size_t)n * 4, hipMemcpyDeviceToHost));
+    ZMI_HIP(hipMemcpy(status, d_st, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i)
+        if (status[i] == 0 && out_len[i])
+            ZMI_HIP(hipMemcpy(out + (uint64_t)i * out_stride, d_out + (uint64_t)i * out_stride, out_len[i], hipMemcpyDeviceToHost));
+    return ZMI_E_OK;
+}
+
+extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
+                                 int wrap, uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len,
+                                 int32_t* status) {
+    if (!c || (!in && n) || !in_off || !in_len || !out_off || !out_cap || !out_len || !status)
+        return zmi_fail(ZMI_E_ARG, "null argument");
+    if (n == 0) return ZMI_E_OK;
+    ZMI_HIP(hipSetDevice(c->device));
+    std::vector<uint64_t> dioff(n), dooff(n);
+    uint64_t tin = 0, tout = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        dioff[i] = tin;
+        tin += ((uint64_t)in_len[i] + 15u) & ~15ull;
+        dooff[i] = tout;
+        tout += ((uint64_t)out_cap[i] + 15u) & ~15ull;
+    }
+    zmi_dev_alloc A;
+    uint8_t* d_in = (uint8_t*)A.get(tin + 16);
+    uint8_t* d_out = (uint8_t*)A.get(tout + 16);
+    uint64_t* d_ioff = (uint64_t*)A.get((size_t)n * 8);
+    uint64_t* d_ooff = (uint64_t*)A.get((size_t)n * 8);
+    uint32_t* d_ilen = (uint32_t*)A.get((size_t)n * 4);
+    uint32_t* d_ocap = (uint32_t*)A.get((size_t)n * 4);
+    uint32_t* d_olen = (uint32_t*)A.get((size_t)n * 4);
+    int32_t* d_st = (int32_t*)A.get((size_t)n * 4);
+    if (!d_in || !d_out || !d_ioff || !d_ooff || !d_ilen || !d_ocap || !d_olen || !d_st)
+        return zmi_fail(ZMI_E_NOMEM, "hipMalloc(batch buffers)");
+    for (uint32_t i = 0; i < n; ++i)
+        if (in_len[i]) ZMI_HIP(hipMemcpy(d_in + dioff[i], in + in_off[i], in_len[i], hipMemcpyHostToDevice));
+    ZMI_HIP(hipMemcpy(d_ioff, dioff.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    ZMI_HIP(hipMemcpy(d_ooff, dooff.data(), (size_t)n * 8, hipMemcpyHostToDevice));
+    ZMI_HIP(hipMemcpy(d_ilen, in_len, (size_t)n * 4, hipMemcpyHostToDevice));
+    ZMI_HIP(hipMemcpy(d_ocap, out_cap, (size_t)n * 4, hipMemcpyHostToDevice));
+    int rc = zmi_inflate_batch_dev(c, d_in, d_ioff, d_ilen, n, wrap, d_out, d_ooff, d_ocap, d_olen, d_st, nullptr);
+    if (rc) return rc;
+    ZMI_HIP(hipDeviceSynchronize());
+    ZMI_HIP(hipMemcpy(out_len, d_olen, (size_t)n * 4, hipMemcpyDeviceToHost));
+    ZMI_HIP(hipMemcpy(status, d_st, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n; ++i)
+        if (out_len[i] && out_len[i] <= out_cap[i])
+            ZMI_HIP(hipMemcpy(out + out_off[i], d_out + dooff[i], out_len[i], hipMemcpyDeviceToHost));
+    return ZMI_E_OK;
+}

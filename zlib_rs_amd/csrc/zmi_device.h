@@ -1,0 +1,89 @@
+// zmi_device.h -- the handful of device-side primitives every kernel in this directory uses.
+//
+// Product build: hipcc --offload-arch=gfx950 (wave64, CDNA4).  There is no other GPU backend.
+// The only alternative definition of these names is the CPU SIMT emulator used by the kernel
+// unit tests (tests/emu/hip_emu.h, selected with -DZMI_EMU); it is test infrastructure and is
+// never part of libzmi355.so.
+#pragma once
+#include <stdint.h>
+
+#ifdef ZMI_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+// dynamic LDS base must stay 16-byte aligned (guide: Guideline 17)
+#define ZMI_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define ZMI_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    hipLaunchKernelGGL(kernel, (grid), (block), (shmem), (stream), __VA_ARGS__)
+#endif
+
+#define ZMI_WAVE 64
+
+// Orders LDS/global traffic between the lanes of ONE wave (a wave executes in lockstep on the
+// hardware, so this only has to stop the compiler from moving memory operations across it).
+#ifdef ZMI_EMU
+static inline void zmi_wave_sync() { emu::wave_rendezvous(0, false); }
+#else
+static __device__ __forceinline__ void zmi_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+#endif
+
+static __device__ __forceinline__ unsigned zmi_lane() { return threadIdx.x & 63u; }
+static __device__ __forceinline__ unsigned zmi_wave() { return threadIdx.x >> 6; }
+
+// number of set bits of `mask` strictly below this lane
+static __device__ __forceinline__ unsigned zmi_mbcnt(uint64_t mask) {
+    return __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+}
+
+// wave-wide inclusive prefix sum (all 64 lanes must call)
+static __device__ __forceinline__ unsigned zmi_wave_incl_scan(unsigned v) {
+    unsigned lane = zmi_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned t = __shfl_up(v, d);
+        if (lane >= (unsigned)d) v += t;
+    }
+    return v;
+}
+static __device__ __forceinline__ unsigned zmi_wave_sum(unsigned v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+static __device__ __forceinline__ unsigned zmi_wave_max(unsigned v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        unsigned t = __shfl_xor(v, d);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+// unaligned little-endian 32-bit read from a byte array that lives in LDS or global memory:
+// two aligned dword reads + v_alignbyte.  `base` must be 4-byte aligned.
+static __device__ __forceinline__ uint32_t zmi_load32u(const unsigned char* base, uint32_t off) {
+    const uint32_t* w = (const uint32_t*)(base + (off & ~3u));
+    return __builtin_amdgcn_alignbyte(w[1], w[0], off & 3u);
+}
+
+struct zmi_b16 {
+    uint32_t w[4];
+};
+
+// 16 bytes starting at p; bytes past nvalid read as zero.  Fast path needs p 16-byte aligned.
+static __device__ __forceinline__ zmi_b16 zmi_ld16(const uint8_t* p, uint32_t nvalid, bool aligned) {
+    zmi_b16 r;
+    if (aligned && nvalid >= 16u) {
+        const uint4* q = (const uint4*)p;
+        uint4 v = *q;
+        r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
+    } else {
+        r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
+        for (uint32_t i = 0; i < 16u && i < nvalid; ++i) r.w[i >> 2] |= (uint32_t)p[i] << (8u * (i & 3u));
+    }
+    return r;
+}
+

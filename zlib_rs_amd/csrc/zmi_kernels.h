@@ -1,0 +1,49 @@
+// zmi_kernels.h -- launch entry points and parameter blocks shared by the kernels and the host API.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef ZMI_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+
+// match-finder effort (the GPU analogue of CONFIGURATION_TABLE, deflate/algorithm/mod.rs:69-82)
+struct zmi_lz_params {
+    uint32_t max_chain;  // hash-chain links followed per position
+    uint32_t nice_len;   // stop searching once a match this long is found
+    uint32_t good_len;   // halve the remaining chain budget above this length
+    uint32_t max_dist;   // farthest back-reference (<= 32768 - 3*1024 - 16, ring-buffer constraint)
+};
+
+struct zmi_enc_params {
+    uint32_t max_lazy;    // defer a match shorter than this if the next position has a longer one (0 = greedy)
+    uint32_t wrap;        // 0 raw deflate, 1 zlib (RFC 1950), 2 gzip (RFC 1952)
+    uint32_t level;       // only used for the header's level hint bits
+    uint32_t block_span;  // input bytes per deflate block (multiple of 64)
+    uint32_t strategy;    // 0 default, 4 = Z_FIXED (static trees only)
+};
+
+// per-shard result codes written by the kernels (zlib numbering, zlib-rs/src/c_api.rs:140-148)
+#define ZMI_OK 0
+#define ZMI_STREAM_END 1
+#define ZMI_DATA_ERROR (-3)
+#define ZMI_BUF_ERROR (-5)
+
+extern "C" {
+int zmi_launch_gen(uint8_t* d_out, uint64_t seed, uint32_t first_shard, uint32_t n_shards, uint32_t shard_bytes,
+                   hipStream_t stream);
+int zmi_launch_checksum(const uint8_t* d_data, const uint64_t* d_off, const uint32_t* d_len, uint32_t n_shards,
+                        uint32_t kind, uint32_t* d_adler, uint32_t* d_crc, hipStream_t stream);
+int zmi_launch_lz77(const uint8_t* d_data, const uint64_t* d_off, const uint32_t* d_len, uint32_t first_shard,
+                    uint32_t n_shards, uint32_t* d_match, uint64_t match_stride, zmi_lz_params prm, hipStream_t stream);
+int zmi_launch_encode(const uint8_t* d_data, const uint64_t* d_off, const uint32_t* d_len, uint32_t first_shard,
+                      uint32_t n_shards, uint32_t* d_match, uint64_t match_stride, const uint32_t* d_adler,
+                      const uint32_t* d_crc, uint8_t* d_out, uint64_t out_stride, uint32_t out_cap, uint32_t* d_out_len,
+                      int32_t* d_status, zmi_enc_params prm, hipStream_t stream);
+int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n_streams,
+                       uint32_t wrap, uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
+                       uint32_t* d_out_len, uint32_t* d_in_used, uint32_t* d_check, int32_t* d_status,
+                       hipStream_t stream);
+}
