@@ -52,6 +52,12 @@ int zmi_ctx_destroy(zmi_ctx* ctx);
 /* upper bound of scratch the context may allocate on the device (default 8 GiB; env ZMI_SCRATCH_MB) */
 int zmi_ctx_set_scratch_limit(zmi_ctx* ctx, uint64_t bytes);
 
+/* per-kernel HIP-event timing for benchmarking: kernels 0 checksum, 1 lz77, 2 encode, 3 inflate,
+ * 4 verify.  zmi_ctx_get_timing synchronises, returns the sums (ms) / launch counts since the
+ * previous call (arrays of 8) and resets them. */
+int zmi_ctx_set_timing(zmi_ctx* ctx, int on);
+int zmi_ctx_get_timing(zmi_ctx* ctx, double* ms_sums, uint32_t* counts);
+
 /* worst-case compressed size of an n-byte shard; same formula as the reference's compress_bound
  * (zlib-rs/src/deflate.rs:2975-2991) with the wrapper overhead of `wrap`, rounded up to 16. */
 uint64_t zmi_deflate_bound(uint64_t n, int wrap);

@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def engine():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from zlib_rs_amd.engine import Engine
+    e = Engine()
+    yield e
+    e.close()

@@ -1,0 +1,204 @@
+"""GPU parity tests (-m gpu): the HIP path through the C ABI against a conformant CPU inflater /
+deflater on the same seeded inputs.
+
+Deflate direction: compressed bytes need not match the reference (BASELINE.json north_star), the
+bar is that a conformant inflater (system zlib and the oracle restatement) expands every stream
+bit-exactly to the input and that the stream never exceeds compress_bound
+(zlib-rs/src/deflate.rs:2975-2991).  Inflate direction: bit-exact against the CPU inflater,
+including the error codes for corrupt / truncated input (test-libz-rs-sys/src/inflate.rs).
+"""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SHARD = 1 << 20
+
+
+def _to_dev(e, blobs):
+    import torch
+    lens = np.array([len(b) for b in blobs], dtype=np.int32)
+    # 16-byte aligned starts
+    offs = np.zeros(len(blobs), dtype=np.int64)
+    pos = 0
+    for i, b in enumerate(blobs):
+        offs[i] = pos
+        pos += (len(b) + 15) & ~15
+    buf = np.zeros(pos + 16, dtype=np.uint8)
+    for o, b in zip(offs, blobs):
+        buf[o:o + len(b)] = np.frombuffer(b, dtype=np.uint8)
+    return (torch.from_numpy(buf).to(e.device), torch.from_numpy(offs).to(e.device), torch.from_numpy(lens).to(e.device),
+            int(lens.max()) if len(blobs) else 0)
+
+
+def _deflate(e, blobs, level=6, strategy=0, wrap=1):
+    import torch
+    d, off, ln, mx = _to_dev(e, blobs)
+    out, olen, st = e.deflate_batch(d, off, ln, mx, level=level, strategy=strategy, wrap=wrap)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    olen = olen.cpu().numpy()
+    st = st.cpu().numpy()
+    return [bytes(out[i, :olen[i]]) for i in range(len(blobs))], st
+
+
+def _inflate(e, streams, caps, wrap=1):
+    import torch
+    d, off, ln, _ = _to_dev(e, streams)
+    caps = np.array(caps, dtype=np.int32)
+    ooff = np.zeros(len(caps), dtype=np.int64)
+    pos = 0
+    for i, c in enumerate(caps):
+        ooff[i] = pos
+        pos += (int(c) + 15) & ~15
+    out = torch.zeros(pos + 16, dtype=torch.uint8, device=e.device)
+    olen, st = e.inflate_batch(d, off, ln, out, torch.from_numpy(ooff).to(e.device), torch.from_numpy(caps).to(e.device),
+                               wrap=wrap)
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    olen = olen.cpu().numpy()
+    return [bytes(out[ooff[i]:ooff[i] + min(olen[i], caps[i])]) for i in range(len(caps))], st.cpu().numpy()
+
+
+def _gen(e, n, shard=SHARD, first=0):
+    import torch
+    t = e.gen_shards(n, shard, first_shard=first)
+    torch.cuda.synchronize()
+    a = t.cpu().numpy()
+    return [bytes(a[i * shard:(i + 1) * shard]) for i in range(n)]
+
+
+def _dec(stream, wrap):
+    wb = {0: -15, 1: 15, 2: 31}[wrap]
+    return zlib.decompress(stream, wb)
+
+
+def test_generator_matches_cpu_twin(engine):
+    import oracle_lib
+    o = oracle_lib.load()
+    shards = _gen(engine, 16, 1 << 16)
+    for i, s in enumerate(shards):
+        assert s == o.gen_shard(i, 1 << 16), "shard %d differs from the CPU generator" % i
+
+
+@pytest.mark.parametrize("level", [1, 6, 9])
+def test_deflate_roundtrip_full_size(engine, level):
+    shards = _gen(engine, 16)
+    outs, st = _deflate(engine, shards, level=level)
+    assert (st == 0).all()
+    tot = 0
+    for s, o in zip(shards, outs):
+        assert len(o) <= engine.deflate_bound(len(s))
+        assert zlib.decompress(o) == s
+        tot += len(o)
+    ratio = len(shards) * SHARD / tot
+    assert ratio > 1.8, ratio
+
+
+@pytest.mark.parametrize("wrap", [0, 1, 2])
+def test_deflate_edge_sizes(engine, wrap):
+    rng = np.random.default_rng(7)
+    text = _gen(engine, 1, 1 << 16)[0]
+    blobs = [b"", b"a", b"ab", b"abc", b"abcd", b"aaaaa", bytes(1), bytes(5), bytes(300), bytes(70000), text[:63], text[:64],
+             text[:65], text[:1023], text[:1024], text[:1025], text[:4097], text[:33000], text,
+             rng.integers(0, 256, 100000, dtype=np.uint8).tobytes(), b"abcdefgh" * 9000, text[:777] * 40]
+    outs, st = _deflate(engine, blobs, level=6, wrap=wrap)
+    assert (st == 0).all()
+    for b, o in zip(blobs, outs):
+        assert _dec(o, wrap) == b
+        assert len(o) <= engine.deflate_bound(len(b), wrap)
+
+
+@pytest.mark.parametrize("level", list(range(0, 10)))
+def test_deflate_all_levels(engine, level):
+    shards = _gen(engine, 8, 1 << 17)
+    outs, st = _deflate(engine, shards, level=level)
+    assert (st == 0).all()
+    for s, o in zip(shards, outs):
+        assert zlib.decompress(o) == s
+
+
+@pytest.mark.parametrize("strategy", [1, 2, 3, 4])
+def test_deflate_strategies(engine, strategy):
+    shards = _gen(engine, 8, 1 << 16)
+    outs, st = _deflate(engine, shards, level=6, strategy=strategy)
+    assert (st == 0).all()
+    for s, o in zip(shards, outs):
+        assert zlib.decompress(o) == s
+
+
+def test_deflate_unaligned_offsets(engine):
+    import torch
+    base = _gen(engine, 1, 1 << 16)[0]
+    blob = np.frombuffer(base, dtype=np.uint8)
+    d = torch.from_numpy(blob.copy()).to(engine.device)
+    offs = np.array([1, 3, 1001, 4099], dtype=np.int64)
+    lens = np.array([5000, 777, 30000, 20001], dtype=np.int32)
+    out, olen, st = engine.deflate_batch(d, torch.from_numpy(offs).to(engine.device), torch.from_numpy(lens).to(engine.device),
+                                         int(lens.max()))
+    torch.cuda.synchronize()
+    out = out.cpu().numpy()
+    olen = olen.cpu().numpy()
+    assert (st.cpu().numpy() == 0).all()
+    for i in range(4):
+        assert zlib.decompress(bytes(out[i, :olen[i]])) == base[offs[i]:offs[i] + lens[i]]
+
+
+@pytest.mark.parametrize("wrap,level", [(1, 6), (2, 6), (0, 6), (1, 1), (1, 9), (2, 0)])
+def test_inflate_matches_cpu(engine, wrap, level):
+    shards = _gen(engine, 16)
+    wb = {0: -15, 1: 15, 2: 31}[wrap]
+    streams = []
+    for s in shards:
+        co = zlib.compressobj(level, zlib.DEFLATED, wb)
+        streams.append(co.compress(s) + co.flush())
+    outs, st = _inflate(engine, streams, [SHARD] * len(shards), wrap=wrap)
+    assert (st == 0).all(), st
+    for s, o in zip(shards, outs):
+        assert o == s
+
+
+def test_inflate_of_gpu_deflate(engine):
+    shards = _gen(engine, 16)
+    for level in (1, 6, 9):
+        outs, st = _deflate(engine, shards, level=level, wrap=2)
+        assert (st == 0).all()
+        back, st2 = _inflate(engine, outs, [SHARD] * len(shards), wrap=2)
+        assert (st2 == 0).all()
+        assert back == shards
+
+
+def test_inflate_errors(engine):
+    s = _gen(engine, 1, 1 << 16)[0]
+    good = zlib.compress(s, 6)
+    bad_body = bytearray(good)
+    bad_body[200] ^= 0x5A
+    bad_check = bytearray(good)
+    bad_check[-1] ^= 1
+    bad_hdr = bytearray(good)
+    bad_hdr[0] = 0x79
+    streams = [good, bytes(bad_body), bytes(bad_check), bytes(bad_hdr), good[:1000], good, b"\x78\x9c\x07"]
+    caps = [len(s)] * 5 + [100] + [100]
+    outs, st = _inflate(engine, streams, caps, wrap=1)
+    assert st[0] == 0 and outs[0] == s
+    assert st[1] in (-3, -5)            # corrupt body: data error (or runs off the end)
+    assert st[2] == -3                  # "incorrect data check"
+    assert st[3] == -3                  # "incorrect header check"
+    assert st[4] == -5                  # truncated input
+    assert st[5] == -5                  # output buffer too small
+    assert st[6] == -3                  # invalid block type (BTYPE=3)
+
+
+def test_checksums(engine):
+    import torch
+    blobs = [b"", b"a", b"abc", bytes(range(256)) * 300] + _gen(engine, 4, 1 << 16) + _gen(engine, 2)
+    d, off, ln, _ = _to_dev(engine, blobs)
+    a, c = engine.checksums(d, off, ln)
+    torch.cuda.synchronize()
+    a = a.cpu().numpy().astype(np.uint32)
+    c = c.cpu().numpy().astype(np.uint32)
+    for i, b in enumerate(blobs):
+        assert int(a[i]) == zlib.adler32(b), i
+        assert int(c[i]) == zlib.crc32(b), i

@@ -1,0 +1,82 @@
+"""GPU probe: per-kernel timings across levels / batch sizes + determinism check against the CPU emulator.
+Run on the MI355X box through gpurun; writes human-readable lines to stdout."""
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+from zlib_rs_amd.engine import Engine, uniform_layout  # noqa: E402
+
+
+def timing(e):
+    sums = (C.c_double * 8)()
+    cnts = (C.c_uint32 * 8)()
+    e.L.zmi_ctx_get_timing(e._ctx, sums, cnts)
+    return list(sums), list(cnts)
+
+
+def main():
+    e = Engine(0)
+    props = torch.cuda.get_device_properties(0)
+    print("device", props.name, "CUs", props.multi_processor_count, "mem GiB", props.total_memory / 2**30)
+    B = 1 << 20
+    # determinism vs emulator
+    gold = os.path.join(ROOT, "tests", "golden", "emu_deflate_hashes.json")
+    if os.path.exists(gold):
+        g = json.load(open(gold))
+        n, sb = g["n"], g["shard_bytes"]
+        d = e.gen_shards(n, sb)
+        off, ln = uniform_layout(n, sb, e.device)
+        for lvl in g["levels"]:
+            out, olen, st = e.deflate_batch(d, off, ln, sb, level=int(lvl))
+            torch.cuda.synchronize()
+            o = out.cpu().numpy(); l = olen.cpu().numpy()
+            hs = [hashlib.sha1(bytes(o[i, :l[i]])).hexdigest() for i in range(n)]
+            print("emu-vs-gpu level", lvl, "identical" if hs == g["levels"][lvl] else "DIFFERENT",
+                  [int(x) for x in l][:8])
+    e.L.zmi_ctx_set_timing(e._ctx, 1)
+    for S in (256, 2048):
+        data = e.gen_shards(S, B)
+        off, ln = uniform_layout(S, B, e.device)
+        for lvl in (1, 3, 6, 9):
+            out, olen, st = e.deflate_batch(data, off, ln, B, level=lvl)
+            torch.cuda.synchronize()
+            timing(e)
+            t = time.perf_counter()
+            out, olen, st = e.deflate_batch(data, off, ln, B, level=lvl, out=out, out_len=olen, status=st)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t
+            sums, cnts = timing(e)
+            ratio = S * B / float(olen.to(torch.int64).sum().item())
+            print("deflate S=%d L%d: %.2f GiB/s wall  ratio %.3f  ms: checksum %.2f lz77 %.2f encode %.2f" %
+                  (S, lvl, S * B / 2**30 / dt, ratio, sums[0], sums[1], sums[2]))
+            if lvl == 6:
+                # per-class ratio
+                l = olen.cpu().numpy().astype("int64")
+                print("  per-class ratio L6:", ["%.2f" % (B * len(l[c::8]) / l[c::8].sum()) for c in range(8)])
+                # inflate of our own output
+                back = torch.empty(S * B, dtype=torch.uint8, device=e.device)
+                cap = torch.full((S,), B, dtype=torch.int32, device=e.device)
+                ooff = torch.arange(S, dtype=torch.int64, device=e.device) * B
+                coff = torch.arange(S, dtype=torch.int64, device=e.device) * out.stride(0)
+                e.inflate_batch(out, coff, olen, back, ooff, cap)
+                torch.cuda.synchronize(); timing(e)
+                t = time.perf_counter()
+                blen, bst = e.inflate_batch(out, coff, olen, back, ooff, cap)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t
+                sums, cnts = timing(e)
+                print("inflate S=%d: %.2f GiB/s wall  ok=%s  ms: inflate %.2f checksum %.2f" %
+                      (S, S * B / 2**30 / dt, bool(torch.equal(back, data)) and int((bst != 0).sum()) == 0, sums[3], sums[0]))
+        del data
+    e.close()
+
+
+if __name__ == "__main__":
+    main()

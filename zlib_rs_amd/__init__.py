@@ -1,0 +1,13 @@
+"""zlib_rs_amd -- MI355X-native DEFLATE engine behind the zlib C ABI of trifectatechfoundation/zlib-rs.
+
+Only what the deflate/inflate hot path needs lives here:
+  csrc/        hand-written HIP kernels for gfx950 + the C ABI (libzmi355.so)
+  engine.py    device-resident batch API (torch tensors in HBM, HIP stream from torch)
+  zlibmod.py   host-bytes mirror of the reference's one-shot API (compress / decompress / checksums)
+"""
+from ._build import build  # noqa: F401
+
+
+def _engine(*a, **k):
+    from .engine import Engine
+    return Engine(*a, **k)

@@ -37,7 +37,15 @@ struct zmi_buf {
     size_t cap = 0;
 };
 
+struct zmi_timer {
+    hipEvent_t a, b;
+    int kernel;
+};
+enum { ZMI_K_CHECKSUM = 0, ZMI_K_LZ77 = 1, ZMI_K_ENCODE = 2, ZMI_K_INFLATE = 3, ZMI_K_VERIFY = 4, ZMI_K_GEN = 5 };
+
 struct zmi_ctx {
+    bool timing = false;
+    std::vector<zmi_timer> timers;
     int device = 0;
     uint64_t scratch_limit = 8ull << 30;
     zmi_buf match;    // u32 per position of the current group
@@ -82,6 +90,49 @@ extern "C" int zmi_ctx_destroy(zmi_ctx* c) {
     return ZMI_E_OK;
 }
 
+// per-kernel HIP-event timing (used by bench.py for the roofline line; off by default)
+struct zmi_scope_timer {
+    zmi_ctx* c;
+    hipStream_t st;
+    zmi_timer t;
+    bool on;
+    zmi_scope_timer(zmi_ctx* c_, int kernel, hipStream_t st_) : c(c_), st(st_), on(c_->timing) {
+        if (!on) return;
+        t.kernel = kernel;
+        if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(t.a, st);
+    }
+    ~zmi_scope_timer() {
+        if (!on) return;
+        (void)hipEventRecord(t.b, st);
+        c->timers.push_back(t);
+    }
+};
+
+extern "C" int zmi_ctx_set_timing(zmi_ctx* c, int on) {
+    if (!c) return zmi_fail(ZMI_E_ARG, "null context");
+    c->timing = on != 0;
+    return ZMI_E_OK;
+}
+
+// sums[k] = total milliseconds of kernel k since the last call, counts[k] = launches (k < 8)
+extern "C" int zmi_ctx_get_timing(zmi_ctx* c, double* sums, uint32_t* counts) {
+    if (!c || !sums || !counts) return zmi_fail(ZMI_E_ARG, "null argument");
+    for (int k = 0; k < 8; ++k) { sums[k] = 0; counts[k] = 0; }
+    for (zmi_timer& t : c->timers) {
+        (void)hipEventSynchronize(t.b);
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess && t.kernel >= 0 && t.kernel < 8) {
+            sums[t.kernel] += ms;
+            counts[t.kernel]++;
+        }
+        (void)hipEventDestroy(t.a);
+        (void)hipEventDestroy(t.b);
+    }
+    c->timers.clear();
+    return ZMI_E_OK;
+}
+
 extern "C" int zmi_ctx_set_scratch_limit(zmi_ctx* c, uint64_t bytes) {
     if (!c || bytes < (64ull << 20)) return zmi_fail(ZMI_E_ARG, "scratch limit must be >= 64 MiB");
     c->scratch_limit = bytes;
@@ -119,7 +170,10 @@ extern "C" int zmi_checksum_batch_dev(zmi_ctx* c, const void* d_data, const uint
                                       uint32_t n, int kind, uint32_t* d_adler, uint32_t* d_crc, void* stream) {
     if (!c) return zmi_fail(ZMI_E_ARG, "null context");
     if (n == 0) return ZMI_E_OK;
-    zmi_launch_checksum((const uint8_t*)d_data, d_off, d_len, n, (uint32_t)kind, d_adler, d_crc, (hipStream_t)stream);
+    {
+        zmi_scope_timer tm(c, ZMI_K_CHECKSUM, (hipStream_t)stream);
+        zmi_launch_checksum((const uint8_t*)d_data, d_off, d_len, n, (uint32_t)kind, d_adler, d_crc, (hipStream_t)stream);
+    }
     ZMI_HIP(hipGetLastError());
     return ZMI_E_OK;
 }
@@ -154,7 +208,10 @@ extern "C" int zmi_deflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_
     uint32_t* d_adler = (uint32_t*)c->sums.p;
     uint32_t* d_crc = d_adler + n;
     uint32_t kind = wrap == ZMI_WRAP_ZLIB ? 1u : (wrap == ZMI_WRAP_GZIP ? 2u : 0u);
-    if (kind) zmi_launch_checksum((const uint8_t*)d_in, d_in_off, d_in_len, n, kind, d_adler, d_crc, stream);
+    if (kind) {
+        zmi_scope_timer tm(c, ZMI_K_CHECKSUM, stream);
+        zmi_launch_checksum((const uint8_t*)d_in, d_in_off, d_in_len, n, kind, d_adler, d_crc, stream);
+    }
 
     const zmi_level_cfg& L = kLevels[level];
     zmi_lz_params lp;
@@ -184,8 +241,13 @@ extern "C" int zmi_deflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_
     if (rc) return rc;
     for (uint64_t first = 0; first < n; first += group) {
         uint32_t cnt = (uint32_t)((n - first < group) ? (n - first) : group);
-        zmi_launch_lz77((const uint8_t*)d_in, d_in_off, d_in_len, (uint32_t)first, cnt, (uint32_t*)c->match.p, per_shard / 4u,
-                        lp, stream);
+        {
+            zmi_scope_timer tm(c, ZMI_K_LZ77, stream);
+            int lrc = zmi_launch_lz77((const uint8_t*)d_in, d_in_off, d_in_len, (uint32_t)first, cnt, (uint32_t*)c->match.p,
+                                      per_shard / 4u, lp, stream);
+            if (lrc) return zmi_fail(ZMI_E_HIP, "lz77 launch setup", (hipError_t)lrc);
+        }
+        zmi_scope_timer tm2(c, ZMI_K_ENCODE, stream);
         zmi_launch_encode((const uint8_t*)d_in, d_in_off, d_in_len, (uint32_t)first, cnt, (uint32_t*)c->match.p,
                           per_shard / 4u, d_adler, d_crc, (uint8_t*)d_out, out_stride, (uint32_t)out_stride, d_out_len,
                           d_status, ep, stream);
@@ -208,11 +270,18 @@ extern "C" int zmi_inflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_
     uint32_t* d_check = d_used + n;
     uint32_t* d_adler = d_check + n;
     uint32_t* d_crc = d_adler + n;
-    zmi_launch_inflate((const uint8_t*)d_in, d_in_off, d_in_len, n, (uint32_t)wrap, (uint8_t*)d_out, d_out_off, d_out_cap,
-                       d_out_len, d_used, d_check, d_status, stream);
+    {
+        zmi_scope_timer tm(c, ZMI_K_INFLATE, stream);
+        zmi_launch_inflate((const uint8_t*)d_in, d_in_off, d_in_len, n, (uint32_t)wrap, (uint8_t*)d_out, d_out_off, d_out_cap,
+                           d_out_len, d_used, d_check, d_status, stream);
+    }
     if (wrap != ZMI_WRAP_RAW) {
         uint32_t kind = wrap == ZMI_WRAP_ZLIB ? 1u : (wrap == ZMI_WRAP_GZIP ? 2u : 3u);
-        zmi_launch_checksum((const uint8_t*)d_out, d_out_off, d_out_len, n, kind, d_adler, d_crc, stream);
+        {
+            zmi_scope_timer tm(c, ZMI_K_CHECKSUM, stream);
+            zmi_launch_checksum((const uint8_t*)d_out, d_out_off, d_out_len, n, kind, d_adler, d_crc, stream);
+        }
+        zmi_scope_timer tm(c, ZMI_K_VERIFY, stream);
         zmi_launch_inflate_verify((const uint8_t*)d_in, d_in_off, d_in_len, n, (uint32_t)wrap, d_check, d_adler, d_crc,
                                   d_status, stream);
     }

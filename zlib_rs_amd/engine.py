@@ -1,0 +1,102 @@
+"""Device-resident batch deflate / inflate on one MI355X.
+
+torch is plumbing here: it owns the HBM buffers and the HIP stream; all compute is in the
+hand-written HIP kernels of csrc/ reached through the C ABI (include/zmi355.h).
+
+Mirrors the per-stream contract of the reference's C API
+(libz-rs-sys/src/lib.rs: deflateInit2_ :2005, deflate :1281, inflateInit2_ :967, inflate :636):
+every shard is compressed as deflateInit2_(level, Z_DEFLATED, wbits, 8, strategy) +
+deflate(Z_FINISH) would, and the per-shard return code uses zlib's numbering.
+"""
+import torch
+
+from . import _lib
+
+WRAP_RAW, WRAP_ZLIB, WRAP_GZIP, WRAP_AUTO = 0, 1, 2, 3
+GEN_SEED = 0x5A4C4942
+
+
+def _stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Engine:
+    def __init__(self, device=None, scratch_bytes=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("zlib_rs_amd needs an MI355X (no HIP device visible); there is no CPU path")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.L = _lib.lib()
+        import ctypes as C
+        self._ctx = C.c_void_p()
+        _lib.check(self.L.zmi_ctx_create(C.byref(self._ctx), self.device.index), "zmi_ctx_create")
+        if scratch_bytes:
+            _lib.check(self.L.zmi_ctx_set_scratch_limit(self._ctx, int(scratch_bytes)), "zmi_ctx_set_scratch_limit")
+
+    def close(self):
+        if self._ctx:
+            self.L.zmi_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def deflate_bound(self, n, wrap=WRAP_ZLIB):
+        return int(self.L.zmi_deflate_bound(int(n), int(wrap)))
+
+    # ---- synthetic benchmark shards (csrc/shardgen.h) ----
+    def gen_shards(self, n_shards, shard_bytes=1 << 20, first_shard=0, seed=GEN_SEED, out=None):
+        if out is None:
+            out = torch.empty(n_shards * shard_bytes, dtype=torch.uint8, device=self.device)
+        # the generator kernel indexes lines with 32-bit block ids: chunk very large batches
+        step = 16384
+        for s0 in range(0, n_shards, step):
+            cnt = min(step, n_shards - s0)
+            _lib.check(self.L.zmi_gen_shards_dev(self._ctx, out.data_ptr() + s0 * shard_bytes, seed, first_shard + s0, cnt,
+                                                 shard_bytes, _stream_ptr()), "zmi_gen_shards_dev")
+        return out
+
+    # ---- deflate ----
+    def deflate_batch(self, data, offsets, lengths, max_len, level=6, strategy=0, wrap=WRAP_ZLIB, out=None, out_len=None,
+                      status=None):
+        """data: uint8 device tensor; offsets (uint64 as int64) / lengths (uint32 as int32) device tensors.
+        Returns (out [n, stride] uint8, out_len [n] int32, status [n] int32)."""
+        n = int(lengths.numel())
+        stride = self.deflate_bound(max_len, wrap)
+        if out is None:
+            out = torch.empty((n, stride), dtype=torch.uint8, device=self.device)
+        if out_len is None:
+            out_len = torch.empty(n, dtype=torch.int32, device=self.device)
+        if status is None:
+            status = torch.empty(n, dtype=torch.int32, device=self.device)
+        _lib.check(self.L.zmi_deflate_batch_dev(self._ctx, data.data_ptr(), offsets.data_ptr(), lengths.data_ptr(), n,
+                                                int(max_len), int(level), int(strategy), int(wrap), out.data_ptr(),
+                                                out.stride(0) if out.dim() == 2 else stride, out_len.data_ptr(),
+                                                status.data_ptr(), _stream_ptr()), "zmi_deflate_batch_dev")
+        return out, out_len, status
+
+    # ---- inflate ----
+    def inflate_batch(self, data, offsets, lengths, out, out_offsets, out_caps, wrap=WRAP_ZLIB, out_len=None, status=None):
+        n = int(lengths.numel())
+        if out_len is None:
+            out_len = torch.empty(n, dtype=torch.int32, device=self.device)
+        if status is None:
+            status = torch.empty(n, dtype=torch.int32, device=self.device)
+        _lib.check(self.L.zmi_inflate_batch_dev(self._ctx, data.data_ptr(), offsets.data_ptr(), lengths.data_ptr(), n,
+                                                int(wrap), out.data_ptr(), out_offsets.data_ptr(), out_caps.data_ptr(),
+                                                out_len.data_ptr(), status.data_ptr(), _stream_ptr()),
+                   "zmi_inflate_batch_dev")
+        return out_len, status
+
+    # ---- checksums ----
+    def checksums(self, data, offsets, lengths, adler=True, crc=True):
+        n = int(lengths.numel())
+        a = torch.zeros(n, dtype=torch.int32, device=self.device)
+        c = torch.zeros(n, dtype=torch.int32, device=self.device)
+        kind = (1 if adler else 0) | (2 if crc else 0)
+        _lib.check(self.L.zmi_checksum_batch_dev(self._ctx, data.data_ptr(), offsets.data_ptr(), lengths.data_ptr(), n, kind,
+                                                 a.data_ptr(), c.data_ptr(), _stream_ptr()), "zmi_checksum_batch_dev")
+        return a, c
+
+
+def uniform_layout(n, shard_bytes, device):
+    """offsets/lengths tensors for n back-to-back shards of equal size"""
+    off = (torch.arange(n, dtype=torch.int64, device=device) * shard_bytes)
+    ln = torch.full((n,), shard_bytes, dtype=torch.int32, device=device)
+    return off, ln
