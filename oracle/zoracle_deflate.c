@@ -892,16 +892,17 @@ static const struct { uint16_t good, lazy, nice, chain; int func; } config_table
 
 /* one-shot deflate; wrap 0 raw / 1 zlib / 2 gzip; strategy 0 default 1 filtered 2 huffman 3 rle 4 fixed;
  * returns 0 (Z_OK) or -5 (Z_BUF_ERROR) when out_cap is too small */
-int zo_deflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, int level, int wrap, int strategy,
-               int mem_level, size_t* out_len) {
+int zo_deflate2(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, int level, int wrap, int strategy,
+                int mem_level, int wbits, size_t* out_len) {
     if (!tables_ready) tables_init();
     if (level == -1) level = 6;
-    if (level < 0 || level > 9 || mem_level < 1 || mem_level > 9) return -2;
+    if (level < 0 || level > 9 || mem_level < 1 || mem_level > 9 || wbits < 8 || wbits > 15) return -2;
+    if (wbits == 8) wbits = 9; /* deflate.rs:308-312 */
     zst* s = (zst*)calloc(1, sizeof(zst));
     if (!s) return -4;
     s->in = in; s->in_len = in_len; s->out = out; s->out_cap = out_cap;
     s->level = level; s->strategy = strategy; s->wrap = wrap;
-    s->w_size = 32768; s->w_mask = 32767; s->window_size = 65536;
+    s->w_size = 1u << wbits; s->w_mask = s->w_size - 1; s->window_size = 2 * s->w_size;
     s->window = (uint8_t*)calloc(1, s->window_size + 8 + 512);
     s->prev = (uint16_t*)calloc(s->w_size, 2);
     s->head = (uint16_t*)calloc(HASH_SIZE, 2);
@@ -919,7 +920,7 @@ int zo_deflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, i
     /* header: deflate.rs:1572-1601 / :2574-2627 */
     if (wrap == 1) {
         unsigned lf = (strategy >= 2 || level < 2) ? 0 : (level < 6 ? 1 : (level == 6 ? 2 : 3));
-        unsigned h = (0x78u << 8) | (lf << 6);
+        unsigned h = ((8u + ((unsigned)(wbits - 8) << 4)) << 8) | (lf << 6);
         h += 31 - (h % 31);
         put_byte(s, (uint8_t)(h >> 8)); put_byte(s, (uint8_t)h);
     } else if (wrap == 2) {
@@ -948,4 +949,9 @@ int zo_deflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, i
     if (out_len) *out_len = s->out_pos;
     free(s->window); free(s->prev); free(s->head); free(s->sym_buf); free(s);
     return rc;
+}
+
+int zo_deflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, int level, int wrap, int strategy,
+               int mem_level, size_t* out_len) {
+    return zo_deflate2(in, in_len, out, out_cap, level, wrap, strategy, mem_level, 15, out_len);
 }

@@ -62,9 +62,11 @@ static void run_block(dim3 block, unsigned bx, size_t shmem) {
     }
     blockIdx.x = bx; blockIdx.y = 0; blockIdx.z = 0;
     unsigned remaining = n;
-    unsigned long idle_passes = 0;
+    unsigned long idle_passes = 0, spin_passes = 0;
     while (remaining) {
         bool progressed = false;
+        bool real_progress = false;
+        g.pass_counter = g.pass_counter + 1;
         for (unsigned t = 0; t < n; ++t) {
             Fiber& f = g.fibers[t];
             if (f.done) continue;
@@ -74,8 +76,10 @@ static void run_block(dim3 block, unsigned bx, size_t shmem) {
             }
             g.cur = t;
             threadIdx.x = t; threadIdx.y = 0; threadIdx.z = 0;
+            g.last_yield_was_spin = false;
             swapcontext(&g.sched, &f.ctx);
             progressed = true;
+            if (!g.last_yield_was_spin) real_progress = true;
             if (f.done) remaining--;
         }
         if (!progressed) {
@@ -88,6 +92,14 @@ static void run_block(dim3 block, unsigned bx, size_t shmem) {
             }
         } else {
             idle_passes = 0;
+        }
+        if (progressed && !real_progress) {
+            if (++spin_passes > 2000000ul) {
+                fprintf(stderr, "[hip_emu] LIVELOCK in block %u: %u threads only spin-waiting\n", bx, remaining);
+                abort();
+            }
+        } else {
+            spin_passes = 0;
         }
     }
     free(smem);

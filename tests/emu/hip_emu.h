@@ -52,14 +52,15 @@ struct State {
     unsigned cur = 0;
     unsigned char* dyn_smem = nullptr;
     std::function<void()> body;
-    bool shuffle_order = false;
-    uint64_t rng = 0x1234567;
+    volatile int pass_counter = 0;   // bumped once per scheduler pass (spin_yield parks for one pass)
+    bool last_yield_was_spin = false;
 };
 extern State g;
 extern uint3_emu threadIdx, blockIdx;
 extern dim3 blockDim, gridDim;
 
 void yield_wait(volatile int* var, int val);
+// polling loops (LDS flags between waves) must give the other fibers a turn
 void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body);
 
 // rendezvous of all live lanes in the caller's wave; returns generation index used (for vals[])
@@ -82,6 +83,10 @@ inline int wave_rendezvous(uint64_t v, bool p) {
         yield_wait(&w.gen, gen);
     }
     return gen & 1;
+}
+inline void spin_yield() {
+    g.last_yield_was_spin = true;
+    yield_wait(&g.pass_counter, g.pass_counter);
 }
 }  // namespace emu
 

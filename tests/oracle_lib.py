@@ -30,6 +30,9 @@ class Oracle:
             lib.zo_deflate.restype = C.c_int
             lib.zo_deflate.argtypes = [u8p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int,
                                        C.POINTER(C.c_size_t)]
+            lib.zo_deflate2.restype = C.c_int
+            lib.zo_deflate2.argtypes = [u8p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.POINTER(C.c_size_t)]
 
     def adler32(self, data, start=1):
         return self.lib.zo_adler32(start, data, len(data))
@@ -54,11 +57,11 @@ class Oracle:
         rc = self.lib.zo_inflate(data, len(data), out, cap, wrap, C.byref(olen), C.byref(used), C.byref(msg))
         return rc, out.raw[:olen.value], used.value, (msg.value.decode() if msg.value else None)
 
-    def deflate(self, data, level=6, wrap=1, strategy=0, mem_level=8):
-        cap = int(self.lib.zo_compress_bound(len(data), wrap)) + 64
+    def deflate(self, data, level=6, wrap=1, strategy=0, mem_level=8, wbits=15):
+        cap = int(self.lib.zo_compress_bound(len(data), wrap)) + 64 + 5 * (len(data) // 256 + 1)
         out = C.create_string_buffer(cap)
         olen = C.c_size_t(0)
-        rc = self.lib.zo_deflate(data, len(data), out, cap, level, wrap, strategy, mem_level, C.byref(olen))
+        rc = self.lib.zo_deflate2(data, len(data), out, cap, level, wrap, strategy, mem_level, wbits, C.byref(olen))
         return rc, out.raw[:olen.value]
 
 

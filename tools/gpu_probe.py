@@ -41,7 +41,7 @@ def main():
             print("emu-vs-gpu level", lvl, "identical" if hs == g["levels"][lvl] else "DIFFERENT",
                   [int(x) for x in l][:8])
     e.L.zmi_ctx_set_timing(e._ctx, 1)
-    for S in (256, 2048):
+    for S in [int(x) for x in os.environ.get("PROBE_S", "256,2048").split(",")]:
         data = e.gen_shards(S, B)
         off, ln = uniform_layout(S, B, e.device)
         for lvl in (1, 3, 6, 9):

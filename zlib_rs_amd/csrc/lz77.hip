@@ -7,38 +7,82 @@
 //
 // MI355X design (not a translation):
 //   * one 1024-thread workgroup per shard, the whole search state in LDS (131 KiB, 1 workgroup/CU):
-//       win  32 KiB ring of input bytes (+16 mirrored bytes so a dword read may straddle the wrap)
+//       win  32 KiB ring of input bytes (+16 mirrored bytes so an unaligned 8-byte read may
+//            straddle the wrap)
 //       prev 32 Ki x u16 ring: DISTANCE to the previous position with the same hash (0 = end of
-//            chain) -- storing deltas instead of positions removes the reference's slide_hash pass
+//            chain) -- deltas instead of positions remove the reference's slide_hash pass
 //            (deflate/slide_hash.rs) entirely
 //       head 8 Ki x u32: last position+1 per hash bucket
-//   * the shard is consumed in tiles of 1024 positions, ONE barrier per tile, software-pipelined:
-//       during phase k  wave 0  loads tile k+2 from HBM (one coalesced 16 B/lane load),
-//                               inserts tile k+1 into head/prev in position order
-//                               (64 positions per LDS atomic-max; the returned old value IS the
-//                               chain predecessor),
-//                       all waves pull 64-position sub-tiles of tile k from an LDS ticket counter
-//                               and search EVERY position in parallel (one lane = one position;
-//                               the chain walk and the match extension are per-lane loops).
-//   * output: one u32 per position  lit | len<<8 | (dist-1)<<17  (len = 0: no match >= 4),
-//     written coalesced (256 B per wave store).  The parse (greedy/lazy selection) happens in
-//     encode.hip, which sees the best match of every position, not just the visited ones.
-// Bound: LDS bandwidth/latency (random 4-byte window reads), not HBM: algorithmic HBM traffic is
+//   * NO workgroup barrier in the steady state.  Wave 0 is the PRODUCER: it streams the shard from
+//     HBM (one coalesced 16 B/lane load per 1 KiB), inserts 64 positions per step into head/prev
+//     (LDS atomic-max; the returned old value is the chain predecessor) and publishes a `ready`
+//     frontier.  It is throttled only by the ring: it may not overwrite bytes that the oldest
+//     in-flight search can still reference.
+//   * Waves 1..15 are SEARCHERS.  Every lane runs two independent match-search state machines
+//     ("slots"); each loop iteration issues one round of LDS reads per slot (8 window bytes at the
+//     candidate, 8 more for extension/tail, the prev link) and advances the slot by one step:
+//         INIT -> CHAIN (one hash-chain candidate per step) -> EXTEND (8 bytes per step) -> done.
+//     A finished slot is refilled from a shared position counter, so a wave's cost follows the
+//     AVERAGE chain length of its positions, not the maximum (the SIMT analogue of the CPU loop's
+//     early exits), and the two slots per lane double the LDS requests in flight (the profile of
+//     the first version was latency-bound: LDS pipe 24 % busy, 61 % of wave cycles waiting).
+//   * output: one u32 per position  lit | len<<8 | (dist-1)<<17  (len = 0: no match >= 4).
+//     The parse (greedy/lazy selection) happens in encode.hip, which sees the best match of every
+//     position, not just the visited ones.
+// Bound: LDS latency / VALU issue (random window reads), not HBM: algorithmic HBM traffic is
 // 1 B read + 4 B scratch written per input byte.
 #include "zmi_device.h"
 #include "zmi_kernels.h"
 
 #define LZ_T 1024u
 #define LZ_SUB (LZ_T / 64u)
+#define LZ_NW 16u
 #define LZ_WSIZE 32768u
 #define LZ_WMASK 32767u
 #define LZ_HBITS 13
 #define LZ_HSIZE (1u << LZ_HBITS)
 #define LZ_MIRROR 16u
-#define LZ_SMEM (LZ_WSIZE + LZ_MIRROR + 2u * LZ_WSIZE + 4u * LZ_HSIZE + 16u)
+#define LZ_CTL 128u
+#define LZ_SMEM (LZ_WSIZE + LZ_MIRROR + 2u * LZ_WSIZE + 4u * LZ_HSIZE + LZ_CTL)
+#define LZ_REFILL_MIN 24u
+
+struct LzCtl {
+    uint32_t ready;  // positions < ready are searchable (chain built, look-ahead bytes loaded)
+    uint32_t next;   // next unclaimed position
+    uint32_t pad[2];
+    uint32_t wmin[LZ_NW];  // per wave: lower bound of its oldest in-flight position
+};
+
+#ifdef ZMI_EMU
+static inline uint32_t lz_ld_acq(uint32_t* p) { return *p; }
+static inline void lz_st_rel(uint32_t* p, uint32_t v) { *p = v; }
+static inline void lz_pause() { emu::spin_yield(); }
+#else
+static __device__ __forceinline__ uint32_t lz_ld_acq(uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+static __device__ __forceinline__ void lz_st_rel(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+static __device__ __forceinline__ void lz_pause() { __builtin_amdgcn_s_sleep(4); }
+#endif
 
 static __device__ __forceinline__ uint32_t lz_ring32(const uint8_t* win, uint32_t pos) {
     return zmi_load32u(win, pos & LZ_WMASK);
+}
+// 8 bytes at ring position pos (unaligned): three aligned dwords + two v_alignbyte
+static __device__ __forceinline__ void lz_ring64(const uint8_t* win, uint32_t pos, uint32_t& lo, uint32_t& hi) {
+    uint32_t r = pos & LZ_WMASK;
+    const uint32_t* w = (const uint32_t*)(win + (r & ~3u));
+    uint32_t a = w[0], b = w[1], c = w[2];
+    lo = __builtin_amdgcn_alignbyte(b, a, r & 3u);
+    hi = __builtin_amdgcn_alignbyte(c, b, r & 3u);
+}
+// number of equal leading bytes (0..8) given the XOR of two 8-byte strings
+static __device__ __forceinline__ uint32_t lz_match8(uint32_t xlo, uint32_t xhi) {
+    if (xlo) return (uint32_t)(__ffs(xlo) - 1) >> 3;
+    if (xhi) return 4u + ((uint32_t)(__ffs(xhi) - 1) >> 3);
+    return 8u;
 }
 
 static __device__ __forceinline__ void lz_store_chunk(uint8_t* win, uint32_t pos, const zmi_b16& v) {
@@ -49,73 +93,43 @@ static __device__ __forceinline__ void lz_store_chunk(uint8_t* win, uint32_t pos
     if (r == 0) *(uint4*)(win + LZ_WSIZE) = q;
 }
 
-// insert the 1024 positions of one tile into head/prev, in position order (one wave)
+// insert the 1024 positions of one tile into head/prev in position order (one wave, 16 steps of 64;
+// the three phases let the LDS reads, the atomics and the prev stores of all steps pipeline)
 static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_t* prev, uint32_t* head, uint32_t tile,
                                                      uint32_t n, uint32_t max_dist) {
     const uint32_t lane = zmi_lane();
-#pragma unroll 4
+    uint32_t hv[LZ_SUB];
+#pragma unroll
     for (uint32_t s = 0; s < LZ_SUB; ++s) {
         uint32_t p = tile * LZ_T + s * 64u + lane;
-        uint32_t delta = 0;
-        if (p + 4u <= n) {
-            uint32_t v = lz_ring32(win, p);
-            uint32_t h = (v * 2654435761u) >> (32 - LZ_HBITS);  // multiplier as hash_calc.rs:30-33
-            uint32_t old = atomicMax(&head[h], p + 1u);
-            if (old != 0u && old <= p) {
-                uint32_t d = p + 1u - old;
-                if (d <= max_dist) delta = d;
-            }
+        uint32_t v = lz_ring32(win, p);
+        hv[s] = (v * 2654435761u) >> (32 - LZ_HBITS);  // multiplier as hash_calc.rs:30-33
+    }
+#pragma unroll
+    for (uint32_t s = 0; s < LZ_SUB; ++s) {
+        uint32_t p = tile * LZ_T + s * 64u + lane;
+        uint32_t old = 0;
+        if (p + 4u <= n) old = atomicMax(&head[hv[s]], p + 1u);
+        hv[s] = old;
+        zmi_wave_sync();  // steps are position-ordered (no-op on hardware: one wave, in-order LDS)
+    }
+#pragma unroll
+    for (uint32_t s = 0; s < LZ_SUB; ++s) {
+        uint32_t p = tile * LZ_T + s * 64u + lane;
+        uint32_t old = hv[s], delta = 0;
+        if (old != 0u && old <= p) {
+            uint32_t d = p + 1u - old;
+            if (d <= max_dist) delta = d;
         }
         prev[p & LZ_WMASK] = (uint16_t)delta;
-        zmi_wave_sync();  // steps are position-ordered (no-op on hardware: the wave runs in lockstep)
     }
 }
 
-static __device__ __forceinline__ uint32_t lz_search(const uint8_t* win, const uint16_t* prev, uint32_t p, uint32_t n,
-                                                     const zmi_lz_params& prm) {
-    uint32_t res = win[p & LZ_WMASK];
-    uint32_t maxlen = n - p;
-    if (maxlen > 258u) maxlen = 258u;
-    if (maxlen >= 4u) {
-        const uint32_t my4 = lz_ring32(win, p);
-        uint32_t delta = prev[p & LZ_WMASK];
-        uint32_t cand = p - delta;
-        uint32_t blen = 3u, bdist = 0u;
-        uint32_t tail = my4;
-        uint32_t chain = prm.max_chain;
-        while (delta != 0u && chain != 0u) {
-            --chain;
-            uint32_t dist = p - cand;
-            if (dist > prm.max_dist) break;
-            if (lz_ring32(win, cand + blen - 3u) == tail && (blen == 3u || lz_ring32(win, cand) == my4)) {
-                uint32_t l = 4u;
-                for (;;) {
-                    if (l + 4u > maxlen) {
-                        while (l < maxlen && win[(p + l) & LZ_WMASK] == win[(cand + l) & LZ_WMASK]) ++l;
-                        break;
-                    }
-                    uint32_t x = lz_ring32(win, p + l) ^ lz_ring32(win, cand + l);
-                    if (x) {
-                        l += (uint32_t)(__ffs(x) - 1) >> 3;
-                        break;
-                    }
-                    l += 4u;
-                }
-                if (l > blen) {
-                    blen = l;
-                    bdist = dist;
-                    if (l >= prm.nice_len || l >= maxlen) break;
-                    tail = lz_ring32(win, p + blen - 3u);
-                    if (l >= prm.good_len) chain >>= 1;
-                }
-            }
-            delta = prev[cand & LZ_WMASK];
-            cand -= delta;
-        }
-        if (blen >= 4u) res |= (blen << 8) | ((bdist - 1u) << 17);
-    }
-    return res;
-}
+enum { LZ_EMPTY = 0, LZ_INIT = 1, LZ_CHAIN = 2, LZ_EXTEND = 3, LZ_TAIL = 4 };
+
+struct LzSlot {
+    uint32_t p, cand, blen, bdist, chain, maxlen, mylo, myhi, tail, xlen, xd, mode;
+};
 
 __global__ void __launch_bounds__(1024) zmi_lz77_kernel(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off,
                                                         const uint32_t* __restrict__ len, uint32_t first_shard,
@@ -125,7 +139,7 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel(const uint8_t* __restric
     uint8_t* win = smem;
     uint16_t* prev = (uint16_t*)(smem + LZ_WSIZE + LZ_MIRROR);
     uint32_t* head = (uint32_t*)(smem + LZ_WSIZE + LZ_MIRROR + 2u * LZ_WSIZE);
-    uint32_t* ctr = head + LZ_HSIZE;
+    LzCtl* ctl = (LzCtl*)(head + LZ_HSIZE);
 
     const uint32_t t = threadIdx.x;
     const uint32_t lane = zmi_lane();
@@ -138,37 +152,195 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel(const uint8_t* __restric
     const uint32_t ntiles = (n + LZ_T - 1u) / LZ_T;
     if (ntiles == 0) return;
 
-    // prologue: clear head, load bytes [0, 2T+16), build tile 0
     for (uint32_t i = t; i < LZ_HSIZE; i += 1024u) head[i] = 0u;
-    if (t < 2u) ctr[t] = 0u;
-    if (t < (2u * LZ_T + 16u) / 16u) {
-        uint32_t c = t * 16u;
-        zmi_b16 v = zmi_ld16(src + c, c < n ? n - c : 0u, aligned);
-        lz_store_chunk(win, c, v);
-    }
-    __syncthreads();
-    if (wave == 0) lz_build_tile(win, prev, head, 0u, n, prm.max_dist);
+    if (t == 0) { ctl->ready = 0u; ctl->next = 0u; }
+    if (t < LZ_NW) ctl->wmin[t] = 0xFFFFFFFFu;
     __syncthreads();
 
-    for (uint32_t k = 0; k < ntiles; ++k) {
-        if (wave == 0) {
-            // bytes available at phase start: [0, (k+2)T+16); fetch the next T
-            uint32_t c = (k + 2u) * LZ_T + 16u + lane * 16u;
-            zmi_b16 v = zmi_ld16(src + c, c < n ? n - c : 0u, aligned);
-            if (k + 1u < ntiles) lz_build_tile(win, prev, head, k + 1u, n, prm.max_dist);
-            lz_store_chunk(win, c, v);
-            if (lane == 0) ctr[(k + 1u) & 1u] = 0u;
+    if (wave == 0) {
+        // ---------------- producer ----------------
+        for (uint32_t k = 0; k < ntiles; ++k) {
+            const uint32_t E = (k + 2u) * LZ_T + 16u;  // bytes [0, E) must be resident after this round
+            // ring throttle: byte E-1 lands on the slot of byte E-1-32768, which the oldest in-flight
+            // search (position q) may still read while q - max_dist <= E-1-32768
+            for (;;) {
+                uint32_t v = 0xFFFFFFFFu;
+                if (lane < LZ_NW) v = lz_ld_acq(&ctl->wmin[lane]);
+                else if (lane == LZ_NW) v = lz_ld_acq(&ctl->next);
+                uint32_t m = v;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    uint32_t o = __shfl_xor(m, d);
+                    m = o < m ? o : m;
+                }
+                if ((uint64_t)E + prm.max_dist <= (uint64_t)m + LZ_WSIZE) break;
+                lz_pause();
+            }
+            if (k == 0) {
+                for (uint32_t c = lane * 16u; c < LZ_T + 16u; c += 1024u) {
+                    zmi_b16 v = zmi_ld16(src + c, c < n ? n - c : 0u, aligned);
+                    lz_store_chunk(win, c, v);
+                }
+            }
+            {
+                uint32_t c = (k + 1u) * LZ_T + 16u + lane * 16u;
+                zmi_b16 v = zmi_ld16(src + c, c < n ? n - c : 0u, aligned);
+                lz_store_chunk(win, c, v);
+            }
+            zmi_wave_sync();
+            lz_build_tile(win, prev, head, k, n, prm.max_dist);
+            zmi_wave_sync();
+            uint32_t r = (k + 1u) * LZ_T;
+            if (r > n) r = n;
+            if (lane == 0) lz_st_rel(&ctl->ready, r);
         }
-        for (;;) {
-            uint32_t sub = 0;
-            if (lane == 0) sub = atomicAdd(&ctr[k & 1u], 1u);
-            sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)sub);
-            if (sub >= LZ_SUB) break;
-            uint32_t p = k * LZ_T + sub * 64u + lane;
-            if (p < n) mout[p] = lz_search(win, prev, p, n, prm);
-        }
-        __syncthreads();
+        return;
     }
+
+    // ---------------- searchers ----------------
+    LzSlot S[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        S[q].mode = LZ_EMPTY; S[q].p = 0; S[q].cand = 0; S[q].blen = 0; S[q].bdist = 0; S[q].chain = 0; S[q].maxlen = 0;
+        S[q].mylo = 0; S[q].myhi = 0; S[q].tail = 0; S[q].xlen = 0; S[q].xd = 0;
+    }
+    bool exhausted = false;
+    uint32_t amin = 0xFFFFFFFFu;  // published lower bound of this wave's oldest active position
+    for (;;) {
+        // ---- refill empty slots from the shared position counter ----
+        const uint64_t e0 = __ballot(S[0].mode == LZ_EMPTY);
+        const uint64_t e1 = __ballot(S[1].mode == LZ_EMPTY);
+        const uint32_t n0 = (uint32_t)__popcll(e0), n1 = (uint32_t)__popcll(e1);
+        const uint32_t nempty = n0 + n1;
+        if (exhausted && nempty == 128u) break;
+        if (!exhausted && nempty >= LZ_REFILL_MIN) {
+            uint32_t base = 0;
+            if (lane == 0) {
+                uint32_t tnext = lz_ld_acq(&ctl->next);
+                uint32_t lb = tnext < amin ? tnext : amin;
+                lz_st_rel(&ctl->wmin[wave], lb);  // published BEFORE the claim
+                base = atomicAdd(&ctl->next, nempty);
+            }
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            uint32_t cnt = 0;
+            if (base < n) cnt = (n - base < nempty) ? n - base : nempty;
+            if (base + nempty >= n) exhausted = true;
+            const uint32_t r0 = zmi_mbcnt(e0), r1 = n0 + zmi_mbcnt(e1);
+            if (S[0].mode == LZ_EMPTY && r0 < cnt) { S[0].p = base + r0; S[0].mode = LZ_INIT; }
+            if (S[1].mode == LZ_EMPTY && r1 < cnt) { S[1].p = base + r1; S[1].mode = LZ_INIT; }
+            uint32_t m = 0xFFFFFFFFu;
+            if (S[0].mode != LZ_EMPTY) m = S[0].p;
+            if (S[1].mode != LZ_EMPTY && S[1].p < m) m = S[1].p;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                uint32_t o = __shfl_xor(m, d);
+                m = o < m ? o : m;
+            }
+            amin = m;
+            if (lane == 0) lz_st_rel(&ctl->wmin[wave], amin);
+        }
+        const uint32_t ready = lz_ld_acq(&ctl->ready);
+
+        // ---- one step per slot ----
+        bool finished_min = false;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            LzSlot& Z = S[q];
+            const uint32_t mode = Z.mode;
+            if (mode == LZ_EMPTY) continue;
+            if (mode == LZ_INIT && Z.p >= ready) continue;  // producer has not reached this position yet
+            // addresses of this step's reads
+            uint32_t aA, aB = 0;
+            bool needB = false, needC = false;
+            if (mode == LZ_INIT) { aA = Z.p; needC = true; }
+            else if (mode == LZ_CHAIN) { aA = Z.cand; needC = true; if (Z.blen >= 8u) { aB = Z.cand + Z.blen - 3u; needB = true; } }
+            else if (mode == LZ_EXTEND) { aA = Z.p + Z.xlen; aB = Z.cand + Z.xlen; needB = true; }
+            else { aA = Z.p + Z.blen - 3u; }
+            uint32_t alo, ahi, blo = 0, bhi = 0, cd = 0;
+            lz_ring64(win, aA, alo, ahi);
+            if (needB) lz_ring64(win, aB, blo, bhi);
+            if (needC) cd = prev[(mode == LZ_INIT ? Z.p : Z.cand) & LZ_WMASK];
+
+            bool fin = false;        // slot done
+            bool adv = false;        // follow the chain link advd from node advfrom
+            uint32_t advfrom = 0, advd = 0;
+            if (mode == LZ_INIT) {
+                Z.mylo = alo; Z.myhi = ahi;
+                uint32_t ml = n - Z.p;
+                Z.maxlen = ml > 258u ? 258u : ml;
+                Z.blen = 3u; Z.bdist = 0u; Z.chain = prm.max_chain;
+                if (Z.maxlen < 4u) fin = true;
+                else { adv = true; advfrom = Z.p; advd = cd; }
+            } else if (mode == LZ_CHAIN) {
+                const uint32_t m8 = lz_match8(alo ^ Z.mylo, ahi ^ Z.myhi);
+                bool ext = false;
+                if (Z.blen < 8u) {
+                    if (m8 == 8u && Z.maxlen > 8u) ext = true;
+                    else {
+                        uint32_t l = m8 < Z.maxlen ? m8 : Z.maxlen;
+                        if (l > Z.blen) {
+                            Z.blen = l; Z.bdist = Z.p - Z.cand;
+                            if (l >= prm.nice_len || l >= Z.maxlen) fin = true;
+                            else if (l >= prm.good_len) Z.chain >>= 1;
+                        }
+                    }
+                } else if (m8 == 8u && blo == Z.tail) {
+                    ext = true;
+                }
+                if (ext) { Z.mode = LZ_EXTEND; Z.xlen = 8u; Z.xd = cd; }
+                else if (!fin) { adv = true; advfrom = Z.cand; advd = cd; }
+            } else if (mode == LZ_EXTEND) {
+                const uint32_t m8 = lz_match8(alo ^ blo, ahi ^ bhi);
+                Z.xlen += m8;
+                if (!(m8 == 8u && Z.xlen < Z.maxlen)) {
+                    uint32_t l = Z.xlen < Z.maxlen ? Z.xlen : Z.maxlen;
+                    bool better = l > Z.blen;
+                    if (better) {
+                        Z.blen = l; Z.bdist = Z.p - Z.cand;
+                        if (l >= prm.nice_len || l >= Z.maxlen) fin = true;
+                        else if (l >= prm.good_len) Z.chain >>= 1;
+                    }
+                    if (!fin) {
+                        adv = true; advfrom = Z.cand; advd = Z.xd;
+                        Z.mode = (better && Z.blen >= 8u) ? LZ_TAIL : LZ_CHAIN;
+                    }
+                }
+            } else {  // LZ_TAIL: refresh the 4 bytes ending at the best length, then resume the chain
+                Z.tail = alo;
+                Z.mode = LZ_CHAIN;
+            }
+            if (adv) {
+                if (advd == 0u || Z.chain == 0u) fin = true;
+                else {
+                    Z.chain -= 1u;
+                    Z.cand = advfrom - advd;
+                    if (Z.p - Z.cand > prm.max_dist) fin = true;
+                    else if (Z.mode == LZ_INIT) Z.mode = LZ_CHAIN;
+                }
+            }
+            if (fin) {
+                uint32_t res = Z.mylo & 0xFFu;
+                if (Z.blen >= 4u) res |= (Z.blen << 8) | ((Z.bdist - 1u) << 17);
+                mout[Z.p] = res;
+                if (Z.p == amin) finished_min = true;
+                Z.mode = LZ_EMPTY;
+            }
+        }
+        // the wave's oldest position retired: publish the new lower bound so the producer can move on
+        if (__ballot(finished_min)) {
+            uint32_t m = 0xFFFFFFFFu;
+            if (S[0].mode != LZ_EMPTY) m = S[0].p;
+            if (S[1].mode != LZ_EMPTY && S[1].p < m) m = S[1].p;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                uint32_t o = __shfl_xor(m, d);
+                m = o < m ? o : m;
+            }
+            amin = m;
+            if (lane == 0) lz_st_rel(&ctl->wmin[wave], amin);
+        }
+    }
+    if (lane == 0) lz_st_rel(&ctl->wmin[wave], 0xFFFFFFFFu);
 }
 
 extern "C" int zmi_launch_lz77(const uint8_t* d_data, const uint64_t* d_off, const uint32_t* d_len, uint32_t first_shard,
