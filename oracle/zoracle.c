@@ -368,11 +368,15 @@ int zo_inflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, i
         b.pos += 4;
         if (want != zo_adler32(1, out, op)) ZO_FAIL(ZO_DATA_ERROR, "incorrect data check");
     } else if (kind == 2) {
-        if (b.pos + 8 > b.n) ZO_FAIL(ZO_BUF_ERROR, NULL);
+        /* the check value is verified as soon as its 4 bytes are there, the length after 4 more
+         * (inflate.rs:1398-1430 then :1814-1831) */
+        if (b.pos + 4 > b.n) ZO_FAIL(ZO_BUF_ERROR, NULL);
         uint32_t want = in[b.pos] | ((uint32_t)in[b.pos + 1] << 8) | ((uint32_t)in[b.pos + 2] << 16) | ((uint32_t)in[b.pos + 3] << 24);
-        uint32_t isz = in[b.pos + 4] | ((uint32_t)in[b.pos + 5] << 8) | ((uint32_t)in[b.pos + 6] << 16) | ((uint32_t)in[b.pos + 7] << 24);
-        b.pos += 8;
+        b.pos += 4;
         if (want != zo_crc32(0, out, op)) ZO_FAIL(ZO_DATA_ERROR, "incorrect data check");
+        if (b.pos + 4 > b.n) ZO_FAIL(ZO_BUF_ERROR, NULL);
+        uint32_t isz = in[b.pos] | ((uint32_t)in[b.pos + 1] << 8) | ((uint32_t)in[b.pos + 2] << 16) | ((uint32_t)in[b.pos + 3] << 24);
+        b.pos += 4;
         if (isz != (uint32_t)op) ZO_FAIL(ZO_DATA_ERROR, "incorrect length check");
     }
     rc = ZO_STREAM_END;

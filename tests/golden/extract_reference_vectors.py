@@ -293,3 +293,44 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ---------------------------------------------------------------------------------------------
+# inflate direction: hand-made bitstreams of test-libz-rs-sys/src/inflate.rs (try_inflate) and the
+# small binary fixtures of test-libz-rs-sys/src/test-data (copied as data, with their expected
+# CRC-32 / length computed by system zlib here).
+# ---------------------------------------------------------------------------------------------
+def extract_inflate():
+    import base64
+    import zlib as _z
+    vec = []
+    src = strip_comments(open(os.path.join(REF, "test-libz-rs-sys/src/inflate.rs"), encoding="utf-8").read())
+    for name, body in function_spans(src):
+        m = re.search(r"try_inflate\(\s*(&\[[^\]]*\])\s*,\s*(Z_\w+)\s*,?\s*\)", body, re.S)
+        if not m or name in ("try_inflate",):
+            continue
+        data = parse_bytes(m.group(1), {})
+        expect = m.group(2)
+        # try_inflate(): expected_err >= 0 -> raw inflate (windowBits -15); a non-Z_OK expectation
+        # means inflate() must return Z_DATA_ERROR (test-libz-rs-sys/src/inflate.rs:633-690)
+        vec.append({"source": "test-libz-rs-sys/src/inflate.rs:%s" % name, "wrap": 0 if expect in ("Z_OK", "Z_STREAM_END") else 3,
+                    "input": data.hex(), "expect": "ok" if expect == "Z_OK" else "data_error"})
+    files = []
+    td = os.path.join(REF, "test-libz-rs-sys/src/test-data")
+    fixtures = [("window-match-bug.zraw", 0), ("op-len-edge-case.zraw", 0), ("text.gz", 2), ("issue-109.gz", 2)]
+    fixtures += [("compression-corpus/" + f, 2) for f in sorted(os.listdir(os.path.join(td, "compression-corpus")))]
+    for rel, wrap in fixtures:
+        raw = open(os.path.join(td, rel), "rb").read()
+        out = _z.decompress(raw, {0: -15, 2: 31}[wrap])
+        files.append({"source": "test-libz-rs-sys/src/test-data/" + rel, "wrap": wrap, "data_b64": base64.b64encode(raw).decode(),
+                      "out_len": len(out), "out_crc32": _z.crc32(out), "out_adler32": _z.adler32(out)})
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "inflate_vectors.json")
+    json.dump({"reference": "trifectatechfoundation/zlib-rs v0.6.7 (/root/reference)", "bitstreams": vec, "files": files},
+              open(out, "w"), indent=1)
+    print("wrote %d bitstreams + %d files to %s" % (len(vec), len(files), out))
+    for v in vec:
+        print("  ", v["source"].split(":")[1], v["wrap"], v["expect"], len(v["input"]) // 2)
+
+
+if __name__ == "__main__":
+    extract_inflate()

@@ -1,0 +1,96 @@
+"""CPU tests of the HIP kernels themselves, compiled by g++ against the SIMT emulator
+(tests/emu/, -DZMI_EMU).  Small inputs only (the emulator runs ~1 us per fiber switch); the same
+kernels are tested at full size on the MI355X by test_gpu_parity.py."""
+import json
+import os
+import zlib
+
+import pytest
+
+import oracle_lib
+import zmi_ctypes
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = zmi_ctypes.Engine(zmi_ctypes.load_emu())
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def o():
+    return oracle_lib.load()
+
+
+def test_deflate_kernels_roundtrip(eng, o):
+    blobs = [b"", b"a", b"abcd", b"abcde" * 7, bytes(3000), b"abcd" * 1000, o.gen_shard(0, 1 << 13), o.gen_shard(3, 1 << 13),
+             o.gen_shard(5, 1 << 12), o.gen_shard(7, 1 << 13)[2000:7000], o.prng_bytes(7, 5000, 1)]
+    for level, wrap in ((6, 1), (1, 0), (9, 2), (0, 1)):
+        outs, st = eng.deflate(blobs, level=level, wrap=wrap)
+        assert all(s == 0 for s in st)
+        for b, c in zip(blobs, outs):
+            assert zlib.decompress(c, {0: -15, 1: 15, 2: 31}[wrap]) == b
+            rc, back, _, msg = o.inflate(c, len(b), wrap)
+            assert rc == 1 and back == b, msg
+
+
+def test_deflate_multi_piece_streams(eng, o, monkeypatch):
+    monkeypatch.setenv("ZMI_BLOCK_SPAN", "2048")
+    d = o.gen_shard(1, 1 << 14)
+    outs, st = eng.deflate([d, d[:5000], d[:2049]], level=6, wrap=2)
+    assert st == [0, 0, 0]
+    for b, c in zip([d, d[:5000], d[:2049]], outs):
+        assert zlib.decompress(c, 31) == b
+
+
+def test_deflate_strategies(eng, o):
+    d = o.gen_shard(4, 1 << 13)
+    for strat in (1, 2, 3, 4):
+        outs, st = eng.deflate([d], level=6, strategy=strat, wrap=1)
+        assert st == [0] and zlib.decompress(outs[0]) == d
+
+
+def test_inflate_kernel_matches_oracle(eng, o):
+    blobs = [b"", b"a", b"hello world", bytes(1000), b"abc" * 3000, o.gen_shard(0, 1 << 13), o.gen_shard(6, 1 << 13)]
+    for wrap, wb in ((1, 15), (2, 31), (0, -15)):
+        for level in (0, 1, 6, 9):
+            streams = []
+            for b in blobs:
+                co = zlib.compressobj(level, zlib.DEFLATED, wb)
+                streams.append(co.compress(b) + co.flush())
+            outs, st = eng.inflate(streams, [len(b) + 4 for b in blobs], wrap)
+            assert all(s == 0 for s in st), st
+            assert outs == blobs
+    # streams produced by the oracle's restatement of the reference (fixed + dynamic + stored blocks)
+    streams = [o.deflate(b, 6, 1)[1] for b in blobs] + [o.deflate(blobs[5], 6, 1, 4)[1]]
+    outs, st = eng.inflate(streams, [len(b) + 4 for b in blobs] + [len(blobs[5])], 1)
+    assert all(s == 0 for s in st) and outs == blobs + [blobs[5]]
+
+
+def test_inflate_kernel_golden_bitstreams(eng, o):
+    inf = json.load(open(os.path.join(HERE, "golden", "inflate_vectors.json")))
+    streams = [bytes.fromhex(v["input"]) for v in inf["bitstreams"]]
+    for wrap in (0, 3):
+        idx = [i for i, v in enumerate(inf["bitstreams"]) if v["wrap"] == wrap]
+        outs, st = eng.inflate([streams[i] for i in idx], [8 * len(streams[i]) + 64 for i in idx], wrap)
+        for k, i in enumerate(idx):
+            rc, want, _, msg = o.inflate(streams[i], 8 * len(streams[i]) + 64, wrap)
+            if inf["bitstreams"][i]["expect"] == "data_error":
+                assert st[k] == -3, (inf["bitstreams"][i]["source"], st[k])
+            else:
+                assert st[k] in (0, -5)
+                if st[k] == 0:
+                    assert outs[k] == want
+
+
+def test_inflate_kernel_errors(eng, o):
+    d = o.gen_shard(2, 1 << 13)
+    good = zlib.compress(d, 6)
+    bad = bytearray(good); bad[300] ^= 0x40
+    badchk = bytearray(good); badchk[-2] ^= 1
+    outs, st = eng.inflate([good, bytes(bad), bytes(badchk), good[:700], good, b"\x78\x9c\x07"], [len(d)] * 4 + [100, 10], 1)
+    assert st[0] == 0 and outs[0] == d
+    assert st[1] in (-3, -5) and st[2] == -3 and st[3] == -5 and st[4] == -5 and st[5] == -3

@@ -441,20 +441,36 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
                                                         const uint32_t* __restrict__ len, uint32_t first_shard,
                                                         uint32_t* match, uint64_t match_stride,
                                                         const uint32_t* __restrict__ adler, const uint32_t* __restrict__ crc,
-                                                        uint8_t* __restrict__ out, uint64_t out_stride, uint32_t out_cap,
-                                                        uint32_t* __restrict__ out_len, int32_t* __restrict__ status,
+                                                        uint8_t* __restrict__ out, uint64_t out_stride, uint32_t pieces,
+                                                        uint32_t region_stride, uint32_t* __restrict__ piece_len,
                                                         zmi_enc_params prm) {
     __shared__ EncShared Sh;
     EncShared* S = &Sh;
     const uint32_t lane = zmi_lane();
-    const uint32_t s = first_shard + blockIdx.x;
+    const uint32_t local = blockIdx.x / pieces;   // shard index inside this launch group
+    const uint32_t piece = blockIdx.x % pieces;
+    const uint32_t s = first_shard + local;
     const uint8_t* src = data + off[s];
     const uint32_t n = len[s];
-    uint32_t* tokbuf = match + (uint64_t)blockIdx.x * match_stride;
+    uint32_t* tokbuf = match + (uint64_t)local * match_stride;
+
+    // piece geometry: `pieces` equal ranges (multiple of 64 positions); ranges past the end are empty
+    uint32_t psize = ((n + pieces - 1u) / pieces + 63u) & ~63u;
+    if (psize == 0u) psize = 64u;
+    const uint32_t npieces = n ? (n + psize - 1u) / psize : 1u;  // pieces that hold data
+    const uint32_t pstart = piece * psize;
+    uint32_t pend = pstart + psize;
+    if (pend > n) pend = n;
+    const bool is_first = piece == 0u;
+    const bool is_last = piece + 1u == npieces;
+    if (piece >= npieces) {
+        if (lane == 0) piece_len[(uint64_t)s * pieces + piece] = 0u;
+        return;
+    }
 
     EncWriter W;
-    W.outw = (uint32_t*)(out + (uint64_t)s * out_stride);
-    W.cap_w = out_cap >> 2;
+    W.outw = (uint32_t*)(out + (uint64_t)s * out_stride + (uint64_t)piece * region_stride);
+    W.cap_w = region_stride >> 2;
     W.wbase = 0;
     W.rel = 0;
     W.err = 0;
@@ -464,10 +480,11 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
     if (lane < ENC_ND) S->dfreq[lane] = 0;
     zmi_wave_sync();
 
-    // stream header
+    // stream header (first piece only)
     if (lane == 0) {
         uint32_t rel = 0;
-        if (prm.wrap == 1u) {
+        if (!is_first) {
+        } else if (prm.wrap == 1u) {
             uint32_t lf = prm.level < 2u ? 0u : (prm.level < 6u ? 1u : (prm.level == 6u ? 2u : 3u));
             uint32_t h = (0x78u << 8) | (lf << 6);
             h += 31u - (h % 31u);
@@ -497,24 +514,27 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
         W.rel = S->misc[M_REL];
     }
 
-    const uint32_t nseg = (n + 63u) / 64u;
+    const uint32_t seg0 = pstart / 64u;
+    const uint32_t nseg = (pend + 63u) / 64u;  // one past the last segment of this piece
     uint32_t e = 0;        // entry offset into the current segment (>= 64: segment fully covered by a match)
     uint32_t ntok = 0;     // tokens of the open block
-    uint32_t tok0 = 0;     // scratch index of the open block's first token (its first segment's position)
-    uint32_t bstart = 0;   // first input byte covered by the open block
-    uint32_t m_cur = (nseg > 0u && lane < n) ? tokbuf[lane] : 0u;
-    for (uint32_t seg = 0; seg < nseg; ++seg) {
+    uint32_t tok0 = pstart;  // scratch index of the open block's first token (its first segment's position)
+    uint32_t bstart = pstart;  // first input byte covered by the open block
+    uint32_t m_cur = (pstart + lane < pend) ? tokbuf[pstart + lane] : 0u;
+    for (uint32_t seg = seg0; seg < nseg; ++seg) {
         const uint32_t pos = seg * 64u + lane;
         uint32_t npos = pos + 64u;
-        uint32_t m_next = (npos < n) ? tokbuf[npos] : 0u;
+        uint32_t m_next = (npos < pend) ? tokbuf[npos] : 0u;
         uint32_t first_next = (uint32_t)__shfl((int)m_next, 0);
         uint32_t m1 = __shfl_down(m_cur, 1u);
         if (lane == 63u) m1 = first_next;
-        const bool valid = pos < n;
+        const bool valid = pos < pend;
         uint32_t mlen = (m_cur >> 8) & 0x1FFu;
         uint32_t mlen1 = (m1 >> 8) & 0x1FFu;
         uint32_t step = 1u;
         if (valid && mlen >= 4u && !(mlen < prm.max_lazy && mlen1 > mlen)) step = mlen;
+        // a token may not cross the end of the piece (the next piece starts a fresh parse there)
+        if (valid && pos + step > pend) { step = pend - pos; if (step < 3u) step = 1u; }
         if (e < 64u) {
             uint64_t mask;
             uint32_t enext;
@@ -542,11 +562,11 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
             mask &= __ballot(valid);
             const bool in = (mask >> lane) & 1ull;
             if (in) {
-                uint32_t tk = step > 1u ? m_cur : (m_cur & 0xFFu);
+                uint32_t tk = step > 1u ? ((m_cur & ~(0x1FFu << 8)) | (step << 8)) : (m_cur & 0xFFu);
                 tokbuf[tok0 + ntok + zmi_mbcnt(mask)] = tk;
                 if (step > 1u) {
                     uint32_t li, leb, lev, di, deb, dev;
-                    enc_len_sym(mlen, li, leb, lev);
+                    enc_len_sym(step, li, leb, lev);
                     enc_dist_sym((m_cur >> 17) + 1u, di, deb, dev);
                     atomicAdd(&S->lfreq[257u + li], 1u);
                     atomicAdd(&S->dfreq[di], 1u);
@@ -563,8 +583,8 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
         const uint32_t done = (seg + 1u) * 64u;
         if (done - tok0 >= prm.block_span || seg + 1u == nseg) {
             uint32_t bend = done + e;
-            if (bend > n) bend = n;
-            const uint32_t is_final = (seg + 1u == nseg) ? 1u : 0u;
+            if (bend > pend) bend = pend;
+            const uint32_t is_final = (seg + 1u == nseg && is_last) ? 1u : 0u;
             __threadfence_block();  // token stores of other lanes must be visible to the encode pass
             zmi_wave_sync();
             enc_flush_block(S, W, tokbuf + tok0, ntok, src, bstart, bend, is_final, prm);
@@ -577,16 +597,25 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
         }
     }
 
-    // trailer
+    // end of piece: the last piece appends the wrapper trailer, every other piece an empty stored
+    // block (00 00 FF FF after padding -- the Z_SYNC_FLUSH marker, zlib-rs/src/deflate.rs:2733-2738)
+    // so that the next piece starts on a byte boundary and the pieces can simply be concatenated
     if (lane == 0) {
-        uint32_t rel = (W.rel + 7u) & ~7u;
-        if (prm.wrap == 1u) {
-            uint32_t a = adler[s];
-            uint32_t be = (a >> 24) | ((a >> 8) & 0xFF00u) | ((a << 8) & 0xFF0000u) | (a << 24);
-            enc_put0(S, rel, be, 32u);
-        } else if (prm.wrap == 2u) {
-            enc_put0(S, rel, crc[s], 32u);
-            enc_put0(S, rel, n, 32u);
+        uint32_t rel = W.rel;
+        if (!is_last) {
+            enc_put0(S, rel, 0u, 3u);
+            rel = (rel + 7u) & ~7u;
+            enc_put0(S, rel, 0xFFFF0000u, 32u);
+        } else {
+            rel = (rel + 7u) & ~7u;
+            if (prm.wrap == 1u) {
+                uint32_t a = adler[s];
+                uint32_t be = (a >> 24) | ((a >> 8) & 0xFF00u) | ((a << 8) & 0xFF0000u) | (a << 24);
+                enc_put0(S, rel, be, 32u);
+            } else if (prm.wrap == 2u) {
+                enc_put0(S, rel, crc[s], 32u);
+                enc_put0(S, rel, n, 32u);
+            }
         }
         S->misc[M_REL] = rel;
     }
@@ -595,26 +624,76 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
     enc_flush(S, W);
     uint32_t tail = W.rel >> 3;  // 0..3 bytes left in stg[0]
     uint32_t total = W.wbase * 4u + tail;
-    if (total > out_cap) W.err = 1u;
+    if (total > region_stride) W.err = 1u;
     if (lane == 0) {
         if (!W.err) {
             uint8_t* ob = (uint8_t*)(W.outw + W.wbase);
             uint32_t v = S->stg[0];
             for (uint32_t j = 0; j < tail; ++j) ob[j] = (uint8_t)(v >> (8u * j));
         }
-        out_len[s] = W.err ? 0u : total;
-        status[s] = W.err ? ZMI_BUF_ERROR : ZMI_OK;
+        piece_len[(uint64_t)s * pieces + piece] = W.err ? 0xFFFFFFFFu : total;
+    }
+}
+
+// Concatenate the pieces of every shard inside its output slot (piece r lives at r*region_stride
+// and only ever moves towards lower addresses, 1 KiB per step), then publish length and status.
+__global__ void __launch_bounds__(64) zmi_compact_kernel(uint8_t* __restrict__ out, uint64_t out_stride, uint32_t first_shard,
+                                                         uint32_t pieces, uint32_t region_stride,
+                                                         const uint32_t* __restrict__ piece_len,
+                                                         uint32_t* __restrict__ out_len, int32_t* __restrict__ status) {
+    const uint32_t lane = zmi_lane();
+    const uint32_t s = first_shard + blockIdx.x;
+    uint8_t* slot = out + (uint64_t)s * out_stride;
+    const uint32_t* pl = piece_len + (uint64_t)s * pieces;
+    uint32_t cur = pl[0];
+    bool err = cur == 0xFFFFFFFFu;
+    for (uint32_t r = 1; r < pieces && !err; ++r) {
+        const uint32_t l = pl[r];
+        if (l == 0xFFFFFFFFu) { err = true; break; }
+        const uint8_t* srcp = slot + (uint64_t)r * region_stride;
+        uint8_t* dstp = slot + cur;
+        if ((cur & 3u) == 0u) {
+            // dword path: both ends 4-byte aligned (regions are 16-byte aligned)
+            const uint32_t nw = (l + 3u) >> 2;
+            for (uint32_t base = 0; base < nw; base += 64u) {
+                uint32_t i = base + lane;
+                uint32_t v = 0;
+                if (i < nw) v = ((const uint32_t*)srcp)[i];
+                zmi_wave_sync();
+                if (i < nw) ((uint32_t*)dstp)[i] = v;
+                zmi_wave_sync();
+            }
+        } else {
+            for (uint32_t base = 0; base < l; base += 64u) {
+                uint32_t i = base + lane;
+                uint8_t v = 0;
+                if (i < l) v = srcp[i];
+                zmi_wave_sync();
+                if (i < l) dstp[i] = v;
+                zmi_wave_sync();
+            }
+        }
+        cur += l;
+    }
+    if (lane == 0) {
+        out_len[s] = err ? 0u : cur;
+        status[s] = err ? ZMI_BUF_ERROR : ZMI_OK;
     }
 }
 
 extern "C" int zmi_launch_encode(const uint8_t* d_data, const uint64_t* d_off, const uint32_t* d_len, uint32_t first_shard,
                                  uint32_t n_shards, uint32_t* d_match, uint64_t match_stride, const uint32_t* d_adler,
                                  const uint32_t* d_crc, uint8_t* d_out, uint64_t out_stride, uint32_t out_cap,
-                                 uint32_t* d_out_len, int32_t* d_status, zmi_enc_params prm, hipStream_t stream) {
+                                 uint32_t* d_out_len, int32_t* d_status, uint32_t pieces, uint32_t* d_piece_len,
+                                 zmi_enc_params prm, hipStream_t stream) {
     if (n_shards == 0) return 0;
     if (prm.block_span < 64u) prm.block_span = 64u;
     prm.block_span &= ~63u;
-    ZMI_LAUNCH(zmi_encode_kernel, dim3(n_shards), dim3(64), 0, stream, d_data, d_off, d_len, first_shard, d_match,
-               match_stride, d_adler, d_crc, d_out, out_stride, out_cap, d_out_len, d_status, prm);
+    if (pieces < 1u) pieces = 1u;
+    uint32_t region = (uint32_t)((out_cap / pieces) & ~15u);
+    ZMI_LAUNCH(zmi_encode_kernel, dim3(n_shards * pieces), dim3(64), 0, stream, d_data, d_off, d_len, first_shard, d_match,
+               match_stride, d_adler, d_crc, d_out, out_stride, pieces, region, d_piece_len, prm);
+    ZMI_LAUNCH(zmi_compact_kernel, dim3(n_shards), dim3(64), 0, stream, d_out, out_stride, first_shard, pieces, region,
+               d_piece_len, d_out_len, d_status);
     return 0;
 }

@@ -22,6 +22,9 @@
 #include "zmi_device.h"
 #include "zmi_kernels.h"
 
+// internal status codes resolved by zmi_inflate_verify_kernel (the CRC of the output is only known there)
+#define ZMI_TRAILER_SHORT (-1005)     // gzip: CRC present, ISIZE cut off   -> data error if CRC wrong, else buf error
+#define ZMI_LENGTH_MISMATCH (-1003)   // gzip: ISIZE wrong                  -> data error either way
 #define INF_LROOT 10u
 #define INF_DROOT 9u
 #define INF_LSIZE 1344u
@@ -427,14 +430,20 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                 B.ipos += 4u;
             }
         } else if (kind_found == 2u) {
-            if (B.ipos + 8u > B.n) st = ZMI_BUF_ERROR;
+            // CRC first (4 bytes), ISIZE after 4 more -- a stream cut between the two still reports a
+            // CRC mismatch as a data error, as the reference's streaming state machine does
+            if (B.ipos + 4u > B.n) st = ZMI_BUF_ERROR;
             else {
                 chk = B.src[B.ipos] | ((uint32_t)B.src[B.ipos + 1u] << 8) | ((uint32_t)B.src[B.ipos + 2u] << 16) |
                       ((uint32_t)B.src[B.ipos + 3u] << 24);
-                uint32_t isize = B.src[B.ipos + 4u] | ((uint32_t)B.src[B.ipos + 5u] << 8) |
-                                 ((uint32_t)B.src[B.ipos + 6u] << 16) | ((uint32_t)B.src[B.ipos + 7u] << 24);
-                B.ipos += 8u;
-                if (isize != opos) st = ZMI_DATA_ERROR;  // "incorrect length check"
+                B.ipos += 4u;
+                if (B.ipos + 4u > B.n) st = ZMI_TRAILER_SHORT;
+                else {
+                    uint32_t isize = B.src[B.ipos] | ((uint32_t)B.src[B.ipos + 1u] << 8) |
+                                     ((uint32_t)B.src[B.ipos + 2u] << 16) | ((uint32_t)B.src[B.ipos + 3u] << 24);
+                    B.ipos += 4u;
+                    if (isize != opos) st = ZMI_LENGTH_MISMATCH;  // "incorrect length check" (after the CRC check)
+                }
             }
         }
     }
@@ -454,14 +463,17 @@ __global__ void __launch_bounds__(256) zmi_inflate_verify_kernel(const uint8_t* 
                                                                  const uint32_t* __restrict__ crc, uint32_t n,
                                                                  int32_t* __restrict__ status) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n || status[s] != ZMI_OK) return;
+    if (s >= n) return;
+    int32_t st = status[s];
+    if (st != ZMI_OK && st != ZMI_TRAILER_SHORT && st != ZMI_LENGTH_MISMATCH) return;
     uint32_t kind = wrap;
     if (wrap == 3u) {
         const uint8_t* p = in + in_off[s];
         kind = (in_len[s] >= 2u && p[0] == 0x1Fu && p[1] == 0x8Bu) ? 2u : 1u;
     }
-    if (kind == 1u && check[s] != adler[s]) status[s] = ZMI_DATA_ERROR;  // "incorrect data check"
-    if (kind == 2u && check[s] != crc[s]) status[s] = ZMI_DATA_ERROR;
+    bool bad = (kind == 1u && check[s] != adler[s]) || (kind == 2u && check[s] != crc[s]);  // "incorrect data check"
+    if (bad || st == ZMI_LENGTH_MISMATCH) status[s] = ZMI_DATA_ERROR;
+    else if (st == ZMI_TRAILER_SHORT) status[s] = ZMI_BUF_ERROR;
 }
 
 extern "C" int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n_streams,

@@ -18,14 +18,14 @@
 //     (LDS atomic-max; the returned old value is the chain predecessor) and publishes a `ready`
 //     frontier.  It is throttled only by the ring: it may not overwrite bytes that the oldest
 //     in-flight search can still reference.
-//   * Waves 1..15 are SEARCHERS.  Every lane runs two independent match-search state machines
-//     ("slots"); each loop iteration issues one round of LDS reads per slot (8 window bytes at the
-//     candidate, 8 more for extension/tail, the prev link) and advances the slot by one step:
-//         INIT -> CHAIN (one hash-chain candidate per step) -> EXTEND (8 bytes per step) -> done.
-//     A finished slot is refilled from a shared position counter, so a wave's cost follows the
-//     AVERAGE chain length of its positions, not the maximum (the SIMT analogue of the CPU loop's
-//     early exits), and the two slots per lane double the LDS requests in flight (the profile of
-//     the first version was latency-bound: LDS pipe 24 % busy, 61 % of wave cycles waiting).
+//   * Waves 1..15 are SEARCHERS.  A searcher claims 64 consecutive positions (one per lane) from a
+//     shared LDS counter and walks the hash chains as a tight per-lane loop.  Every chain step
+//     issues ONE round of LDS reads (prev link of the candidate + its first 8 window bytes + the 4
+//     bytes ending at the current best length) so it costs one LDS latency; matches that survive
+//     the 8-byte compare are extended 16 bytes per round.  A claim is a bounded amount of work
+//     (<= max_chain steps), so a slow wave delays the ring by far less than its slack; claims are
+//     dynamic, so no wave waits for another (the first version had a barrier per 1 KiB tile and
+//     spent 61 % of its wave-cycles waiting).
 //   * output: one u32 per position  lit | len<<8 | (dist-1)<<17  (len = 0: no match >= 4).
 //     The parse (greedy/lazy selection) happens in encode.hip, which sees the best match of every
 //     position, not just the visited ones.
@@ -44,7 +44,6 @@
 #define LZ_MIRROR 16u
 #define LZ_CTL 128u
 #define LZ_SMEM (LZ_WSIZE + LZ_MIRROR + 2u * LZ_WSIZE + 4u * LZ_HSIZE + LZ_CTL)
-#define LZ_REFILL_MIN 24u
 
 struct LzCtl {
     uint32_t ready;  // positions < ready are searchable (chain built, look-ahead bytes loaded)
@@ -125,12 +124,6 @@ static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_
     }
 }
 
-enum { LZ_EMPTY = 0, LZ_INIT = 1, LZ_CHAIN = 2, LZ_EXTEND = 3, LZ_TAIL = 4 };
-
-struct LzSlot {
-    uint32_t p, cand, blen, bdist, chain, maxlen, mylo, myhi, tail, xlen, xd, mode;
-};
-
 __global__ void __launch_bounds__(1024) zmi_lz77_kernel(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off,
                                                         const uint32_t* __restrict__ len, uint32_t first_shard,
                                                         uint32_t* __restrict__ match, uint64_t match_stride,
@@ -198,146 +191,81 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel(const uint8_t* __restric
     }
 
     // ---------------- searchers ----------------
-    LzSlot S[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        S[q].mode = LZ_EMPTY; S[q].p = 0; S[q].cand = 0; S[q].blen = 0; S[q].bdist = 0; S[q].chain = 0; S[q].maxlen = 0;
-        S[q].mylo = 0; S[q].myhi = 0; S[q].tail = 0; S[q].xlen = 0; S[q].xd = 0;
-    }
-    bool exhausted = false;
-    uint32_t amin = 0xFFFFFFFFu;  // published lower bound of this wave's oldest active position
+    // Each searcher wave claims 64 consecutive positions at a time (one per lane) and runs the chain
+    // walk as a tight per-lane loop: ONE round of LDS reads per candidate (the prev link of the
+    // candidate, its first 8 window bytes and, once the best match is >= 8, the 4 bytes ending at
+    // the best length), so a chain step costs one LDS latency, not two.
     for (;;) {
-        // ---- refill empty slots from the shared position counter ----
-        const uint64_t e0 = __ballot(S[0].mode == LZ_EMPTY);
-        const uint64_t e1 = __ballot(S[1].mode == LZ_EMPTY);
-        const uint32_t n0 = (uint32_t)__popcll(e0), n1 = (uint32_t)__popcll(e1);
-        const uint32_t nempty = n0 + n1;
-        if (exhausted && nempty == 128u) break;
-        if (!exhausted && nempty >= LZ_REFILL_MIN) {
-            uint32_t base = 0;
-            if (lane == 0) {
-                uint32_t tnext = lz_ld_acq(&ctl->next);
-                uint32_t lb = tnext < amin ? tnext : amin;
-                lz_st_rel(&ctl->wmin[wave], lb);  // published BEFORE the claim
-                base = atomicAdd(&ctl->next, nempty);
-            }
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            uint32_t cnt = 0;
-            if (base < n) cnt = (n - base < nempty) ? n - base : nempty;
-            if (base + nempty >= n) exhausted = true;
-            const uint32_t r0 = zmi_mbcnt(e0), r1 = n0 + zmi_mbcnt(e1);
-            if (S[0].mode == LZ_EMPTY && r0 < cnt) { S[0].p = base + r0; S[0].mode = LZ_INIT; }
-            if (S[1].mode == LZ_EMPTY && r1 < cnt) { S[1].p = base + r1; S[1].mode = LZ_INIT; }
-            uint32_t m = 0xFFFFFFFFu;
-            if (S[0].mode != LZ_EMPTY) m = S[0].p;
-            if (S[1].mode != LZ_EMPTY && S[1].p < m) m = S[1].p;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                uint32_t o = __shfl_xor(m, d);
-                m = o < m ? o : m;
-            }
-            amin = m;
-            if (lane == 0) lz_st_rel(&ctl->wmin[wave], amin);
+        uint32_t base = 0;
+        if (lane == 0) {
+            uint32_t tnext = lz_ld_acq(&ctl->next);
+            lz_st_rel(&ctl->wmin[wave], tnext);  // lower bound published BEFORE the claim
+            base = atomicAdd(&ctl->next, 64u);
+            lz_st_rel(&ctl->wmin[wave], base);
         }
-        const uint32_t ready = lz_ld_acq(&ctl->ready);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (base >= n) break;
+        const uint32_t need = base + 64u < n ? base + 64u : n;
+        while (lz_ld_acq(&ctl->ready) < need) lz_pause();
 
-        // ---- one step per slot ----
-        bool finished_min = false;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            LzSlot& Z = S[q];
-            const uint32_t mode = Z.mode;
-            if (mode == LZ_EMPTY) continue;
-            if (mode == LZ_INIT && Z.p >= ready) continue;  // producer has not reached this position yet
-            // addresses of this step's reads
-            uint32_t aA, aB = 0;
-            bool needB = false, needC = false;
-            if (mode == LZ_INIT) { aA = Z.p; needC = true; }
-            else if (mode == LZ_CHAIN) { aA = Z.cand; needC = true; if (Z.blen >= 8u) { aB = Z.cand + Z.blen - 3u; needB = true; } }
-            else if (mode == LZ_EXTEND) { aA = Z.p + Z.xlen; aB = Z.cand + Z.xlen; needB = true; }
-            else { aA = Z.p + Z.blen - 3u; }
-            uint32_t alo, ahi, blo = 0, bhi = 0, cd = 0;
-            lz_ring64(win, aA, alo, ahi);
-            if (needB) lz_ring64(win, aB, blo, bhi);
-            if (needC) cd = prev[(mode == LZ_INIT ? Z.p : Z.cand) & LZ_WMASK];
-
-            bool fin = false;        // slot done
-            bool adv = false;        // follow the chain link advd from node advfrom
-            uint32_t advfrom = 0, advd = 0;
-            if (mode == LZ_INIT) {
-                Z.mylo = alo; Z.myhi = ahi;
-                uint32_t ml = n - Z.p;
-                Z.maxlen = ml > 258u ? 258u : ml;
-                Z.blen = 3u; Z.bdist = 0u; Z.chain = prm.max_chain;
-                if (Z.maxlen < 4u) fin = true;
-                else { adv = true; advfrom = Z.p; advd = cd; }
-            } else if (mode == LZ_CHAIN) {
-                const uint32_t m8 = lz_match8(alo ^ Z.mylo, ahi ^ Z.myhi);
-                bool ext = false;
-                if (Z.blen < 8u) {
-                    if (m8 == 8u && Z.maxlen > 8u) ext = true;
-                    else {
-                        uint32_t l = m8 < Z.maxlen ? m8 : Z.maxlen;
-                        if (l > Z.blen) {
-                            Z.blen = l; Z.bdist = Z.p - Z.cand;
-                            if (l >= prm.nice_len || l >= Z.maxlen) fin = true;
-                            else if (l >= prm.good_len) Z.chain >>= 1;
+        const uint32_t p = base + lane;
+        uint32_t res = 0;
+        if (p < n) {
+            uint32_t mylo, myhi;
+            lz_ring64(win, p, mylo, myhi);
+            res = mylo & 0xFFu;
+            uint32_t maxlen = n - p;
+            if (maxlen > 258u) maxlen = 258u;
+            uint32_t delta = prev[p & LZ_WMASK];
+            if (maxlen >= 4u && delta != 0u) {
+                uint32_t cand = p - delta;
+                uint32_t blen = 3u, bdist = 0u, tail = 0u;
+                uint32_t chain = prm.max_chain;
+                // The loop body is kept branch-light on purpose: the common case (candidate decided by
+                // its first 8 bytes, best length < 8) runs straight through; the two divergent `if`s
+                // are the rare ones (long matches).
+                for (;;) {
+                    const uint32_t r = cand & LZ_WMASK;
+                    const uint32_t* w = (const uint32_t*)(win + (r & ~3u));
+                    const uint32_t dn = prev[r];
+                    const uint32_t wa = w[0], wb = w[1], wc = w[2];
+                    uint32_t tl = 0;
+                    if (blen >= 8u) tl = lz_ring32(win, cand + blen - 3u);
+                    const uint32_t sh = r & 3u;
+                    const uint32_t xlo = __builtin_amdgcn_alignbyte(wb, wa, sh) ^ mylo;
+                    const uint32_t xhi = __builtin_amdgcn_alignbyte(wc, wb, sh) ^ myhi;
+                    const uint64_t x = ((uint64_t)xhi << 32) | xlo;
+                    uint32_t l = (uint32_t)(__ffsll((unsigned long long)x) - 1) >> 3;  // x == 0 -> 0x1FFFFFFF
+                    l = l > 8u ? 8u : l;
+                    if (blen >= 8u && !(l == 8u && tl == tail)) l = 0u;
+                    if (l == 8u && maxlen > 8u) {
+                        // extend 16 bytes per round
+                        for (;;) {
+                            uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
+                            lz_ring64(win, p + l, a0, a1);
+                            lz_ring64(win, p + l + 8u, a2, a3);
+                            lz_ring64(win, cand + l, b0, b1);
+                            lz_ring64(win, cand + l + 8u, b2, b3);
+                            uint32_t m = lz_match8(a0 ^ b0, a1 ^ b1);
+                            if (m == 8u) m += lz_match8(a2 ^ b2, a3 ^ b3);
+                            l += m;
+                            if (m < 16u || l >= maxlen) break;
                         }
                     }
-                } else if (m8 == 8u && blo == Z.tail) {
-                    ext = true;
+                    l = l > maxlen ? maxlen : l;
+                    const bool better = l > blen;
+                    blen = better ? l : blen;
+                    bdist = better ? p - cand : bdist;
+                    if (better && l >= 8u) tail = lz_ring32(win, p + l - 3u);
+                    if (better && l >= prm.good_len) chain >>= 1;
+                    const bool stop = better && (l >= prm.nice_len || l >= maxlen);
+                    cand -= dn;
+                    chain = chain ? chain - 1u : 0u;
+                    if (stop || dn == 0u || chain == 0u || p - cand > prm.max_dist) break;
                 }
-                if (ext) { Z.mode = LZ_EXTEND; Z.xlen = 8u; Z.xd = cd; }
-                else if (!fin) { adv = true; advfrom = Z.cand; advd = cd; }
-            } else if (mode == LZ_EXTEND) {
-                const uint32_t m8 = lz_match8(alo ^ blo, ahi ^ bhi);
-                Z.xlen += m8;
-                if (!(m8 == 8u && Z.xlen < Z.maxlen)) {
-                    uint32_t l = Z.xlen < Z.maxlen ? Z.xlen : Z.maxlen;
-                    bool better = l > Z.blen;
-                    if (better) {
-                        Z.blen = l; Z.bdist = Z.p - Z.cand;
-                        if (l >= prm.nice_len || l >= Z.maxlen) fin = true;
-                        else if (l >= prm.good_len) Z.chain >>= 1;
-                    }
-                    if (!fin) {
-                        adv = true; advfrom = Z.cand; advd = Z.xd;
-                        Z.mode = (better && Z.blen >= 8u) ? LZ_TAIL : LZ_CHAIN;
-                    }
-                }
-            } else {  // LZ_TAIL: refresh the 4 bytes ending at the best length, then resume the chain
-                Z.tail = alo;
-                Z.mode = LZ_CHAIN;
+                if (blen >= 4u) res |= (blen << 8) | ((bdist - 1u) << 17);
             }
-            if (adv) {
-                if (advd == 0u || Z.chain == 0u) fin = true;
-                else {
-                    Z.chain -= 1u;
-                    Z.cand = advfrom - advd;
-                    if (Z.p - Z.cand > prm.max_dist) fin = true;
-                    else if (Z.mode == LZ_INIT) Z.mode = LZ_CHAIN;
-                }
-            }
-            if (fin) {
-                uint32_t res = Z.mylo & 0xFFu;
-                if (Z.blen >= 4u) res |= (Z.blen << 8) | ((Z.bdist - 1u) << 17);
-                mout[Z.p] = res;
-                if (Z.p == amin) finished_min = true;
-                Z.mode = LZ_EMPTY;
-            }
-        }
-        // the wave's oldest position retired: publish the new lower bound so the producer can move on
-        if (__ballot(finished_min)) {
-            uint32_t m = 0xFFFFFFFFu;
-            if (S[0].mode != LZ_EMPTY) m = S[0].p;
-            if (S[1].mode != LZ_EMPTY && S[1].p < m) m = S[1].p;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                uint32_t o = __shfl_xor(m, d);
-                m = o < m ? o : m;
-            }
-            amin = m;
-            if (lane == 0) lz_st_rel(&ctl->wmin[wave], amin);
+            mout[p] = res;
         }
     }
     if (lane == 0) lz_st_rel(&ctl->wmin[wave], 0xFFFFFFFFu);

@@ -50,6 +50,7 @@ struct zmi_ctx {
     uint64_t scratch_limit = 8ull << 30;
     zmi_buf match;    // u32 per position of the current group
     zmi_buf sums;     // adler[n] crc[n]
+    zmi_buf pieces;   // per shard x piece compressed length
     zmi_buf inf_tmp;  // in_used[n] check[n] adler[n] crc[n]
 };
 
@@ -85,6 +86,7 @@ extern "C" int zmi_ctx_destroy(zmi_ctx* c) {
     if (!c) return ZMI_E_OK;
     if (c->match.p) (void)hipFree(c->match.p);
     if (c->sums.p) (void)hipFree(c->sums.p);
+    if (c->pieces.p) (void)hipFree(c->pieces.p);
     if (c->inf_tmp.p) (void)hipFree(c->inf_tmp.p);
     delete c;
     return ZMI_E_OK;
@@ -160,8 +162,8 @@ static const zmi_level_cfg kLevels[10] = {
     {8, 32, 8, 4},        // 3
     {12, 64, 16, 8},      // 4
     {16, 64, 16, 16},     // 5
-    {32, 128, 32, 16},    // 6
-    {64, 128, 32, 32},    // 7
+    {24, 128, 32, 16},    // 6
+    {48, 128, 32, 32},    // 7
     {128, 258, 64, 128},  // 8
     {256, 258, 128, 258}, // 9
 };
@@ -228,6 +230,8 @@ extern "C" int zmi_deflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_
     if (level == 0) ep.strategy = 100u;           // stored blocks only (deflate_stored)
     if (strategy == 2) lp.max_chain = 0;          // Z_HUFFMAN_ONLY: literals only
     if (strategy == 3) lp.max_dist = 1;           // Z_RLE: distance-1 matches only
+    const char* chain_env = getenv("ZMI_CHAIN");  // tuning aid: override the chain budget of the selected level
+    if (chain_env && atoi(chain_env) > 0 && level > 0 && strategy != 2) lp.max_chain = (uint32_t)atoi(chain_env);
     const char* span_env = getenv("ZMI_BLOCK_SPAN");
     if (span_env && atoi(span_env) >= 64) ep.block_span = (uint32_t)atoi(span_env);
 
@@ -238,6 +242,23 @@ extern "C" int zmi_deflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_
     if (group == 0) return zmi_fail(ZMI_E_NOMEM, "scratch limit too small for one shard");
     if (group > n) group = n;
     rc = zmi_reserve(c->match, (size_t)(group * per_shard));
+    if (rc) return rc;
+    // the encoder runs `pieces` waves per shard (byte-aligned sub-streams, concatenated afterwards):
+    // one piece per block_span of input, at most 16
+    uint32_t pieces = (max_len + ep.block_span - 1u) / ep.block_span;
+    if (pieces < 1u) pieces = 1u;
+    if (pieces > 16u) pieces = 16u;
+    const char* pieces_env = getenv("ZMI_PIECES");
+    if (pieces_env && atoi(pieces_env) >= 1 && atoi(pieces_env) <= 64) pieces = (uint32_t)atoi(pieces_env);
+    // every piece region must hold its worst case (stored blocks + marker) and stay 16-byte aligned
+    while (pieces > 1u) {
+        uint64_t region = (out_stride / pieces) & ~15ull;
+        uint64_t psize = (((uint64_t)max_len + pieces - 1u) / pieces + 63u) & ~63ull;
+        uint64_t worst = psize + 5u * (psize / 32768u + 2u) + 32u;
+        if (region >= worst) break;
+        --pieces;
+    }
+    rc = zmi_reserve(c->pieces, (size_t)n * pieces * 4u);
     if (rc) return rc;
     for (uint64_t first = 0; first < n; first += group) {
         uint32_t cnt = (uint32_t)((n - first < group) ? (n - first) : group);
@@ -250,7 +271,7 @@ extern "C" int zmi_deflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_
         zmi_scope_timer tm2(c, ZMI_K_ENCODE, stream);
         zmi_launch_encode((const uint8_t*)d_in, d_in_off, d_in_len, (uint32_t)first, cnt, (uint32_t*)c->match.p,
                           per_shard / 4u, d_adler, d_crc, (uint8_t*)d_out, out_stride, (uint32_t)out_stride, d_out_len,
-                          d_status, ep, stream);
+                          d_status, pieces, (uint32_t*)c->pieces.p, ep, stream);
     }
     ZMI_HIP(hipGetLastError());
     return ZMI_E_OK;

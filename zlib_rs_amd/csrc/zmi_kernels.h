@@ -41,7 +41,7 @@ int zmi_launch_lz77(const uint8_t* d_data, const uint64_t* d_off, const uint32_t
 int zmi_launch_encode(const uint8_t* d_data, const uint64_t* d_off, const uint32_t* d_len, uint32_t first_shard,
                       uint32_t n_shards, uint32_t* d_match, uint64_t match_stride, const uint32_t* d_adler,
                       const uint32_t* d_crc, uint8_t* d_out, uint64_t out_stride, uint32_t out_cap, uint32_t* d_out_len,
-                      int32_t* d_status, zmi_enc_params prm, hipStream_t stream);
+                      int32_t* d_status, uint32_t pieces, uint32_t* d_piece_len, zmi_enc_params prm, hipStream_t stream);
 int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n_streams,
                        uint32_t wrap, uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                        uint32_t* d_out_len, uint32_t* d_in_used, uint32_t* d_check, int32_t* d_status,
