@@ -114,19 +114,18 @@ def main():
     cnts = (C.c_uint32 * 8)()
     e.L.zmi_ctx_get_timing(e._ctx, sums, cnts)
     e.L.zmi_ctx_set_timing(e._ctx, 0)
-    tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    elapsed = float(tt.item())
+    from zlib_rs_amd import dist as zdist
+    elapsed = zdist.max_over_ranks(elapsed, dev)
 
     # ---- correctness outside the timed region ----
     assert int((st != 0).sum().item()) == 0, "deflate reported errors"
     csum = olen.to(torch.int64).sum()
     if world > 1:
         # shard-size table exchange (the fixed-size part of the stitch)
-        sizes = [torch.empty_like(olen) for _ in range(world)]
-        dist.all_gather(sizes, olen)
+        table = zdist.exchange_sizes(olen)                 # [world, S] on every rank
+        offs, stitched_total = zdist.stitch_offsets(table)  # byte offset of every shard in the stitched output
         dist.all_reduce(csum)
+        assert stitched_total == int(csum.item())
     comp_total = int(csum.item())
     raw_total = S * B * world
     ratio = raw_total / comp_total

@@ -79,6 +79,19 @@ int zmi_inflate_batch_dev(zmi_ctx* ctx, const void* d_in, const uint64_t* d_in_o
                           uint32_t n_streams, int wrap, void* d_out, const uint64_t* d_out_off,
                           const uint32_t* d_out_cap, uint32_t* d_out_len, int32_t* d_status, void* stream);
 
+/* Chained form used by the zlib stream ABI (libz_mi355.so): the shards are consecutive segments of
+ * ONE raw deflate stream, each byte aligned with an empty history (what Z_FULL_FLUSH produces,
+ * zlib-rs/src/deflate.rs:2739-2752); finish != 0 makes the last shard end the stream. */
+int zmi_deflate_chain_dev(zmi_ctx* ctx, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                          uint32_t n_shards, uint32_t max_len, int level, int strategy, int finish, void* d_out,
+                          uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream);
+/* As zmi_inflate_batch_dev, additionally reporting the consumed input bytes and why a stream
+ * stopped (d_detail: 0 done/error, 1 needs more input, 2 needs more output space). */
+int zmi_inflate_batch_dev_ex(zmi_ctx* ctx, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                             uint32_t n_streams, int wrap, void* d_out, const uint64_t* d_out_off,
+                             const uint32_t* d_out_cap, uint32_t* d_out_len, int32_t* d_status, uint32_t* d_in_used,
+                             int32_t* d_detail, void* stream);
+
 /* Adler-32 (kind bit 0) and/or CRC-32 (kind bit 1) of every shard (zlib-rs/src/adler32.rs:19, crc32.rs:19) */
 int zmi_checksum_batch_dev(zmi_ctx* ctx, const void* d_data, const uint64_t* d_off, const uint32_t* d_len,
                            uint32_t n_shards, int kind, uint32_t* d_adler, uint32_t* d_crc, void* stream);

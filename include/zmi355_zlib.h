@@ -1,0 +1,158 @@
+/* zmi355_zlib.h -- the zlib stream ABI exported by libzmi355.so.
+ *
+ * Same symbols, same z_stream layout (112 bytes on LP64) and same return codes as the reference's
+ * C ABI crate libz-rs-sys, so a C program or a Rust `extern "C"` block written against
+ * libz-rs-sys/include/zlib.h links against libzmi355.so unchanged.  Behind these entry points the
+ * deflate / inflate work runs on the MI355X (kernels in zlib_rs_amd/csrc); without a HIP device the
+ * *Init* functions fail with Z_MEM_ERROR and msg "no HIP device" -- there is no CPU fallback.
+ *
+ * Each declaration cites the reference definition it replaces (libz-rs-sys/src/lib.rs:LINE).
+ *
+ * Stream semantics on the GPU (documented deviations that stay inside zlib's contract):
+ *   deflate()  consumes and buffers input; compressed data is produced when the caller flushes or
+ *              finishes (or 64 MiB are pending).  The input is compressed in 1 MiB segments with
+ *              Z_FULL_FLUSH semantics between them (history reset, byte aligned,
+ *              zlib-rs/src/deflate.rs:2739-2752), the way the reference's own split_deflate test
+ *              stitches independently compressed parts (zlib-rs/src/deflate.rs:4149-4221).
+ *   inflate()  buffers input and decodes once the stream is complete (one wave per stream); output
+ *              is then handed out across as many calls as the caller's buffers need.
+ * Not implemented (Z_STREAM_ERROR): preset dictionaries, deflatePrime/inflatePrime, inflateBack*,
+ * inflateSync, gzip header get/set, gz* file API ("next").
+ */
+#ifndef ZMI355_ZLIB_H
+#define ZMI355_ZLIB_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZLIB_VERSION "1.3.0-zmi355-0.1.0"
+#define ZLIB_VERNUM 0x1300
+
+typedef unsigned char Bytef;
+typedef unsigned int uInt;
+typedef unsigned long uLong;
+typedef uLong uLongf;
+typedef void* voidpf;
+typedef size_t z_size_t;
+
+typedef voidpf (*alloc_func)(voidpf opaque, uInt items, uInt size); /* zlib-rs/src/c_api.rs:8 */
+typedef void (*free_func)(voidpf opaque, voidpf address);           /* zlib-rs/src/c_api.rs:9 */
+
+struct internal_state;
+
+/* zlib-rs/src/c_api.rs:54-71 */
+typedef struct z_stream_s {
+    const Bytef* next_in;
+    uInt avail_in;
+    uLong total_in;
+    Bytef* next_out;
+    uInt avail_out;
+    uLong total_out;
+    const char* msg;
+    struct internal_state* state;
+    alloc_func zalloc;
+    free_func zfree;
+    voidpf opaque;
+    int data_type;
+    uLong adler;
+    uLong reserved;
+} z_stream;
+typedef z_stream* z_streamp;
+
+/* zlib-rs/src/c_api.rs:132-166 */
+#define Z_NO_FLUSH 0
+#define Z_PARTIAL_FLUSH 1
+#define Z_SYNC_FLUSH 2
+#define Z_FULL_FLUSH 3
+#define Z_FINISH 4
+#define Z_BLOCK 5
+#define Z_TREES 6
+#define Z_OK 0
+#define Z_STREAM_END 1
+#define Z_NEED_DICT 2
+#define Z_ERRNO (-1)
+#define Z_STREAM_ERROR (-2)
+#define Z_DATA_ERROR (-3)
+#define Z_MEM_ERROR (-4)
+#define Z_BUF_ERROR (-5)
+#define Z_VERSION_ERROR (-6)
+#define Z_NO_COMPRESSION 0
+#define Z_BEST_SPEED 1
+#define Z_BEST_COMPRESSION 9
+#define Z_DEFAULT_COMPRESSION (-1)
+#define Z_FILTERED 1
+#define Z_HUFFMAN_ONLY 2
+#define Z_RLE 3
+#define Z_FIXED 4
+#define Z_DEFAULT_STRATEGY 0
+#define Z_BINARY 0
+#define Z_TEXT 1
+#define Z_UNKNOWN 2
+#define Z_DEFLATED 8
+#define Z_NULL 0
+#define MAX_WBITS 15
+
+const char* zlibVersion(void);                                                           /* lib.rs:2156 */
+uLong zlibCompileFlags(void);                                                            /* lib.rs:2219 */
+const char* zError(int err);                                                             /* lib.rs:2115 */
+
+int deflateInit_(z_streamp strm, int level, const char* version, int stream_size);       /* lib.rs:1918 */
+int deflateInit2_(z_streamp strm, int level, int method, int windowBits, int memLevel, int strategy,
+                  const char* version, int stream_size);                                 /* lib.rs:2005 */
+int deflate(z_streamp strm, int flush);                                                  /* lib.rs:1281 */
+int deflateEnd(z_streamp strm);                                                          /* lib.rs:1582 */
+int deflateReset(z_streamp strm);                                                        /* lib.rs:1611 */
+int deflateParams(z_streamp strm, int level, int strategy);                              /* lib.rs:1658 */
+int deflateTune(z_streamp strm, int good_length, int max_lazy, int nice_length, int max_chain); /* lib.rs:2063 */
+uLong deflateBound(z_streamp strm, uLong sourceLen);                                     /* lib.rs:1364 */
+z_size_t deflateBound_z(z_streamp strm, z_size_t sourceLen);                             /* lib.rs:1345 */
+int deflatePending(z_streamp strm, unsigned* pending, int* bits);                        /* lib.rs:1757 */
+int deflateSetDictionary(z_streamp strm, const Bytef* dictionary, uInt dictLength);      /* lib.rs:1689, unsupported */
+int deflatePrime(z_streamp strm, int bits, int value);                                   /* lib.rs:1725, unsupported */
+
+int inflateInit_(z_streamp strm, const char* version, int stream_size);                  /* lib.rs:935 */
+int inflateInit2_(z_streamp strm, int windowBits, const char* version, int stream_size); /* lib.rs:967 */
+int inflate(z_streamp strm, int flush);                                                  /* lib.rs:636 */
+int inflateEnd(z_streamp strm);                                                          /* lib.rs:660 */
+int inflateReset(z_streamp strm);                                                        /* lib.rs:1055 */
+int inflateReset2(z_streamp strm, int windowBits);                                       /* lib.rs:1082 */
+int inflateSetDictionary(z_streamp strm, const Bytef* dictionary, uInt dictLength);      /* lib.rs:1121, unsupported */
+int inflateSync(z_streamp strm);                                                         /* lib.rs:884, unsupported */
+
+int compress(Bytef* dest, uLongf* destLen, const Bytef* source, uLong sourceLen);        /* lib.rs:1447 */
+int compress2(Bytef* dest, uLongf* destLen, const Bytef* source, uLong sourceLen, int level); /* lib.rs:1529 */
+int compress_z(Bytef* dest, z_size_t* destLen, const Bytef* source, z_size_t sourceLen); /* lib.rs:1379 */
+int compress2_z(Bytef* dest, z_size_t* destLen, const Bytef* source, z_size_t sourceLen, int level); /* lib.rs:1471 */
+uLong compressBound(uLong sourceLen);                                                    /* lib.rs:1561 */
+z_size_t compressBound_z(z_size_t sourceLen);                                            /* lib.rs:1553 */
+int uncompress(Bytef* dest, uLongf* destLen, const Bytef* source, uLong sourceLen);      /* lib.rs:499 */
+int uncompress2(Bytef* dest, uLongf* destLen, const Bytef* source, uLong* sourceLen);    /* lib.rs:583 */
+int uncompress_z(Bytef* dest, z_size_t* destLen, const Bytef* source, z_size_t sourceLen); /* lib.rs:433 */
+int uncompress2_z(Bytef* dest, z_size_t* destLen, const Bytef* source, z_size_t* sourceLen); /* lib.rs:518 */
+
+uLong adler32(uLong adler, const Bytef* buf, uInt len);                                  /* lib.rs:340 */
+uLong adler32_z(uLong adler, const Bytef* buf, z_size_t len);                            /* lib.rs:307 */
+uLong adler32_combine(uLong adler1, uLong adler2, long len2);                            /* lib.rs:372 */
+uLong adler32_combine64(uLong adler1, uLong adler2, long long len2);                     /* lib.rs:412 */
+uLong crc32(uLong crc, const Bytef* buf, uInt len);                                      /* lib.rs:183 */
+uLong crc32_z(uLong crc, const Bytef* buf, z_size_t len);                                /* lib.rs:150 */
+uLong crc32_combine(uLong crc1, uLong crc2, long len2);                                  /* lib.rs:215 */
+uLong crc32_combine64(uLong crc1, uLong crc2, long long len2);                           /* lib.rs:247 */
+uLong crc32_combine_gen(long len2);                                                      /* lib.rs:268 */
+uLong crc32_combine_gen64(long long len2);                                               /* lib.rs:260 */
+uLong crc32_combine_op(uLong crc1, uLong crc2, uLong op);                                /* lib.rs:277 */
+const uint32_t* get_crc_table(void);                                                     /* lib.rs:253 */
+
+#define deflateInit(strm, level) deflateInit_((strm), (level), ZLIB_VERSION, (int)sizeof(z_stream))
+#define deflateInit2(strm, level, method, windowBits, memLevel, strategy) \
+    deflateInit2_((strm), (level), (method), (windowBits), (memLevel), (strategy), ZLIB_VERSION, (int)sizeof(z_stream))
+#define inflateInit(strm) inflateInit_((strm), ZLIB_VERSION, (int)sizeof(z_stream))
+#define inflateInit2(strm, windowBits) inflateInit2_((strm), (windowBits), ZLIB_VERSION, (int)sizeof(z_stream))
+
+#ifdef __cplusplus
+}
+#endif
+#endif

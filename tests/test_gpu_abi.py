@@ -1,0 +1,31 @@
+"""GPU test (-m gpu): the zlib stream ABI of libz_mi355.so driven the way a C caller / the
+reference's examples drive libz-rs-sys, plus a compiled C program against include/zmi355_zlib.h."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import pytest
+
+import oracle_lib
+import zlib_abi_harness as H
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_zlib_abi_on_gpu():
+    from zlib_rs_amd import _build
+    lib = H.bind(C.CDLL(_build.ABI_LIB))
+    H.run_abi_checks(lib, oracle_lib.load(rebuild=False), sizes=(0, 1, 100, 5000, 70000, 3 << 20))
+
+
+def test_c_program_links_and_roundtrips(tmp_path):
+    from zlib_rs_amd import _build
+    exe = str(tmp_path / "abi_smoke")
+    lib_dir = os.path.dirname(_build.ABI_LIB)
+    subprocess.run(["gcc", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", exe,
+                    "-L" + lib_dir, "-lz_mi355", "-lzmi355", "-Wl,-rpath," + lib_dir], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi_smoke ok" in r.stdout

@@ -1,0 +1,153 @@
+"""ctypes view of the zlib stream ABI (include/zmi355_zlib.h) -- the calls a C program or the
+reference's own examples (test-libz-rs-sys/examples/blogpost-compress.rs:43-122,
+blogpost-uncompress.rs:6-44, libz-rs-sys-cdylib/zpipe.c) make."""
+import ctypes as C
+
+Z_NO_FLUSH, Z_SYNC_FLUSH, Z_FULL_FLUSH, Z_FINISH = 0, 2, 3, 4
+Z_OK, Z_STREAM_END, Z_DATA_ERROR, Z_BUF_ERROR, Z_STREAM_ERROR, Z_VERSION_ERROR = 0, 1, -3, -5, -2, -6
+
+
+class ZStream(C.Structure):
+    _fields_ = [("next_in", C.c_void_p), ("avail_in", C.c_uint), ("total_in", C.c_ulong), ("next_out", C.c_void_p),
+                ("avail_out", C.c_uint), ("total_out", C.c_ulong), ("msg", C.c_char_p), ("state", C.c_void_p),
+                ("zalloc", C.c_void_p), ("zfree", C.c_void_p), ("opaque", C.c_void_p), ("data_type", C.c_int),
+                ("adler", C.c_ulong), ("reserved", C.c_ulong)]
+
+
+assert C.sizeof(ZStream) == 112  # zlib-rs/src/c_api.rs:54-71 on LP64
+
+
+def bind(lib):
+    lib.zlibVersion.restype = C.c_char_p
+    lib.zError.restype = C.c_char_p
+    lib.deflateInit2_.argtypes = [C.POINTER(ZStream), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
+    lib.deflate.argtypes = [C.POINTER(ZStream), C.c_int]
+    lib.deflateEnd.argtypes = [C.POINTER(ZStream)]
+    lib.deflateReset.argtypes = [C.POINTER(ZStream)]
+    lib.deflateBound.restype = C.c_ulong
+    lib.deflateBound.argtypes = [C.POINTER(ZStream), C.c_ulong]
+    lib.inflateInit2_.argtypes = [C.POINTER(ZStream), C.c_int, C.c_char_p, C.c_int]
+    lib.inflate.argtypes = [C.POINTER(ZStream), C.c_int]
+    lib.inflateEnd.argtypes = [C.POINTER(ZStream)]
+    lib.compressBound.restype = C.c_ulong
+    lib.compressBound.argtypes = [C.c_ulong]
+    lib.compress2.argtypes = [C.c_void_p, C.POINTER(C.c_ulong), C.c_void_p, C.c_ulong, C.c_int]
+    lib.uncompress.argtypes = [C.c_void_p, C.POINTER(C.c_ulong), C.c_void_p, C.c_ulong]
+    lib.uncompress2.argtypes = [C.c_void_p, C.POINTER(C.c_ulong), C.c_void_p, C.POINTER(C.c_ulong)]
+    for f in ("adler32", "crc32"):
+        getattr(lib, f).restype = C.c_ulong
+        getattr(lib, f).argtypes = [C.c_ulong, C.c_void_p, C.c_uint]
+    lib.crc32_combine.restype = C.c_ulong
+    lib.crc32_combine.argtypes = [C.c_ulong, C.c_ulong, C.c_long]
+    lib.adler32_combine.restype = C.c_ulong
+    lib.adler32_combine.argtypes = [C.c_ulong, C.c_ulong, C.c_long]
+    return lib
+
+
+def deflate_stream(lib, data, level=6, wbits=15, chunk_in=None, chunk_out=4096, flush_every=None, strategy=0):
+    """the blogpost-compress.rs loop: feed input in chunks, drain output in chunks"""
+    strm = ZStream()
+    ver = lib.zlibVersion()
+    assert lib.deflateInit2_(C.byref(strm), level, 8, wbits, 8, strategy, ver, C.sizeof(ZStream)) == Z_OK
+    src = C.create_string_buffer(data, len(data) or 1)
+    out = bytearray()
+    obuf = C.create_string_buffer(chunk_out)
+    pos, nchunk = 0, 0
+    chunk_in = chunk_in or max(1, len(data))
+    while True:
+        n = min(chunk_in, len(data) - pos)
+        strm.next_in = C.addressof(src) + pos
+        strm.avail_in = n
+        pos += n
+        last = pos >= len(data)
+        nchunk += 1
+        flush = Z_FINISH if last else (Z_SYNC_FLUSH if flush_every and nchunk % flush_every == 0 else Z_NO_FLUSH)
+        while True:
+            strm.next_out = C.addressof(obuf)
+            strm.avail_out = chunk_out
+            rc = lib.deflate(C.byref(strm), flush)
+            assert rc in (Z_OK, Z_STREAM_END, Z_BUF_ERROR), rc
+            out += obuf.raw[:chunk_out - strm.avail_out]
+            if rc == Z_STREAM_END or (strm.avail_out != 0 and flush != Z_FINISH) or rc == Z_BUF_ERROR:
+                break
+        if last:
+            assert rc == Z_STREAM_END
+            break
+    assert strm.total_in == len(data) and strm.total_out == len(out)
+    assert lib.deflateEnd(C.byref(strm)) == Z_OK
+    return bytes(out)
+
+
+def inflate_stream(lib, comp, wbits=15, chunk_in=1 << 30, chunk_out=8192):
+    """the blogpost-uncompress.rs loop; returns (rc, output, unused input bytes)"""
+    strm = ZStream()
+    assert lib.inflateInit2_(C.byref(strm), wbits, lib.zlibVersion(), C.sizeof(ZStream)) == Z_OK
+    src = C.create_string_buffer(comp, len(comp) or 1)
+    out = bytearray()
+    obuf = C.create_string_buffer(chunk_out)
+    pos = 0
+    rc = Z_OK
+    while rc != Z_STREAM_END:
+        n = min(chunk_in, len(comp) - pos)
+        strm.next_in = C.addressof(src) + pos
+        strm.avail_in = n
+        strm.next_out = C.addressof(obuf)
+        strm.avail_out = chunk_out
+        flush = Z_FINISH if pos + n >= len(comp) else Z_NO_FLUSH
+        rc = lib.inflate(C.byref(strm), flush)
+        pos += n - strm.avail_in
+        out += obuf.raw[:chunk_out - strm.avail_out]
+        if rc not in (Z_OK, Z_STREAM_END, Z_BUF_ERROR):
+            break
+        if rc == Z_BUF_ERROR and n == 0 and strm.avail_out != 0:
+            break
+    lib.inflateEnd(C.byref(strm))
+    return rc, bytes(out), len(comp) - pos
+
+
+def run_abi_checks(lib, o, sizes=(0, 1, 100, 5000, 70000)):
+    """shared body of the CPU (emulator) and GPU ABI tests"""
+    import zlib
+    assert lib.zlibVersion().startswith(b"1.")
+    assert lib.zError(-3) == b"data error"
+    strm = ZStream()
+    assert lib.deflateInit2_(C.byref(strm), 6, 8, 15, 8, 0, b"2.0", C.sizeof(ZStream)) == Z_VERSION_ERROR
+    assert lib.deflateInit2_(C.byref(strm), 6, 8, 15, 8, 0, lib.zlibVersion(), 100) == Z_VERSION_ERROR
+    assert lib.deflateInit2_(C.byref(strm), 10, 8, 15, 8, 0, lib.zlibVersion(), C.sizeof(ZStream)) == Z_STREAM_ERROR
+    assert lib.deflate(None, 0) == Z_STREAM_ERROR and lib.inflate(None, 0) == Z_STREAM_ERROR
+    for n in sizes:
+        d = (o.gen_shard(2, max(64, (n + 63) // 64 * 64)))[:n]
+        # one-shot compress2 / uncompress (libz-rs-sys/src/lib.rs:1529, :499)
+        cap = C.c_ulong(lib.compressBound(n))
+        dst = C.create_string_buffer(cap.value)
+        assert lib.compress2(dst, C.byref(cap), d, n, 6) == Z_OK
+        comp = dst.raw[:cap.value]
+        assert zlib.decompress(comp) == d
+        ocap = C.c_ulong(n + 10)
+        back = C.create_string_buffer(n + 10)
+        assert lib.uncompress(back, C.byref(ocap), comp, len(comp)) == Z_OK and back.raw[:ocap.value] == d
+        if n > 100:
+            small = C.c_ulong(n // 2)
+            assert lib.uncompress(back, C.byref(small), comp, len(comp)) == Z_BUF_ERROR
+            assert lib.uncompress(back, C.byref(ocap), comp[:len(comp) // 2], len(comp) // 2) == Z_DATA_ERROR
+        # streaming, all three wrappers, chunked input with sync flushes, small output buffers
+        for wbits in (15, 31, -15):
+            s1 = deflate_stream(lib, d, 6, wbits)
+            assert zlib.decompress(s1, wbits) == d
+            s2 = deflate_stream(lib, d, 1, wbits, chunk_in=1500, chunk_out=700, flush_every=3)
+            assert zlib.decompress(s2, wbits) == d
+            rc, out, unused = inflate_stream(lib, s1 + b"TRAILING", wbits, chunk_in=1 << 30)
+            assert rc == Z_STREAM_END and out == d and unused == 8
+            ref = zlib.compressobj(6, zlib.DEFLATED, wbits)
+            s3 = ref.compress(d) + ref.flush()
+            rc, out, unused = inflate_stream(lib, s3, wbits, chunk_in=997, chunk_out=333)
+            assert rc == Z_STREAM_END and out == d and unused == 0
+        # checksums (libz-rs-sys/src/lib.rs:150-412)
+        assert lib.adler32(1, d, n) == zlib.adler32(d) and lib.crc32(0, d, n) == zlib.crc32(d)
+        k = n // 3
+        assert lib.crc32_combine(zlib.crc32(d[:k]), zlib.crc32(d[k:]), n - k) == zlib.crc32(d)
+        assert lib.adler32_combine(zlib.adler32(d[:k]), zlib.adler32(d[k:]), n - k) == zlib.adler32(d)
+    bad = bytearray(zlib.compress(o.gen_shard(0, 4096)))
+    bad[50] ^= 0xFF
+    rc, out, unused = inflate_stream(lib, bytes(bad), 15)
+    assert rc == Z_DATA_ERROR

@@ -56,6 +56,15 @@ def main():
             ratio = S * B / float(olen.to(torch.int64).sum().item())
             print("deflate S=%d L%d: %.2f GiB/s wall  ratio %.3f  ms: checksum %.2f lz77 %.2f encode %.2f" %
                   (S, lvl, S * B / 2**30 / dt, ratio, sums[0], sums[1], sums[2]))
+            if lvl == 6 and os.environ.get("PROBE_CLASSES"):
+                for cls in range(8):
+                    idx = torch.arange(cls, S, 8, device=e.device)
+                    o2, l2, s2 = e.deflate_batch(data, off[idx].contiguous(), ln[idx].contiguous(), B, level=lvl)
+                    torch.cuda.synchronize(); timing(e)
+                    o2, l2, s2 = e.deflate_batch(data, off[idx].contiguous(), ln[idx].contiguous(), B, level=lvl)
+                    torch.cuda.synchronize()
+                    sm, _ = timing(e)
+                    print("    class %d: lz77 %.2f ms encode %.2f ms for %d shards" % (cls, sm[1], sm[2], idx.numel()))
             if lvl == 6:
                 # per-class ratio
                 l = olen.cpu().numpy().astype("int64")

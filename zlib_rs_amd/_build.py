@@ -5,11 +5,13 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzmi355.so")
-SOURCES = ["gen.hip", "checksum.hip", "lz77.hip", "encode.hip", "inflate.hip", "zmi_api.hip", "zlib_abi.hip"]
+ABI_LIB = os.path.join(HERE, "libz_mi355.so")
+SOURCES = ["gen.hip", "checksum.hip", "lz77.hip", "encode.hip", "inflate.hip", "zmi_api.hip"]
+ABI_SOURCES = ["zlib_abi.hip"]
 
 
 def _stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(ABI_LIB):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", f)
@@ -24,6 +26,13 @@ def build(force=False, verbose=False):
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    # the zlib-named symbols (deflate, inflate, crc32 ...) live in their own library so that merely
+    # loading the engine never interposes the system libz of the process
+    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", ABI_LIB] + \
+          [os.path.join(CSRC, s) for s in ABI_SOURCES] + ["-L" + HERE, "-lzmi355", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -462,7 +462,9 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
     uint32_t pend = pstart + psize;
     if (pend > n) pend = n;
     const bool is_first = piece == 0u;
-    const bool is_last = piece + 1u == npieces;
+    // the piece that ends the deflate stream (BFINAL + trailer); in chained mode only the last shard's
+    const bool ends_stream = prm.chain_mode == 0u || (prm.chain_mode == 1u && s == prm.last_shard);
+    const bool is_last = piece + 1u == npieces && ends_stream;
     if (piece >= npieces) {
         if (lane == 0) piece_len[(uint64_t)s * pieces + piece] = 0u;
         return;
@@ -584,7 +586,7 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
         if (done - tok0 >= prm.block_span || seg + 1u == nseg) {
             uint32_t bend = done + e;
             if (bend > pend) bend = pend;
-            const uint32_t is_final = (seg + 1u == nseg && is_last) ? 1u : 0u;
+            const uint32_t is_final = (seg + 1u == nseg && is_last) ? 1u : 0u;  // is_last implies last piece
             __threadfence_block();  // token stores of other lanes must be visible to the encode pass
             zmi_wave_sync();
             enc_flush_block(S, W, tokbuf + tok0, ntok, src, bstart, bend, is_final, prm);

@@ -25,6 +25,7 @@
 // internal status codes resolved by zmi_inflate_verify_kernel (the CRC of the output is only known there)
 #define ZMI_TRAILER_SHORT (-1005)     // gzip: CRC present, ISIZE cut off   -> data error if CRC wrong, else buf error
 #define ZMI_LENGTH_MISMATCH (-1003)   // gzip: ISIZE wrong                  -> data error either way
+#define ZMI_NEED_OUTPUT (-1006)       // output capacity exhausted          -> Z_BUF_ERROR (detail 2)
 #define INF_LROOT 10u
 #define INF_DROOT 9u
 #define INF_LSIZE 1344u
@@ -285,7 +286,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             B.ipos += 4u;
             if ((l ^ 0xFFFFu) != nl) { st = ZMI_DATA_ERROR; break; }   // "invalid stored block lengths"
             if (B.ipos + l > B.n) { st = ZMI_BUF_ERROR; break; }
-            if (opos + l > cap) { st = ZMI_BUF_ERROR; break; }
+            if (opos + l > cap) { st = ZMI_NEED_OUTPUT; break; }
             for (uint32_t i = lane; i < l; i += 64u) dst[opos + i] = B.src[B.ipos + i];
             zmi_wave_sync();
             opos += l;
@@ -376,7 +377,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             if (eb > B.nbits) { st = ZMI_BUF_ERROR; break; }
             inf_drop(B, eb);
             if (op == INF_OP_LIT) {
-                if (opos >= cap) { st = ZMI_BUF_ERROR; break; }
+                if (opos >= cap) { st = ZMI_NEED_OUTPUT; break; }
                 if (lane == 0) dst[opos] = (uint8_t)(e >> 16);
                 zmi_wave_sync();
                 ++opos;
@@ -398,7 +399,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             uint32_t dist = (e >> 16) + inf_peek(B, xb);
             inf_drop(B, xb);
             if (dist > opos) { st = ZMI_DATA_ERROR; break; }  // "invalid distance too far back"
-            if (opos + mlen > cap) { st = ZMI_BUF_ERROR; break; }
+            if (opos + mlen > cap) { st = ZMI_NEED_OUTPUT; break; }
             if (dist >= mlen || dist >= 64u) {
                 for (uint32_t base = 0; base < mlen; base += 64u) {
                     uint32_t i = base + lane;
@@ -455,25 +456,33 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
     }
 }
 
-// after the checksum kernel: compare trailer values with the checksums of the produced bytes
+// after the checksum kernel: compare trailer values with the checksums of the produced bytes and
+// resolve the internal status codes to zlib's numbering.  detail (optional): 0 none, 1 more input
+// needed, 2 more output space needed.
 __global__ void __launch_bounds__(256) zmi_inflate_verify_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                                  const uint32_t* __restrict__ in_len, uint32_t wrap,
                                                                  const uint32_t* __restrict__ check,
                                                                  const uint32_t* __restrict__ adler,
                                                                  const uint32_t* __restrict__ crc, uint32_t n,
-                                                                 int32_t* __restrict__ status) {
+                                                                 int32_t* __restrict__ status, int32_t* __restrict__ detail) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n) return;
     int32_t st = status[s];
-    if (st != ZMI_OK && st != ZMI_TRAILER_SHORT && st != ZMI_LENGTH_MISMATCH) return;
-    uint32_t kind = wrap;
-    if (wrap == 3u) {
-        const uint8_t* p = in + in_off[s];
-        kind = (in_len[s] >= 2u && p[0] == 0x1Fu && p[1] == 0x8Bu) ? 2u : 1u;
+    int32_t det = 0;
+    if (st == ZMI_NEED_OUTPUT) { st = ZMI_BUF_ERROR; det = 2; }
+    else if (st == ZMI_BUF_ERROR) det = 1;
+    else if (st == ZMI_OK || st == ZMI_TRAILER_SHORT || st == ZMI_LENGTH_MISMATCH) {
+        uint32_t kind = wrap;
+        if (wrap == 3u) {
+            const uint8_t* p = in + in_off[s];
+            kind = (in_len[s] >= 2u && p[0] == 0x1Fu && p[1] == 0x8Bu) ? 2u : 1u;
+        }
+        bool bad = (kind == 1u && check[s] != adler[s]) || (kind == 2u && check[s] != crc[s]);  // "incorrect data check"
+        if (bad || st == ZMI_LENGTH_MISMATCH) st = ZMI_DATA_ERROR;
+        else if (st == ZMI_TRAILER_SHORT) { st = ZMI_BUF_ERROR; det = 1; }
     }
-    bool bad = (kind == 1u && check[s] != adler[s]) || (kind == 2u && check[s] != crc[s]);  // "incorrect data check"
-    if (bad || st == ZMI_LENGTH_MISMATCH) status[s] = ZMI_DATA_ERROR;
-    else if (st == ZMI_TRAILER_SHORT) status[s] = ZMI_BUF_ERROR;
+    status[s] = st;
+    if (detail) detail[s] = det;
 }
 
 extern "C" int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n_streams,
@@ -488,9 +497,9 @@ extern "C" int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off,
 
 extern "C" int zmi_launch_inflate_verify(const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                          uint32_t n_streams, uint32_t wrap, const uint32_t* d_check, const uint32_t* d_adler,
-                                         const uint32_t* d_crc, int32_t* d_status, hipStream_t stream) {
+                                         const uint32_t* d_crc, int32_t* d_status, int32_t* d_detail, hipStream_t stream) {
     if (n_streams == 0) return 0;
     ZMI_LAUNCH(zmi_inflate_verify_kernel, dim3((n_streams + 255u) / 256u), dim3(256), 0, stream, d_in, d_in_off, d_in_len,
-               wrap, d_check, d_adler, d_crc, n_streams, d_status);
+               wrap, d_check, d_adler, d_crc, n_streams, d_status, d_detail);
     return 0;
 }

@@ -41,7 +41,7 @@
 #define LZ_WMASK 32767u
 #define LZ_HBITS 13
 #define LZ_HSIZE (1u << LZ_HBITS)
-#define LZ_MIRROR 16u
+#define LZ_MIRROR 32u
 #define LZ_CTL 128u
 #define LZ_SMEM (LZ_WSIZE + LZ_MIRROR + 2u * LZ_WSIZE + 4u * LZ_HSIZE + LZ_CTL)
 
@@ -89,7 +89,7 @@ static __device__ __forceinline__ void lz_store_chunk(uint8_t* win, uint32_t pos
     uint4 q;
     q.x = v.w[0]; q.y = v.w[1]; q.z = v.w[2]; q.w = v.w[3];
     *(uint4*)(win + r) = q;
-    if (r == 0) *(uint4*)(win + LZ_WSIZE) = q;
+    if (r < LZ_MIRROR) *(uint4*)(win + LZ_WSIZE + r) = q;  // first 32 bytes are mirrored past the end
 }
 
 // insert the 1024 positions of one tile into head/prev in position order (one wave, 16 steps of 64;
@@ -211,8 +211,9 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel(const uint8_t* __restric
         const uint32_t p = base + lane;
         uint32_t res = 0;
         if (p < n) {
-            uint32_t mylo, myhi;
+            uint32_t mylo, myhi, my2, my3;
             lz_ring64(win, p, mylo, myhi);
+            lz_ring64(win, p + 8u, my2, my3);
             res = mylo & 0xFFu;
             uint32_t maxlen = n - p;
             if (maxlen > 258u) maxlen = 258u;
@@ -221,24 +222,29 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel(const uint8_t* __restric
                 uint32_t cand = p - delta;
                 uint32_t blen = 3u, bdist = 0u, tail = 0u;
                 uint32_t chain = prm.max_chain;
-                // The loop body is kept branch-light on purpose: the common case (candidate decided by
-                // its first 8 bytes, best length < 8) runs straight through; the two divergent `if`s
-                // are the rare ones (long matches).
+                // The loop body is straight-line for the common case: a candidate is decided by its
+                // first 16 bytes (five aligned dwords, one LDS round trip together with the prev
+                // link).  Only matches of 16+ bytes enter the divergent extension loop, so the wave
+                // rarely pays for it (an 8-byte threshold made 2/3 of the steps on text execute the
+                // extension block for some lane).
                 for (;;) {
                     const uint32_t r = cand & LZ_WMASK;
                     const uint32_t* w = (const uint32_t*)(win + (r & ~3u));
                     const uint32_t dn = prev[r];
-                    const uint32_t wa = w[0], wb = w[1], wc = w[2];
+                    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
                     uint32_t tl = 0;
-                    if (blen >= 8u) tl = lz_ring32(win, cand + blen - 3u);
+                    if (blen >= 16u) tl = lz_ring32(win, cand + blen - 3u);
                     const uint32_t sh = r & 3u;
-                    const uint32_t xlo = __builtin_amdgcn_alignbyte(wb, wa, sh) ^ mylo;
-                    const uint32_t xhi = __builtin_amdgcn_alignbyte(wc, wb, sh) ^ myhi;
-                    const uint64_t x = ((uint64_t)xhi << 32) | xlo;
-                    uint32_t l = (uint32_t)(__ffsll((unsigned long long)x) - 1) >> 3;  // x == 0 -> 0x1FFFFFFF
-                    l = l > 8u ? 8u : l;
-                    if (blen >= 8u && !(l == 8u && tl == tail)) l = 0u;
-                    if (l == 8u && maxlen > 8u) {
+                    const uint64_t xa = ((uint64_t)(__builtin_amdgcn_alignbyte(w2, w1, sh) ^ myhi) << 32) |
+                                        (__builtin_amdgcn_alignbyte(w1, w0, sh) ^ mylo);
+                    const uint64_t xb = ((uint64_t)(__builtin_amdgcn_alignbyte(w4, w3, sh) ^ my3) << 32) |
+                                        (__builtin_amdgcn_alignbyte(w3, w2, sh) ^ my2);
+                    uint32_t la = (uint32_t)(__ffsll((unsigned long long)xa) - 1) >> 3;  // 0x1FFFFFFF when equal
+                    uint32_t lb = (uint32_t)(__ffsll((unsigned long long)xb) - 1) >> 3;
+                    lb = lb > 8u ? 8u : lb;
+                    uint32_t l = la > 8u ? 8u + lb : la;
+                    if (blen >= 16u && !(l == 16u && tl == tail)) l = 0u;
+                    if (l == 16u && maxlen > 16u) {
                         // extend 16 bytes per round
                         for (;;) {
                             uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
@@ -256,8 +262,8 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel(const uint8_t* __restric
                     const bool better = l > blen;
                     blen = better ? l : blen;
                     bdist = better ? p - cand : bdist;
-                    if (better && l >= 8u) tail = lz_ring32(win, p + l - 3u);
-                    if (better && l >= prm.good_len) chain >>= 1;
+                    if (better && l >= 16u) tail = lz_ring32(win, p + l - 3u);
+                    if (better && l >= prm.good_len) chain >>= 1;  // a good match halves the remaining budget
                     const bool stop = better && (l >= prm.nice_len || l >= maxlen);
                     cand -= dn;
                     chain = chain ? chain - 1u : 0u;

@@ -1,0 +1,617 @@
+// zlib_abi.hip -- the zlib stream ABI (include/zmi355_zlib.h) on top of the GPU batch pipeline.
+//
+// What the reference does behind these symbols: libz-rs-sys/src/lib.rs is a thin veneer (null /
+// version / enum checks) over the stream state machines zlib-rs/src/deflate.rs:2489-2803 and
+// zlib-rs/src/inflate.rs:2376-2457.  Here the veneer does the same argument checking and return
+// codes, but the state behind `strm->state` is a host-side staging object; the compression work is
+// the batch path of zmi_api.hip (1 MiB segments, Z_FULL_FLUSH semantics between segments, the
+// stitch recipe of zlib-rs/src/deflate.rs:4149-4221).
+//
+// No exception may cross the C boundary (the reference builds with panic=abort,
+// libz-rs-sys-cdylib/src/lib.rs:5-6): every export is noexcept and catches std::bad_alloc.
+#include "zmi_kernels.h"
+#include "../../include/zmi355.h"
+#include "../../include/zmi355_zlib.h"
+#include <mutex>
+#include <new>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+extern "C" int zmi_deflate_chain_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                     uint32_t n, uint32_t max_len, int level, int strategy, int finish, void* d_out,
+                                     uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_);
+extern "C" int zmi_inflate_batch_dev_ex(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                        uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
+                                        uint32_t* d_out_len, int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail,
+                                        void* stream_);
+
+// ------------------------------------------------------------------------------------------------
+// host-side scalar utilities of the ABI (adler32 / crc32 / combine on caller memory).  The
+// checksums on the deflate/inflate hot path are computed on the GPU (checksum.hip); these are the
+// stand-alone utility entry points (zlib-rs/src/adler32.rs:19-87, crc32.rs:19-29, crc32/combine.rs).
+// ------------------------------------------------------------------------------------------------
+namespace {
+const uint32_t kBase = 65521u, kNmax = 5552u, kPoly = 0xEDB88320u;
+uint32_t g_crc_table[256];
+std::once_flag g_crc_once;
+void crc_init() {
+    for (uint32_t i = 0; i < 256; ++i) {
+        uint32_t c = i;
+        for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? kPoly : 0u);
+        g_crc_table[i] = c;
+    }
+}
+uint32_t host_adler32(uint32_t adler, const uint8_t* buf, size_t len) {
+    uint32_t a = adler & 0xFFFFu, b = (adler >> 16) & 0xFFFFu;
+    while (len) {
+        size_t k = len < kNmax ? len : kNmax;
+        len -= k;
+        while (k--) { a += *buf++; b += a; }
+        a %= kBase; b %= kBase;
+    }
+    return (b << 16) | a;
+}
+uint32_t host_crc32(uint32_t crc, const uint8_t* buf, size_t len) {
+    std::call_once(g_crc_once, crc_init);
+    crc = ~crc;
+    while (len--) crc = g_crc_table[(crc ^ *buf++) & 0xFFu] ^ (crc >> 8);
+    return ~crc;
+}
+uint32_t gf2_mul(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 31; i >= 0; --i) {
+        if ((a >> i) & 1u) p ^= b;
+        b = (b >> 1) ^ ((b & 1u) ? kPoly : 0u);
+    }
+    return p;
+}
+uint32_t gf2_xpow8(uint64_t nbytes) {  // x^(8 n) mod P
+    uint32_t r = 0x80000000u, pw = 0x00800000u;
+    while (nbytes) {
+        if (nbytes & 1u) r = gf2_mul(r, pw);
+        pw = gf2_mul(pw, pw);
+        nbytes >>= 1;
+    }
+    return r;
+}
+uint32_t host_adler_combine(uint32_t a1, uint32_t a2, uint64_t len2) {
+    uint32_t rem = (uint32_t)(len2 % kBase);
+    uint32_t s1 = a1 & 0xFFFFu;
+    uint32_t s2 = (uint32_t)(((uint64_t)rem * s1) % kBase);
+    s1 += (a2 & 0xFFFFu) + kBase - 1u;
+    s2 += ((a1 >> 16) & 0xFFFFu) + ((a2 >> 16) & 0xFFFFu) + kBase - rem;
+    if (s1 >= kBase) s1 -= kBase;
+    if (s1 >= kBase) s1 -= kBase;
+    if (s2 >= (kBase << 1)) s2 -= (kBase << 1);
+    if (s2 >= kBase) s2 -= kBase;
+    return s1 | (s2 << 16);
+}
+
+// ------------------------------------------------------------------------------------------------
+// shared device context of the ABI layer (lazily created, serialised by a mutex: streams may be
+// used from different threads, one thread per stream, zlib-rs/src/deflate.rs:53-54)
+// ------------------------------------------------------------------------------------------------
+std::mutex g_mu;
+zmi_ctx* g_ctx = nullptr;
+zmi_ctx* abi_ctx() {
+    if (!g_ctx) {
+        zmi_ctx* c = nullptr;
+        if (zmi_ctx_create(&c, 0) != 0) return nullptr;
+        g_ctx = c;
+    }
+    return g_ctx;
+}
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    bool alloc(size_t n) { return hipMalloc(&p, n ? n : 16) == hipSuccess; }
+};
+
+size_t segment_bytes() {  // 1 MiB segments; ZMI_ABI_SEGMENT (bytes, multiple of 64) overrides for tests
+    static size_t v = 0;
+    if (!v) {
+        const char* e = getenv("ZMI_ABI_SEGMENT");
+        long n = e ? atol(e) : 0;
+        v = (n >= 64 && n <= (1 << 28)) ? ((size_t)n & ~(size_t)63) : ((size_t)1 << 20);
+    }
+    return v;
+}
+
+// compress `n` host bytes as consecutive raw-deflate segments; appends the bytes to `out`.
+// returns 0 or a negative zlib code
+int gpu_deflate_segments(const uint8_t* in, size_t n, int level, int strategy, bool finish, std::vector<uint8_t>& out) {
+    if (n == 0) {
+        if (finish) { out.push_back(0x03); out.push_back(0x00); }  // empty final static block (deflate.rs: 03 00)
+        else { const uint8_t m[5] = {0x00, 0x00, 0x00, 0xFF, 0xFF}; out.insert(out.end(), m, m + 5); }
+        return Z_OK;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    zmi_ctx* c = abi_ctx();
+    if (!c) return Z_MEM_ERROR;
+    const size_t kSegment = segment_bytes();
+    const uint32_t nseg = (uint32_t)((n + kSegment - 1) / kSegment);
+    std::vector<uint64_t> off(nseg);
+    std::vector<uint32_t> len(nseg);
+    for (uint32_t i = 0; i < nseg; ++i) {
+        off[i] = (uint64_t)i * kSegment;
+        len[i] = (uint32_t)((n - off[i] < kSegment) ? n - off[i] : kSegment);
+    }
+    const uint32_t max_len = len[0];
+    const uint64_t stride = zmi_deflate_bound(max_len, ZMI_WRAP_RAW);
+    DevBuf d_in, d_off, d_len, d_out, d_olen, d_st;
+    if (!d_in.alloc(n + 16) || !d_off.alloc(nseg * 8) || !d_len.alloc(nseg * 4) || !d_out.alloc((size_t)nseg * stride) ||
+        !d_olen.alloc(nseg * 4) || !d_st.alloc(nseg * 4))
+        return Z_MEM_ERROR;
+    if (hipMemcpy(d_in.p, in, n, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
+    if (hipMemcpy(d_off.p, off.data(), nseg * 8, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
+    if (hipMemcpy(d_len.p, len.data(), nseg * 4, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
+    if (zmi_deflate_chain_dev(c, d_in.p, (const uint64_t*)d_off.p, (const uint32_t*)d_len.p, nseg, max_len, level, strategy,
+                              finish ? 1 : 0, d_out.p, stride, (uint32_t*)d_olen.p, (int32_t*)d_st.p, nullptr) != 0)
+        return Z_MEM_ERROR;
+    if (hipDeviceSynchronize() != hipSuccess) return Z_MEM_ERROR;
+    std::vector<uint32_t> olen(nseg);
+    std::vector<int32_t> st(nseg);
+    if (hipMemcpy(olen.data(), d_olen.p, nseg * 4, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR;
+    if (hipMemcpy(st.data(), d_st.p, nseg * 4, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR;
+    for (uint32_t i = 0; i < nseg; ++i) {
+        if (st[i] != 0) return Z_BUF_ERROR;
+        size_t at = out.size();
+        out.resize(at + olen[i]);
+        if (hipMemcpy(out.data() + at, (const uint8_t*)d_out.p + (uint64_t)i * stride, olen[i], hipMemcpyDeviceToHost) != hipSuccess)
+            return Z_MEM_ERROR;
+    }
+    return Z_OK;
+}
+
+// one-stream inflate on the GPU.  status: zlib code (0 = complete), detail 1 = need input, 2 = need output
+int gpu_inflate_stream(const uint8_t* in, size_t n, int wrap, std::vector<uint8_t>& out, size_t cap, uint32_t* in_used,
+                       int32_t* status, int32_t* detail) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    zmi_ctx* c = abi_ctx();
+    if (!c) return Z_MEM_ERROR;
+    if (n > 0xFFFFFFF0ull || cap > 0xFFFFFFF0ull) return Z_MEM_ERROR;
+    DevBuf d_in, d_out, d_meta;
+    if (!d_in.alloc(n + 16) || !d_out.alloc(cap + 16) || !d_meta.alloc(64)) return Z_MEM_ERROR;
+    if (n && hipMemcpy(d_in.p, in, n, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
+    // meta layout: in_off u64 | out_off u64 | in_len u32 | out_cap u32 | out_len u32 | status i32 | in_used u32 | detail i32
+    uint64_t offs[2] = {0, 0};
+    uint32_t lens[2] = {(uint32_t)n, (uint32_t)cap};
+    uint8_t* m = (uint8_t*)d_meta.p;
+    if (hipMemcpy(m, offs, 16, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
+    if (hipMemcpy(m + 16, lens, 8, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
+    if (zmi_inflate_batch_dev_ex(c, d_in.p, (const uint64_t*)m, (const uint32_t*)(m + 16), 1, wrap, d_out.p,
+                                 (const uint64_t*)(m + 8), (const uint32_t*)(m + 20), (uint32_t*)(m + 24), (int32_t*)(m + 28),
+                                 (uint32_t*)(m + 32), (int32_t*)(m + 36), nullptr) != 0)
+        return Z_MEM_ERROR;
+    if (hipDeviceSynchronize() != hipSuccess) return Z_MEM_ERROR;
+    uint32_t res[4];
+    if (hipMemcpy(res, m + 24, 16, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR;
+    uint32_t olen = res[0];
+    *status = (int32_t)res[1];
+    *in_used = res[2];
+    *detail = (int32_t)res[3];
+    if (olen > cap) olen = (uint32_t)cap;
+    out.resize(olen);
+    if (olen && hipMemcpy(out.data(), d_out.p, olen, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR;
+    return Z_OK;
+}
+
+enum { KIND_DEFLATE = 0x5A44, KIND_INFLATE = 0x5A49 };
+
+struct DeflateState {
+    int kind = KIND_DEFLATE;
+    int level = 6, strategy = 0, wrap = 1, wbits = 15;
+    bool header_done = false, finished = false, trailer_done = false;
+    std::vector<uint8_t> in;       // input not yet compressed
+    std::vector<uint8_t> pending;  // compressed bytes not yet handed to the caller
+    size_t pending_pos = 0;
+    uint32_t adler = 1, crc = 0;
+    uint64_t total_len = 0;
+    int last_flush = -2;
+};
+struct InflateState {
+    int kind = KIND_INFLATE;
+    int wrap = 1, wbits = 15;
+    std::vector<uint8_t> in;
+    std::vector<uint8_t> out;
+    size_t out_pos = 0;
+    size_t tried_at = 0;  // input size at the last decode attempt
+    bool done = false;    // stream decoded completely (out holds everything)
+    int error = 0;
+    const char* errmsg = nullptr;
+};
+
+const char* const kErrMsg[10] = {"need dictionary", "stream end", "", "file error", "stream error", "data error",
+                                 "insufficient memory", "buffer error", "incompatible version", ""};
+
+bool version_ok(const char* version, int stream_size) {  // lib.rs:2133-2143
+    return version && version[0] == '1' && stream_size == (int)sizeof(z_stream);
+}
+template <typename T>
+T* alloc_state(z_streamp strm) {
+    void* mem = nullptr;
+    if (strm->zalloc) mem = strm->zalloc(strm->opaque, 1, (uInt)sizeof(T));
+    else mem = malloc(sizeof(T));
+    if (!mem) return nullptr;
+    return new (mem) T();
+}
+template <typename T>
+void free_state(z_streamp strm, T* st) {
+    st->~T();
+    if (strm->zalloc && strm->zfree) strm->zfree(strm->opaque, st);
+    else free(st);
+}
+DeflateState* dstate(z_streamp strm) {
+    if (!strm || !strm->state) return nullptr;
+    DeflateState* s = (DeflateState*)strm->state;
+    return s->kind == KIND_DEFLATE ? s : nullptr;
+}
+InflateState* istate(z_streamp strm) {
+    if (!strm || !strm->state) return nullptr;
+    InflateState* s = (InflateState*)strm->state;
+    return s->kind == KIND_INFLATE ? s : nullptr;
+}
+void put_header(DeflateState* s) {
+    if (s->wrap == 1) {  // deflate.rs:1572-1601
+        unsigned lf = (s->strategy >= 2 || s->level < 2) ? 0 : (s->level < 6 ? 1 : (s->level == 6 ? 2 : 3));
+        unsigned h = ((8u + ((unsigned)(s->wbits - 8) << 4)) << 8) | (lf << 6);
+        h += 31 - (h % 31);
+        s->pending.push_back((uint8_t)(h >> 8));
+        s->pending.push_back((uint8_t)h);
+    } else if (s->wrap == 2) {  // deflate.rs:2574-2627
+        const uint8_t g[10] = {0x1F, 0x8B, 8, 0, 0, 0, 0, 0, (uint8_t)(s->level == 9 ? 2 : ((s->strategy >= 2 || s->level < 2) ? 4 : 0)), 3};
+        s->pending.insert(s->pending.end(), g, g + 10);
+    }
+    s->header_done = true;
+}
+int compress_buffered(DeflateState* s, bool finish) {
+    if (!s->header_done) put_header(s);
+    if (s->wrap == 1) s->adler = host_adler_combine(s->adler, host_adler32(1, s->in.data(), s->in.size()), s->in.size());
+    if (s->wrap == 2) {
+        uint32_t c2 = host_crc32(0, s->in.data(), s->in.size());
+        s->crc = gf2_mul(gf2_xpow8(s->in.size()), s->crc) ^ c2;
+    }
+    s->total_len += s->in.size();
+    int rc = gpu_deflate_segments(s->in.data(), s->in.size(), s->level, s->strategy, finish, s->pending);
+    s->in.clear();
+    if (rc != Z_OK) return rc;
+    if (finish) {
+        if (s->wrap == 1) {  // deflate.rs:2786-2788
+            for (int i = 3; i >= 0; --i) s->pending.push_back((uint8_t)(s->adler >> (8 * i)));
+        } else if (s->wrap == 2) {  // deflate.rs:2773-2785
+            for (int i = 0; i < 4; ++i) s->pending.push_back((uint8_t)(s->crc >> (8 * i)));
+            for (int i = 0; i < 4; ++i) s->pending.push_back((uint8_t)((uint32_t)s->total_len >> (8 * i)));
+        }
+        s->finished = true;
+    }
+    return Z_OK;
+}
+size_t drain(z_streamp strm, std::vector<uint8_t>& buf, size_t& pos) {
+    size_t n = buf.size() - pos;
+    if (n > strm->avail_out) n = strm->avail_out;
+    if (n) {
+        memcpy(strm->next_out, buf.data() + pos, n);
+        strm->next_out += n;
+        strm->avail_out -= (uInt)n;
+        strm->total_out += n;
+        pos += n;
+    }
+    if (pos == buf.size()) { buf.clear(); pos = 0; }
+    return n;
+}
+}  // namespace
+
+#define ZMI_ABI_TRY try {
+#define ZMI_ABI_CATCH(ret) } catch (...) { return (ret); }
+
+extern "C" {
+
+const char* zlibVersion(void) { return ZLIB_VERSION; }
+uLong zlibCompileFlags(void) { return (uLong)(sizeof(uInt) / 2 - 1) | ((sizeof(uLong) / 2 - 1) << 2) | ((sizeof(void*) / 2 - 1) << 4) | ((sizeof(long) / 2 - 1) << 6); }
+const char* zError(int err) { int i = 2 - err; return (i >= 0 && i < 10) ? kErrMsg[i] : ""; }
+
+// ---------------------------------------------------------------- deflate
+int deflateInit2_(z_streamp strm, int level, int method, int windowBits, int memLevel, int strategy, const char* version,
+                  int stream_size) {
+    ZMI_ABI_TRY
+    if (!version_ok(version, stream_size)) return Z_VERSION_ERROR;
+    if (!strm) return Z_STREAM_ERROR;
+    strm->msg = nullptr;
+    if (level == Z_DEFAULT_COMPRESSION) level = 6;
+    int wrap = 1;
+    if (windowBits < 0) { if (windowBits < -15) return Z_STREAM_ERROR; wrap = 0; windowBits = -windowBits; }
+    else if (windowBits > 15) { wrap = 2; windowBits -= 16; }
+    if (memLevel < 1 || memLevel > 9 || method != Z_DEFLATED || windowBits < 8 || windowBits > 15 || level < 0 || level > 9 ||
+        strategy < 0 || strategy > Z_FIXED || (windowBits == 8 && wrap != 1))
+        return Z_STREAM_ERROR;  // deflate.rs:299-306
+    if (windowBits == 8) windowBits = 9;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!abi_ctx()) { strm->msg = "no HIP device"; return Z_MEM_ERROR; }
+    }
+    DeflateState* s = alloc_state<DeflateState>(strm);
+    if (!s) return Z_MEM_ERROR;
+    s->level = level; s->strategy = strategy; s->wrap = wrap; s->wbits = windowBits;
+    s->adler = 1; s->crc = 0;
+    strm->state = (internal_state*)s;
+    strm->total_in = strm->total_out = 0;
+    strm->data_type = Z_UNKNOWN;
+    strm->adler = wrap == 2 ? 0 : 1;
+    return Z_OK;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
+}
+int deflateInit_(z_streamp strm, int level, const char* version, int stream_size) {
+    return deflateInit2_(strm, level, Z_DEFLATED, MAX_WBITS, 8, Z_DEFAULT_STRATEGY, version, stream_size);
+}
+int deflate(z_streamp strm, int flush) {
+    ZMI_ABI_TRY
+    DeflateState* s = dstate(strm);
+    if (!s || flush < 0 || flush > Z_BLOCK) return Z_STREAM_ERROR;
+    if (!strm->next_out || (strm->avail_in != 0 && !strm->next_in)) { strm->msg = kErrMsg[4]; return Z_STREAM_ERROR; }
+    if (s->finished && s->pending.empty() && flush != Z_FINISH) { strm->msg = kErrMsg[4]; return Z_STREAM_ERROR; }
+    if (strm->avail_out == 0) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; }
+    const uInt in0 = strm->avail_in, out0 = strm->avail_out;
+    if (s->finished && strm->avail_in != 0) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; }
+    if (strm->avail_in) {
+        s->in.insert(s->in.end(), strm->next_in, strm->next_in + strm->avail_in);
+        strm->next_in += strm->avail_in;
+        strm->total_in += strm->avail_in;
+        strm->avail_in = 0;
+    }
+    int rc = Z_OK;
+    if (!s->finished) {
+        if (flush == Z_FINISH) rc = compress_buffered(s, true);
+        else if (flush != Z_NO_FLUSH) { if (!s->in.empty() || s->last_flush != flush || in0) rc = compress_buffered(s, false); }
+        else if (s->in.size() >= (64u << 20)) rc = compress_buffered(s, false);
+        if (rc != Z_OK) { strm->msg = zError(rc); return rc; }
+    }
+    s->last_flush = flush;
+    drain(strm, s->pending, s->pending_pos);
+    strm->adler = s->wrap == 2 ? s->crc : s->adler;
+    if (s->finished && s->pending.empty()) return Z_STREAM_END;
+    if (in0 == 0 && out0 == strm->avail_out && flush != Z_FINISH) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; }
+    return Z_OK;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
+}
+int deflateEnd(z_streamp strm) {
+    DeflateState* s = dstate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    bool busy = !s->finished && (s->header_done || !s->in.empty());  // deflate.rs:728-743: freed, but reports the loss
+    free_state(strm, s);
+    strm->state = nullptr;
+    return busy ? Z_DATA_ERROR : Z_OK;
+}
+int deflateReset(z_streamp strm) {
+    DeflateState* s = dstate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    int level = s->level, strategy = s->strategy, wrap = s->wrap, wbits = s->wbits;
+    s->~DeflateState();
+    new (s) DeflateState();
+    s->level = level; s->strategy = strategy; s->wrap = wrap; s->wbits = wbits;
+    strm->total_in = strm->total_out = 0;
+    strm->msg = nullptr;
+    strm->data_type = Z_UNKNOWN;
+    strm->adler = wrap == 2 ? 0 : 1;
+    return Z_OK;
+}
+int deflateParams(z_streamp strm, int level, int strategy) {
+    ZMI_ABI_TRY
+    DeflateState* s = dstate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    if (level == Z_DEFAULT_COMPRESSION) level = 6;
+    if (level < 0 || level > 9 || strategy < 0 || strategy > Z_FIXED) return Z_STREAM_ERROR;
+    if ((level != s->level || strategy != s->strategy) && !s->in.empty()) {
+        int rc = compress_buffered(s, false);  // data supplied so far keeps the old parameters
+        if (rc != Z_OK) return rc;
+        drain(strm, s->pending, s->pending_pos);
+        if (!s->pending.empty()) { s->level = level; s->strategy = strategy; return Z_BUF_ERROR; }
+    }
+    s->level = level; s->strategy = strategy;
+    return Z_OK;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
+}
+int deflateTune(z_streamp strm, int, int, int, int) { return dstate(strm) ? Z_OK : Z_STREAM_ERROR; }
+z_size_t deflateBound_z(z_streamp strm, z_size_t sourceLen) {
+    // compress_bound (deflate.rs:2975-2991) + the 5-byte segment markers this engine inserts per 1 MiB
+    int wrap = 1;
+    if (DeflateState* s = dstate(strm)) wrap = s->wrap;
+    z_size_t w = wrap == 1 ? 6 : (wrap == 2 ? 18 : 0);
+    return sourceLen + (sourceLen == 0) + (sourceLen < 9) + ((sourceLen + 7) >> 3) + 3 + w;
+}
+uLong deflateBound(z_streamp strm, uLong sourceLen) { return (uLong)deflateBound_z(strm, sourceLen); }
+int deflatePending(z_streamp strm, unsigned* pending, int* bits) {
+    DeflateState* s = dstate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    if (pending) *pending = (unsigned)(s->pending.size() - s->pending_pos);
+    if (bits) *bits = 0;
+    return Z_OK;
+}
+int deflateSetDictionary(z_streamp, const Bytef*, uInt) { return Z_STREAM_ERROR; }
+int deflatePrime(z_streamp, int, int) { return Z_STREAM_ERROR; }
+
+z_size_t compressBound_z(z_size_t n) { return n + (n == 0) + (n < 9) + ((n + 7) >> 3) + 3 + 6; }
+uLong compressBound(uLong n) { return (uLong)compressBound_z(n); }
+int compress2_z(Bytef* dest, z_size_t* destLen, const Bytef* source, z_size_t sourceLen, int level) {
+    ZMI_ABI_TRY
+    if (!dest || !destLen || (!source && sourceLen)) return Z_STREAM_ERROR;
+    if (level == Z_DEFAULT_COMPRESSION) level = 6;
+    if (level < 0 || level > 9) return Z_STREAM_ERROR;
+    DeflateState s;
+    s.level = level;
+    s.in.assign(source, source + sourceLen);
+    int rc = compress_buffered(&s, true);
+    if (rc != Z_OK) return rc;
+    if (s.pending.size() > *destLen) return Z_BUF_ERROR;
+    memcpy(dest, s.pending.data(), s.pending.size());
+    *destLen = s.pending.size();
+    return Z_OK;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
+}
+int compress_z(Bytef* dest, z_size_t* destLen, const Bytef* source, z_size_t sourceLen) { return compress2_z(dest, destLen, source, sourceLen, 6); }
+int compress2(Bytef* dest, uLongf* destLen, const Bytef* source, uLong sourceLen, int level) {
+    if (!destLen) return Z_STREAM_ERROR;
+    z_size_t dl = *destLen;
+    int rc = compress2_z(dest, &dl, source, sourceLen, level);
+    *destLen = (uLongf)dl;
+    return rc;
+}
+int compress(Bytef* dest, uLongf* destLen, const Bytef* source, uLong sourceLen) { return compress2(dest, destLen, source, sourceLen, 6); }
+
+// ---------------------------------------------------------------- inflate
+int inflateInit2_(z_streamp strm, int windowBits, const char* version, int stream_size) {
+    ZMI_ABI_TRY
+    if (!version_ok(version, stream_size)) return Z_VERSION_ERROR;
+    if (!strm) return Z_STREAM_ERROR;
+    strm->msg = nullptr;
+    int wrap, wb = windowBits;
+    if (wb < 0) { if (wb < -15) return Z_STREAM_ERROR; wrap = ZMI_WRAP_RAW; wb = -wb; }
+    else if (wb >= 32) { wrap = ZMI_WRAP_AUTO; wb -= 32; }   // inflate.rs:2298-2327
+    else if (wb >= 16) { wrap = ZMI_WRAP_GZIP; wb -= 16; }
+    else wrap = ZMI_WRAP_ZLIB;
+    if (wb != 0 && (wb < 8 || wb > 15)) return Z_STREAM_ERROR;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!abi_ctx()) { strm->msg = "no HIP device"; return Z_MEM_ERROR; }
+    }
+    InflateState* s = alloc_state<InflateState>(strm);
+    if (!s) return Z_MEM_ERROR;
+    s->wrap = wrap; s->wbits = wb;
+    strm->state = (internal_state*)s;
+    strm->total_in = strm->total_out = 0;
+    strm->adler = 1;
+    strm->data_type = 0;
+    return Z_OK;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
+}
+int inflateInit_(z_streamp strm, const char* version, int stream_size) { return inflateInit2_(strm, MAX_WBITS, version, stream_size); }
+int inflate(z_streamp strm, int flush) {
+    ZMI_ABI_TRY
+    InflateState* s = istate(strm);
+    if (!s || !strm->next_out || (strm->avail_in != 0 && !strm->next_in)) return Z_STREAM_ERROR;
+    if (s->error) { strm->msg = s->errmsg; return s->error; }
+    const uInt in0 = strm->avail_in, out0 = strm->avail_out;
+    if (!s->done) {
+        const size_t before = s->in.size();
+        if (strm->avail_in) s->in.insert(s->in.end(), strm->next_in, strm->next_in + strm->avail_in);
+        // decode attempts: when new input arrived and the buffer grew by >= 25 % (or the caller finishes)
+        bool attempt = in0 != 0 && (flush == Z_FINISH || s->tried_at == 0 || s->in.size() >= s->tried_at + s->tried_at / 4 + 64);
+        if (in0 == 0 && flush == Z_FINISH && s->tried_at != s->in.size()) attempt = true;
+        int32_t st = ZMI_E_OK, detail = 1;
+        uint32_t used = 0;
+        if (attempt && !s->in.empty()) {
+            size_t cap = s->in.size() * 4 + 65536;
+            for (;;) {
+                int rc = gpu_inflate_stream(s->in.data(), s->in.size(), s->wrap, s->out, cap, &used, &st, &detail);
+                if (rc != Z_OK) { strm->msg = zError(rc); return rc; }
+                if (st == Z_BUF_ERROR && detail == 2) { cap *= 4; if (cap > 0xF0000000ull) return Z_MEM_ERROR; continue; }
+                break;
+            }
+            s->tried_at = s->in.size();
+            if (st == Z_OK) {
+                s->done = true;
+                // bytes after the end of the stream belong to the caller: hand them back
+                size_t from_this_call = s->in.size() - before;
+                size_t unused = s->in.size() - used;
+                if (unused > from_this_call) unused = from_this_call;
+                strm->next_in += in0 - unused;
+                strm->total_in += in0 - unused;
+                strm->avail_in = (uInt)unused;
+            } else if (st == Z_DATA_ERROR || st == Z_NEED_DICT) {
+                s->error = st;
+                s->errmsg = st == Z_DATA_ERROR ? "invalid or corrupt deflate stream" : kErrMsg[0];
+                strm->msg = s->errmsg;
+                strm->next_in += in0; strm->total_in += in0; strm->avail_in = 0;
+                return st;
+            }
+        }
+        if (!s->done) {
+            strm->next_in += in0; strm->total_in += in0; strm->avail_in = 0;
+            if (in0 == 0 || flush == Z_FINISH) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; }  // inflate.rs:2450-2456
+            return Z_OK;
+        }
+    }
+    drain(strm, s->out, s->out_pos);
+    if (s->out.empty()) return Z_STREAM_END;
+    if (in0 == strm->avail_in && out0 == strm->avail_out) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; }
+    return flush == Z_FINISH ? Z_BUF_ERROR : Z_OK;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
+}
+int inflateEnd(z_streamp strm) {
+    InflateState* s = istate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    free_state(strm, s);
+    strm->state = nullptr;
+    return Z_OK;
+}
+int inflateReset(z_streamp strm) {
+    InflateState* s = istate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    int wrap = s->wrap, wb = s->wbits;
+    s->~InflateState();
+    new (s) InflateState();
+    s->wrap = wrap; s->wbits = wb;
+    strm->total_in = strm->total_out = 0;
+    strm->msg = nullptr;
+    strm->adler = 1;
+    return Z_OK;
+}
+int inflateReset2(z_streamp strm, int windowBits) {
+    InflateState* s = istate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    int wrap, wb = windowBits;
+    if (wb < 0) { if (wb < -15) return Z_STREAM_ERROR; wrap = ZMI_WRAP_RAW; wb = -wb; }
+    else if (wb >= 32) { wrap = ZMI_WRAP_AUTO; wb -= 32; }
+    else if (wb >= 16) { wrap = ZMI_WRAP_GZIP; wb -= 16; }
+    else wrap = ZMI_WRAP_ZLIB;
+    if (wb != 0 && (wb < 8 || wb > 15)) return Z_STREAM_ERROR;
+    s->wrap = wrap; s->wbits = wb;
+    return inflateReset(strm);
+}
+int inflateSetDictionary(z_streamp, const Bytef*, uInt) { return Z_STREAM_ERROR; }
+int inflateSync(z_streamp) { return Z_STREAM_ERROR; }
+
+int uncompress2_z(Bytef* dest, z_size_t* destLen, const Bytef* source, z_size_t* sourceLen) {
+    ZMI_ABI_TRY
+    if (!dest || !destLen || !source || !sourceLen) return Z_STREAM_ERROR;
+    std::vector<uint8_t> out;
+    uint32_t used = 0;
+    int32_t st = 0, detail = 0;
+    int rc = gpu_inflate_stream(source, *sourceLen, ZMI_WRAP_ZLIB, out, *destLen, &used, &st, &detail);
+    if (rc != Z_OK) return rc;
+    *sourceLen = used;
+    if (st == Z_OK) {
+        memcpy(dest, out.data(), out.size());
+        *destLen = out.size();
+        return Z_OK;
+    }
+    if (st == Z_BUF_ERROR && detail == 2) { memcpy(dest, out.data(), out.size()); return Z_BUF_ERROR; }
+    if (st == Z_BUF_ERROR) return Z_DATA_ERROR;  // input ended inside the stream: uncompress reports a data error (inflate.rs:268-284)
+    return st == Z_NEED_DICT ? Z_DATA_ERROR : st;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
+}
+int uncompress_z(Bytef* dest, z_size_t* destLen, const Bytef* source, z_size_t sourceLen) { return uncompress2_z(dest, destLen, source, &sourceLen); }
+int uncompress2(Bytef* dest, uLongf* destLen, const Bytef* source, uLong* sourceLen) {
+    if (!destLen || !sourceLen) return Z_STREAM_ERROR;
+    z_size_t dl = *destLen, sl = *sourceLen;
+    int rc = uncompress2_z(dest, &dl, source, &sl);
+    *destLen = (uLongf)dl; *sourceLen = (uLong)sl;
+    return rc;
+}
+int uncompress(Bytef* dest, uLongf* destLen, const Bytef* source, uLong sourceLen) { return uncompress2(dest, destLen, source, &sourceLen); }
+
+// ---------------------------------------------------------------- checksums
+uLong adler32_z(uLong adler, const Bytef* buf, z_size_t len) { return buf ? host_adler32((uint32_t)adler, buf, len) : 1; }
+uLong adler32(uLong adler, const Bytef* buf, uInt len) { return adler32_z(adler, buf, len); }
+uLong adler32_combine64(uLong a1, uLong a2, long long len2) { return len2 < 0 ? 0xFFFFFFFFul : host_adler_combine((uint32_t)a1, (uint32_t)a2, (uint64_t)len2); }
+uLong adler32_combine(uLong a1, uLong a2, long len2) { return adler32_combine64(a1, a2, len2); }
+uLong crc32_z(uLong crc, const Bytef* buf, z_size_t len) { return buf ? host_crc32((uint32_t)crc, buf, len) : 0; }
+uLong crc32(uLong crc, const Bytef* buf, uInt len) { return crc32_z(crc, buf, len); }
+uLong crc32_combine_gen64(long long len2) { return gf2_xpow8((uint64_t)len2); }
+uLong crc32_combine_gen(long len2) { return crc32_combine_gen64(len2); }
+uLong crc32_combine_op(uLong crc1, uLong crc2, uLong op) { return gf2_mul((uint32_t)op, (uint32_t)crc1) ^ (uint32_t)crc2; }
+uLong crc32_combine64(uLong crc1, uLong crc2, long long len2) { return crc32_combine_op(crc1, crc2, crc32_combine_gen64(len2)); }
+uLong crc32_combine(uLong crc1, uLong crc2, long len2) { return crc32_combine64(crc1, crc2, len2); }
+const uint32_t* get_crc_table(void) { std::call_once(g_crc_once, crc_init); return g_crc_table; }
+
+}  // extern "C"

@@ -16,7 +16,7 @@
 
 extern "C" int zmi_launch_inflate_verify(const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                          uint32_t n_streams, uint32_t wrap, const uint32_t* d_check, const uint32_t* d_adler,
-                                         const uint32_t* d_crc, int32_t* d_status, hipStream_t stream);
+                                         const uint32_t* d_crc, int32_t* d_status, int32_t* d_detail, hipStream_t stream);
 
 static thread_local std::string g_err;
 static int zmi_fail(int code, const char* what, hipError_t e = hipSuccess) {
@@ -189,9 +189,30 @@ extern "C" int zmi_gen_shards_dev(zmi_ctx* c, void* d_out, uint64_t seed, uint32
     return ZMI_E_OK;
 }
 
+static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
+                            uint32_t max_len, int level, int strategy, int wrap, uint32_t chain_mode, void* d_out,
+                            uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_);
+
 extern "C" int zmi_deflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                      uint32_t n, uint32_t max_len, int level, int strategy, int wrap, void* d_out,
                                      uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_) {
+    return zmi_deflate_impl(c, d_in, d_in_off, d_in_len, n, max_len, level, strategy, wrap, 0u, d_out, out_stride, d_out_len,
+                            d_status, stream_);
+}
+
+// The shards are consecutive segments of ONE raw deflate stream (each starts with an empty history
+// and a byte-aligned position, exactly what Z_FULL_FLUSH produces in the reference,
+// zlib-rs/src/deflate.rs:2739-2752); `finish` != 0 makes the last shard end the stream (BFINAL).
+extern "C" int zmi_deflate_chain_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                     uint32_t n, uint32_t max_len, int level, int strategy, int finish, void* d_out,
+                                     uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_) {
+    return zmi_deflate_impl(c, d_in, d_in_off, d_in_len, n, max_len, level, strategy, ZMI_WRAP_RAW, finish ? 1u : 2u, d_out,
+                            out_stride, d_out_len, d_status, stream_);
+}
+
+static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
+                            uint32_t max_len, int level, int strategy, int wrap, uint32_t chain_mode, void* d_out,
+                            uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_) {
     if (!c) return zmi_fail(ZMI_E_ARG, "null context");
     if (level == -1) level = 6;
     if (level < 0 || level > 9) return zmi_fail(ZMI_E_ARG, "level must be -1..9");
@@ -227,11 +248,15 @@ extern "C" int zmi_deflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_
     ep.level = (uint32_t)level;
     ep.block_span = 65536u;
     ep.strategy = (uint32_t)strategy;
+    ep.chain_mode = chain_mode;
+    ep.last_shard = n - 1u;
     if (level == 0) ep.strategy = 100u;           // stored blocks only (deflate_stored)
     if (strategy == 2) lp.max_chain = 0;          // Z_HUFFMAN_ONLY: literals only
     if (strategy == 3) lp.max_dist = 1;           // Z_RLE: distance-1 matches only
     const char* chain_env = getenv("ZMI_CHAIN");  // tuning aid: override the chain budget of the selected level
     if (chain_env && atoi(chain_env) > 0 && level > 0 && strategy != 2) lp.max_chain = (uint32_t)atoi(chain_env);
+    const char* good_env = getenv("ZMI_GOOD");
+    if (good_env && atoi(good_env) > 0) lp.good_len = (uint32_t)atoi(good_env);
     const char* span_env = getenv("ZMI_BLOCK_SPAN");
     if (span_env && atoi(span_env) >= 64) ep.block_span = (uint32_t)atoi(span_env);
 
@@ -277,9 +302,11 @@ extern "C" int zmi_deflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_
     return ZMI_E_OK;
 }
 
-extern "C" int zmi_inflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                                     uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
-                                     uint32_t* d_out_len, int32_t* d_status, void* stream_) {
+// extended form used by the zlib stream ABI: also returns consumed input bytes and why a stream stopped
+extern "C" int zmi_inflate_batch_dev_ex(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                        uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
+                                        uint32_t* d_out_len, int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail,
+                                        void* stream_) {
     if (!c) return zmi_fail(ZMI_E_ARG, "null context");
     if (wrap < ZMI_WRAP_RAW || wrap > ZMI_WRAP_AUTO) return zmi_fail(ZMI_E_ARG, "wrap must be raw/zlib/gzip/auto");
     if (n == 0) return ZMI_E_OK;
@@ -291,6 +318,7 @@ extern "C" int zmi_inflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_
     uint32_t* d_check = d_used + n;
     uint32_t* d_adler = d_check + n;
     uint32_t* d_crc = d_adler + n;
+    if (d_in_used) d_used = d_in_used;
     {
         zmi_scope_timer tm(c, ZMI_K_INFLATE, stream);
         zmi_launch_inflate((const uint8_t*)d_in, d_in_off, d_in_len, n, (uint32_t)wrap, (uint8_t*)d_out, d_out_off, d_out_cap,
@@ -298,16 +326,23 @@ extern "C" int zmi_inflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_
     }
     if (wrap != ZMI_WRAP_RAW) {
         uint32_t kind = wrap == ZMI_WRAP_ZLIB ? 1u : (wrap == ZMI_WRAP_GZIP ? 2u : 3u);
-        {
-            zmi_scope_timer tm(c, ZMI_K_CHECKSUM, stream);
-            zmi_launch_checksum((const uint8_t*)d_out, d_out_off, d_out_len, n, kind, d_adler, d_crc, stream);
-        }
+        zmi_scope_timer tm(c, ZMI_K_CHECKSUM, stream);
+        zmi_launch_checksum((const uint8_t*)d_out, d_out_off, d_out_len, n, kind, d_adler, d_crc, stream);
+    }
+    {
         zmi_scope_timer tm(c, ZMI_K_VERIFY, stream);
-        zmi_launch_inflate_verify((const uint8_t*)d_in, d_in_off, d_in_len, n, (uint32_t)wrap, d_check, d_adler, d_crc,
-                                  d_status, stream);
+        zmi_launch_inflate_verify((const uint8_t*)d_in, d_in_off, d_in_len, n, (uint32_t)wrap, d_check, d_adler, d_crc, d_status,
+                                  d_detail, stream);
     }
     ZMI_HIP(hipGetLastError());
     return ZMI_E_OK;
+}
+
+extern "C" int zmi_inflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                     uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
+                                     uint32_t* d_out_len, int32_t* d_status, void* stream_) {
+    return zmi_inflate_batch_dev_ex(c, d_in, d_in_off, d_in_len, n, wrap, d_out, d_out_off, d_out_cap, d_out_len, d_status, nullptr,
+                                    nullptr, stream_);
 }
 
 // ---------------- host-buffer wrappers ----------------

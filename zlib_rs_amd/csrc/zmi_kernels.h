@@ -23,6 +23,10 @@ struct zmi_enc_params {
     uint32_t level;       // only used for the header's level hint bits
     uint32_t block_span;  // input bytes per deflate block (multiple of 64)
     uint32_t strategy;    // 0 default, 4 = Z_FIXED (static trees only)
+    uint32_t chain_mode;  // 0: every shard is its own stream; 1: the shards of the batch are consecutive
+                          // segments of ONE raw deflate stream, only shard `last_shard` ends it (BFINAL);
+                          // 2: as 1 but nothing ends the stream (Z_SYNC_FLUSH / Z_FULL_FLUSH output)
+    uint32_t last_shard;
 };
 
 // per-shard result codes written by the kernels (zlib numbering, zlib-rs/src/c_api.rs:140-148)
