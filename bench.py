@@ -23,38 +23,30 @@ GIB = float(1 << 30)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(shard_bytes, level, budget_s=20.0):
-    """oracle level-`level` deflate of the same synthetic shards on all host cores (bounded sample)."""
-    import ctypes as C  # noqa: F401
-    from concurrent.futures import ThreadPoolExecutor
+def cpu_baseline(shard_bytes, level, budget_s=15.0):
+    """oracle level-`level` deflate (C restatement of the reference) of the same synthetic shards on all
+    host cores: POSIX threads inside the oracle library (zo_bench_deflate), bounded sample."""
+    import ctypes as C
     import oracle_lib
     o = oracle_lib.load(rebuild=False)
-    if not hasattr(o.lib, "zo_deflate"):
+    if not hasattr(o.lib, "zo_bench_deflate"):
         return None
+    o.lib.zo_bench_deflate.restype = C.c_double
+    o.lib.zo_bench_deflate.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
     cores = os.cpu_count() or 1
-    # calibrate on one shard, then size the sample to ~budget_s seconds of wall time
-    s0 = o.gen_shard(0, shard_bytes)
-    t = time.perf_counter()
-    rc, c0 = o.deflate(s0, level, 1)
-    dt = max(time.perf_counter() - t, 1e-4)
-    n = int(max(cores, min(4096, budget_s / dt * cores)))
-    n -= n % 8 if n >= 8 else 0
-    shards = [o.gen_shard(i, shard_bytes) for i in range(n)]
-
-    def work(i):
-        rc, c = o.deflate(shards[i], level, 1)
-        return len(c)
-    t = time.perf_counter()
-    with ThreadPoolExecutor(cores) as ex:
-        sizes = list(ex.map(work, range(n)))
-    wall = time.perf_counter() - t
-    t1 = time.perf_counter()
-    for i in range(min(n, 8)):
-        work(i)
-    one = (time.perf_counter() - t1) / min(n, 8)
-    return {"value": n * shard_bytes / GIB / wall, "unit": "GiB/s", "cores": cores, "kind": "port",
-            "sample": "%d x %d B synthetic shards (classes 0-7), oracle zo_deflate level %d, %d threads" % (n, shard_bytes, level, cores),
-            "single_thread_GiB_s": shard_bytes / GIB / one, "ratio": n * shard_bytes / float(sum(sizes))}
+    tot = C.c_uint64(0)
+    # single thread: 8 shards (one of each class)
+    t1 = o.lib.zo_bench_deflate(0x5A4C4942, 0, 8, shard_bytes, level, 1, C.byref(tot))
+    one = 8 * shard_bytes / GIB / t1
+    # all cores: size the sample to ~budget_s seconds, a multiple of 8 shards per thread
+    per_thread = max(8, int(budget_s / (t1 / 8.0)) // 8 * 8)
+    n = min(cores * per_thread, 16384, max(cores * 8, int(24 * GIB / shard_bytes)))
+    n -= n % 8
+    tall = o.lib.zo_bench_deflate(0x5A4C4942, 0, n, shard_bytes, level, cores, C.byref(tot))
+    return {"value": n * shard_bytes / GIB / tall, "unit": "GiB/s", "cores": cores, "kind": "port",
+            "sample": "%d x %d B synthetic shards (classes 0-7), oracle zo_deflate level %d, %d POSIX threads, %.1f s"
+                      % (n, shard_bytes, level, cores, tall),
+            "single_thread_GiB_s": one, "ratio": n * shard_bytes / float(tot.value)}
 
 
 def main():

@@ -955,3 +955,60 @@ int zo_deflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, i
                int mem_level, size_t* out_len) {
     return zo_deflate2(in, in_len, out, out_cap, level, wrap, strategy, mem_level, 15, out_len);
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-threaded timing harness for bench.py's cpu_baseline leg: generates `n_shards` synthetic
+ * shards (csrc/shardgen.h), then compresses them with zo_deflate on `nthreads` POSIX threads
+ * (static partition, one deflate state per call exactly as blogpost-compress.rs:43-122 drives the
+ * reference).  Only the compression is timed.  Returns seconds; *total_out = compressed bytes.
+ * ---------------------------------------------------------------------------------------- */
+#include <pthread.h>
+#include <time.h>
+void zo_gen_shard(uint64_t seed, uint32_t shard, uint32_t nbytes, uint8_t* out);
+
+typedef struct {
+    uint8_t* data; uint32_t shard_bytes, first, count; int level; uint64_t out_bytes; uint8_t* scratch; size_t cap;
+    pthread_barrier_t* bar;
+} zo_job;
+static void* zo_bench_worker(void* arg) {
+    zo_job* j = (zo_job*)arg;
+    pthread_barrier_wait(j->bar);
+    for (uint32_t i = 0; i < j->count; ++i) {
+        size_t olen = 0;
+        zo_deflate(j->data + (size_t)(j->first + i) * j->shard_bytes, j->shard_bytes, j->scratch, j->cap, j->level, 1, 0, 8, &olen);
+        j->out_bytes += olen;
+    }
+    pthread_barrier_wait(j->bar);
+    return NULL;
+}
+static double zo_now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+double zo_bench_deflate(uint64_t seed, uint32_t first_shard, uint32_t n_shards, uint32_t shard_bytes, int level, int nthreads,
+                        uint64_t* total_out) {
+    if (nthreads < 1) nthreads = 1;
+    if ((uint32_t)nthreads > n_shards) nthreads = (int)n_shards;
+    uint8_t* data = (uint8_t*)malloc((size_t)n_shards * shard_bytes);
+    if (!data) return -1.0;
+    for (uint32_t i = 0; i < n_shards; ++i) zo_gen_shard(seed, first_shard + i, shard_bytes, data + (size_t)i * shard_bytes);
+    pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+    zo_job* jobs = (zo_job*)calloc((size_t)nthreads, sizeof(zo_job));
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, (unsigned)nthreads + 1);
+    size_t cap = shard_bytes + shard_bytes / 8 + 4096;
+    uint32_t per = n_shards / (uint32_t)nthreads, extra = n_shards % (uint32_t)nthreads, at = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        jobs[t].data = data; jobs[t].shard_bytes = shard_bytes; jobs[t].first = at;
+        jobs[t].count = per + ((uint32_t)t < extra ? 1u : 0u); at += jobs[t].count;
+        jobs[t].level = level; jobs[t].scratch = (uint8_t*)malloc(cap); jobs[t].cap = cap; jobs[t].bar = &bar;
+        pthread_create(&th[t], NULL, zo_bench_worker, &jobs[t]);
+    }
+    pthread_barrier_wait(&bar);
+    double t0 = zo_now();
+    pthread_barrier_wait(&bar);
+    double dt = zo_now() - t0;
+    uint64_t tot = 0;
+    for (int t = 0; t < nthreads; ++t) { pthread_join(th[t], NULL); tot += jobs[t].out_bytes; free(jobs[t].scratch); }
+    pthread_barrier_destroy(&bar);
+    free(th); free(jobs); free(data);
+    if (total_out) *total_out = tot;
+    return dt;
+}

@@ -373,13 +373,16 @@ static __device__ void enc_flush_block(EncShared* S, EncWriter& W, const uint32_
     if (choice != 0u) {
         W.rel = S->misc[M_REL];
         enc_flush(S, W);
-        // tokens + the end-of-block symbol as virtual token index ntok
+        // tokens + the end-of-block symbol as virtual token index ntok; the next group's tokens are
+        // fetched while the current group is encoded (the HBM/L2 latency is the longest stall here)
+        uint32_t tk_next = lane < ntok ? tok[lane] : 0u;
         for (uint32_t base = 0; base <= ntok; base += 64u) {
             uint32_t i = base + lane;
+            const uint32_t tk = tk_next;
+            tk_next = (i + 64u < ntok) ? tok[i + 64u] : 0u;
             uint64_t bits = 0;
             uint32_t nb = 0;
             if (i < ntok) {
-                uint32_t tk = tok[i];
                 uint32_t len = (tk >> 8) & 0x1FFu;
                 if (len == 0u) {
                     uint32_t c = S->lcode[tk & 0xFFu];
@@ -437,7 +440,7 @@ static __device__ void enc_flush_block(EncShared* S, EncWriter& W, const uint32_
     }
 }
 
-__global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off,
+__global__ void __launch_bounds__(64, 5) zmi_encode_kernel(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off,
                                                         const uint32_t* __restrict__ len, uint32_t first_shard,
                                                         uint32_t* match, uint64_t match_stride,
                                                         const uint32_t* __restrict__ adler, const uint32_t* __restrict__ crc,
@@ -637,13 +640,18 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
     }
 }
 
-// Concatenate the pieces of every shard inside its output slot (piece r lives at r*region_stride
-// and only ever moves towards lower addresses, 1 KiB per step), then publish length and status.
-__global__ void __launch_bounds__(64) zmi_compact_kernel(uint8_t* __restrict__ out, uint64_t out_stride, uint32_t first_shard,
-                                                         uint32_t pieces, uint32_t region_stride,
-                                                         const uint32_t* __restrict__ piece_len,
-                                                         uint32_t* __restrict__ out_len, int32_t* __restrict__ status) {
-    const uint32_t lane = zmi_lane();
+// Concatenate the pieces of every shard inside its output slot (piece r lives at r*region_stride and
+// only ever moves towards lower addresses), then publish length and status.  One 256-thread
+// workgroup per shard; 4 KiB blocks are loaded with aligned 16-byte reads, staged in LDS and
+// written back as aligned dwords (the destination is byte-misaligned in general), so every block
+// is one coalesced load + one coalesced store with all threads busy.
+#define CMP_BLK 4096u
+__global__ void __launch_bounds__(256) zmi_compact_kernel(uint8_t* __restrict__ out, uint64_t out_stride, uint32_t first_shard,
+                                                          uint32_t pieces, uint32_t region_stride,
+                                                          const uint32_t* __restrict__ piece_len,
+                                                          uint32_t* __restrict__ out_len, int32_t* __restrict__ status) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[CMP_BLK + 16];
+    const uint32_t t = threadIdx.x;
     const uint32_t s = first_shard + blockIdx.x;
     uint8_t* slot = out + (uint64_t)s * out_stride;
     const uint32_t* pl = piece_len + (uint64_t)s * pieces;
@@ -652,32 +660,27 @@ __global__ void __launch_bounds__(64) zmi_compact_kernel(uint8_t* __restrict__ o
     for (uint32_t r = 1; r < pieces && !err; ++r) {
         const uint32_t l = pl[r];
         if (l == 0xFFFFFFFFu) { err = true; break; }
-        const uint8_t* srcp = slot + (uint64_t)r * region_stride;
+        const uint8_t* srcp = slot + (uint64_t)r * region_stride;  // 16-byte aligned
         uint8_t* dstp = slot + cur;
-        if ((cur & 3u) == 0u) {
-            // dword path: both ends 4-byte aligned (regions are 16-byte aligned)
-            const uint32_t nw = (l + 3u) >> 2;
-            for (uint32_t base = 0; base < nw; base += 64u) {
-                uint32_t i = base + lane;
-                uint32_t v = 0;
-                if (i < nw) v = ((const uint32_t*)srcp)[i];
-                zmi_wave_sync();
-                if (i < nw) ((uint32_t*)dstp)[i] = v;
-                zmi_wave_sync();
+        for (uint32_t base = 0; base < l; base += CMP_BLK) {
+            const uint32_t nblk = l - base < CMP_BLK ? l - base : CMP_BLK;
+            if (t * 16u < nblk) *(uint4*)(stage + t * 16u) = *(const uint4*)(srcp + base + t * 16u);
+            __syncthreads();
+            uint8_t* A = dstp + base;
+            uint32_t head = (4u - (uint32_t)((uintptr_t)A & 3u)) & 3u;
+            if (head > nblk) head = nblk;
+            const uint32_t ndw = (nblk - head) >> 2;
+            uint32_t* A4 = (uint32_t*)(A + head);
+            for (uint32_t k = t; k < ndw; k += 256u) A4[k] = zmi_load32u(stage, head + 4u * k);
+            if (t == 0) {
+                for (uint32_t j = 0; j < head; ++j) A[j] = stage[j];
+                for (uint32_t j = head + 4u * ndw; j < nblk; ++j) A[j] = stage[j];
             }
-        } else {
-            for (uint32_t base = 0; base < l; base += 64u) {
-                uint32_t i = base + lane;
-                uint8_t v = 0;
-                if (i < l) v = srcp[i];
-                zmi_wave_sync();
-                if (i < l) dstp[i] = v;
-                zmi_wave_sync();
-            }
+            __syncthreads();
         }
         cur += l;
     }
-    if (lane == 0) {
+    if (t == 0) {
         out_len[s] = err ? 0u : cur;
         status[s] = err ? ZMI_BUF_ERROR : ZMI_OK;
     }
@@ -695,7 +698,7 @@ extern "C" int zmi_launch_encode(const uint8_t* d_data, const uint64_t* d_off, c
     uint32_t region = (uint32_t)((out_cap / pieces) & ~15u);
     ZMI_LAUNCH(zmi_encode_kernel, dim3(n_shards * pieces), dim3(64), 0, stream, d_data, d_off, d_len, first_shard, d_match,
                match_stride, d_adler, d_crc, d_out, out_stride, pieces, region, d_piece_len, prm);
-    ZMI_LAUNCH(zmi_compact_kernel, dim3(n_shards), dim3(64), 0, stream, d_out, out_stride, first_shard, pieces, region,
+    ZMI_LAUNCH(zmi_compact_kernel, dim3(n_shards), dim3(256), 0, stream, d_out, out_stride, first_shard, pieces, region,
                d_piece_len, d_out_len, d_status);
     return 0;
 }

@@ -58,21 +58,28 @@ struct InfBits {
     uint32_t nbits;
 };
 
+// 4 input bytes at an arbitrary address: two aligned dword loads + v_alignbyte (the address is
+// wave-uniform, so the loads can be served by the scalar cache)
+static __device__ __forceinline__ uint32_t inf_load32(const uint8_t* p) {
+    const uintptr_t a = (uintptr_t)p;
+    const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
+    const uint32_t sh = (uint32_t)(a & 3u);
+    const uint32_t lo = q[0];
+    const uint32_t hi = sh ? q[1] : 0u;
+    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+}
+// keep at least 33 valid bits in the buffer while input remains
 static __device__ __forceinline__ void inf_refill(InfBits& B) {
-    if (B.ipos + 8u <= B.n) {
-        uint64_t v;
-        const uint8_t* p = B.src + B.ipos;
-        // unaligned 64-bit load from global memory (uniform address)
-        v = (uint64_t)p[0] | ((uint64_t)p[1] << 8) | ((uint64_t)p[2] << 16) | ((uint64_t)p[3] << 24) |
-            ((uint64_t)p[4] << 32) | ((uint64_t)p[5] << 40) | ((uint64_t)p[6] << 48) | ((uint64_t)p[7] << 56);
-        B.hold |= v << B.nbits;
-        uint32_t adv = (63u - B.nbits) >> 3;
-        B.ipos += adv;
-        B.nbits += adv << 3;
-    } else {
-        while (B.nbits <= 56u && B.ipos < B.n) {
-            B.hold |= (uint64_t)B.src[B.ipos++] << B.nbits;
-            B.nbits += 8u;
+    if (B.nbits <= 32u) {
+        if (B.ipos + 4u <= B.n) {
+            B.hold |= (uint64_t)inf_load32(B.src + B.ipos) << B.nbits;
+            B.ipos += 4u;
+            B.nbits += 32u;
+        } else {
+            while (B.nbits <= 56u && B.ipos < B.n) {
+                B.hold |= (uint64_t)B.src[B.ipos++] << B.nbits;
+                B.nbits += 8u;
+            }
         }
     }
 }
@@ -369,6 +376,18 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
         }
 
         // ---- symbol loop ----
+        // Literals are collected (up to 8, in a wave-uniform register) and stored by one masked store;
+        // back-references flush them first because they may read those bytes.
+        uint64_t litbuf = 0;
+        uint32_t nlit = 0;
+#define INF_FLUSH_LITS()                                                                  \
+        do {                                                                              \
+            if (nlit) {                                                                   \
+                if (lane < nlit) dst[opos - nlit + lane] = (uint8_t)(litbuf >> (8u * lane)); \
+                zmi_wave_sync();                                                          \
+                litbuf = 0; nlit = 0;                                                     \
+            }                                                                             \
+        } while (0)
         for (;;) {
             inf_refill(B);
             uint32_t e = inf_lookup(S->ltab, INF_LROOT, B);
@@ -378,9 +397,10 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             inf_drop(B, eb);
             if (op == INF_OP_LIT) {
                 if (opos >= cap) { st = ZMI_NEED_OUTPUT; break; }
-                if (lane == 0) dst[opos] = (uint8_t)(e >> 16);
-                zmi_wave_sync();
+                litbuf |= (uint64_t)(e >> 16) << (8u * nlit);
+                ++nlit;
                 ++opos;
+                if (nlit == 8u) INF_FLUSH_LITS();
                 continue;
             }
             if (op == INF_OP_EOB) break;
@@ -400,6 +420,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             inf_drop(B, xb);
             if (dist > opos) { st = ZMI_DATA_ERROR; break; }  // "invalid distance too far back"
             if (opos + mlen > cap) { st = ZMI_NEED_OUTPUT; break; }
+            INF_FLUSH_LITS();
             if (dist >= mlen || dist >= 64u) {
                 for (uint32_t base = 0; base < mlen; base += 64u) {
                     uint32_t i = base + lane;
@@ -416,6 +437,8 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             }
             opos += mlen;
         }
+        INF_FLUSH_LITS();
+#undef INF_FLUSH_LITS
     }
 
     // ---- trailer ----

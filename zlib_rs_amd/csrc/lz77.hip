@@ -43,7 +43,10 @@
 #define LZ_HSIZE (1u << LZ_HBITS)
 #define LZ_MIRROR 32u
 #define LZ_CTL 128u
-#define LZ_SMEM (LZ_WSIZE + LZ_MIRROR + 2u * LZ_WSIZE + 4u * LZ_HSIZE + LZ_CTL)
+#define LZ_H4BITS 12
+#define LZ_H4SIZE (1u << LZ_H4BITS)
+#define LZ_C4RING 4096u   // positions; >= 4 tiles, the producer never runs further ahead of the oldest search
+#define LZ_SMEM (LZ_WSIZE + LZ_MIRROR + 2u * LZ_WSIZE + 4u * LZ_HSIZE + 4u * LZ_H4SIZE + 2u * LZ_C4RING + LZ_CTL)
 
 struct LzCtl {
     uint32_t ready;  // positions < ready are searchable (chain built, look-ahead bytes loaded)
@@ -92,24 +95,40 @@ static __device__ __forceinline__ void lz_store_chunk(uint8_t* win, uint32_t pos
     if (r < LZ_MIRROR) *(uint4*)(win + LZ_WSIZE + r) = q;  // first 32 bytes are mirrored past the end
 }
 
-// insert the 1024 positions of one tile into head/prev in position order (one wave, 16 steps of 64;
-// the three phases let the LDS reads, the atomics and the prev stores of all steps pipeline)
-static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_t* prev, uint32_t* head, uint32_t tile,
-                                                     uint32_t n, uint32_t max_dist) {
+// insert the 1024 positions of one tile into the hash structures in position order (one wave, 16
+// steps of 64; the three phases let the LDS reads, the atomics and the stores of all steps pipeline).
+// H6 = false: one chain keyed by a 4-byte hash (the reference's structure, hash_calc.rs:30-59).
+// H6 = true : the chain is keyed by a 6-byte hash -- far sparser, every link is a >= 6-byte match --
+//             and a second, chain-less table remembers the most recent position of every 4-byte
+//             hash; its answer for position p is parked in a small ring (c4) until p is searched.
+template <bool H6>
+static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_t* prev, uint32_t* head, uint32_t* head4,
+                                                     uint16_t* c4, uint32_t tile, uint32_t n, uint32_t max_dist) {
     const uint32_t lane = zmi_lane();
-    uint32_t hv[LZ_SUB];
+    uint32_t hv[LZ_SUB], h4[LZ_SUB];
 #pragma unroll
     for (uint32_t s = 0; s < LZ_SUB; ++s) {
         uint32_t p = tile * LZ_T + s * 64u + lane;
-        uint32_t v = lz_ring32(win, p);
-        hv[s] = (v * 2654435761u) >> (32 - LZ_HBITS);  // multiplier as hash_calc.rs:30-33
+        if (H6) {
+            uint32_t lo, hi;
+            lz_ring64(win, p, lo, hi);
+            uint64_t x = ((uint64_t)(hi & 0xFFFFu) << 32) | lo;
+            hv[s] = (uint32_t)((x * 0x9E3779B185EBCA87ull) >> (64 - LZ_HBITS));
+            h4[s] = (lo * 2654435761u) >> (32 - LZ_H4BITS);
+        } else {
+            uint32_t v = lz_ring32(win, p);
+            hv[s] = (v * 2654435761u) >> (32 - LZ_HBITS);  // multiplier as hash_calc.rs:30-33
+            h4[s] = 0;
+        }
     }
 #pragma unroll
     for (uint32_t s = 0; s < LZ_SUB; ++s) {
         uint32_t p = tile * LZ_T + s * 64u + lane;
-        uint32_t old = 0;
-        if (p + 4u <= n) old = atomicMax(&head[hv[s]], p + 1u);
+        uint32_t old = 0, old4 = 0;
+        if (p + (H6 ? 6u : 4u) <= n) old = atomicMax(&head[hv[s]], p + 1u);
+        if (H6 && p + 4u <= n) old4 = atomicMax(&head4[h4[s]], p + 1u);
         hv[s] = old;
+        h4[s] = old4;
         zmi_wave_sync();  // steps are position-ordered (no-op on hardware: one wave, in-order LDS)
     }
 #pragma unroll
@@ -121,10 +140,19 @@ static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_
             if (d <= max_dist) delta = d;
         }
         prev[p & LZ_WMASK] = (uint16_t)delta;
+        if (H6) {
+            uint32_t o4 = h4[s], d4 = 0;
+            if (o4 != 0u && o4 <= p) {
+                uint32_t d = p + 1u - o4;
+                if (d <= max_dist) d4 = d;
+            }
+            c4[p & (LZ_C4RING - 1u)] = (uint16_t)d4;
+        }
     }
 }
 
-__global__ void __launch_bounds__(1024) zmi_lz77_kernel(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off,
+template <bool H6>
+__global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off,
                                                         const uint32_t* __restrict__ len, uint32_t first_shard,
                                                         uint32_t* __restrict__ match, uint64_t match_stride,
                                                         zmi_lz_params prm) {
@@ -132,7 +160,9 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel(const uint8_t* __restric
     uint8_t* win = smem;
     uint16_t* prev = (uint16_t*)(smem + LZ_WSIZE + LZ_MIRROR);
     uint32_t* head = (uint32_t*)(smem + LZ_WSIZE + LZ_MIRROR + 2u * LZ_WSIZE);
-    LzCtl* ctl = (LzCtl*)(head + LZ_HSIZE);
+    uint32_t* head4 = head + LZ_HSIZE;
+    uint16_t* c4 = (uint16_t*)(head4 + LZ_H4SIZE);
+    LzCtl* ctl = (LzCtl*)(c4 + LZ_C4RING);
 
     const uint32_t t = threadIdx.x;
     const uint32_t lane = zmi_lane();
@@ -146,17 +176,30 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel(const uint8_t* __restric
     if (ntiles == 0) return;
 
     for (uint32_t i = t; i < LZ_HSIZE; i += 1024u) head[i] = 0u;
+    for (uint32_t i = t; i < LZ_H4SIZE; i += 1024u) head4[i] = 0u;
     if (t == 0) { ctl->ready = 0u; ctl->next = 0u; }
     if (t < LZ_NW) ctl->wmin[t] = 0xFFFFFFFFu;
     __syncthreads();
 
     if (wave == 0) {
         // ---------------- producer ----------------
+        // The HBM load of the chunk needed NEXT round is issued at the top of the round and consumed
+        // at the top of the following one, so its latency hides behind the throttle wait and the
+        // hash inserts of the current tile.
+        for (uint32_t c = lane * 16u; c < LZ_T + 16u; c += 1024u) {
+            zmi_b16 v0 = zmi_ld16(src + c, c < n ? n - c : 0u, aligned);
+            lz_store_chunk(win, c, v0);
+        }
+        uint32_t cpos = LZ_T + 16u + lane * 16u;   // chunk that round 0 must make resident
+        zmi_b16 cur = zmi_ld16(src + cpos, cpos < n ? n - cpos : 0u, aligned);
+        uint32_t cached_min = 0u;
         for (uint32_t k = 0; k < ntiles; ++k) {
+            const uint32_t npos = cpos + LZ_T;
+            zmi_b16 nxt = zmi_ld16(src + npos, npos < n ? n - npos : 0u, aligned);  // for round k+1
             const uint32_t E = (k + 2u) * LZ_T + 16u;  // bytes [0, E) must be resident after this round
             // ring throttle: byte E-1 lands on the slot of byte E-1-32768, which the oldest in-flight
             // search (position q) may still read while q - max_dist <= E-1-32768
-            for (;;) {
+            while ((uint64_t)E + prm.max_dist > (uint64_t)cached_min + LZ_WSIZE) {
                 uint32_t v = 0xFFFFFFFFu;
                 if (lane < LZ_NW) v = lz_ld_acq(&ctl->wmin[lane]);
                 else if (lane == LZ_NW) v = lz_ld_acq(&ctl->next);
@@ -166,26 +209,19 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel(const uint8_t* __restric
                     uint32_t o = __shfl_xor(m, d);
                     m = o < m ? o : m;
                 }
+                cached_min = m;
                 if ((uint64_t)E + prm.max_dist <= (uint64_t)m + LZ_WSIZE) break;
                 lz_pause();
             }
-            if (k == 0) {
-                for (uint32_t c = lane * 16u; c < LZ_T + 16u; c += 1024u) {
-                    zmi_b16 v = zmi_ld16(src + c, c < n ? n - c : 0u, aligned);
-                    lz_store_chunk(win, c, v);
-                }
-            }
-            {
-                uint32_t c = (k + 1u) * LZ_T + 16u + lane * 16u;
-                zmi_b16 v = zmi_ld16(src + c, c < n ? n - c : 0u, aligned);
-                lz_store_chunk(win, c, v);
-            }
+            lz_store_chunk(win, cpos, cur);
             zmi_wave_sync();
-            lz_build_tile(win, prev, head, k, n, prm.max_dist);
+            lz_build_tile<H6>(win, prev, head, head4, c4, k, n, prm.max_dist);
             zmi_wave_sync();
             uint32_t r = (k + 1u) * LZ_T;
             if (r > n) r = n;
             if (lane == 0) lz_st_rel(&ctl->ready, r);
+            cur = nxt;
+            cpos = npos;
         }
         return;
     }
@@ -196,14 +232,17 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel(const uint8_t* __restric
     // candidate, its first 8 window bytes and, once the best match is >= 8, the 4 bytes ending at
     // the best length), so a chain step costs one LDS latency, not two.
     for (;;) {
-        uint32_t base = 0;
+        // claim prm.claim positions (64 per round, one position per lane); one LDS atomic per claim
+        uint32_t base0 = 0;
         if (lane == 0) {
             uint32_t tnext = lz_ld_acq(&ctl->next);
-            lz_st_rel(&ctl->wmin[wave], tnext);  // lower bound published BEFORE the claim
-            base = atomicAdd(&ctl->next, 64u);
-            lz_st_rel(&ctl->wmin[wave], base);
+            lz_st_rel(&ctl->wmin[wave], tnext);  // lower bound of everything this wave still needs, BEFORE the claim
+            base0 = atomicAdd(&ctl->next, prm.claim);
         }
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        base0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)base0);
+        if (base0 >= n) break;
+      for (uint32_t half = 0; half * 64u < prm.claim; ++half) {
+        const uint32_t base = base0 + half * 64u;
         if (base >= n) break;
         const uint32_t need = base + 64u < n ? base + 64u : n;
         while (lz_ld_acq(&ctl->ready) < need) lz_pause();
@@ -218,6 +257,14 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel(const uint8_t* __restric
             uint32_t maxlen = n - p;
             if (maxlen > 258u) maxlen = 258u;
             uint32_t delta = prev[p & LZ_WMASK];
+            // H6: the first candidate is the most recent 4-byte match (no chain of its own); the walk
+            // then continues along the 6-byte chain starting at this position's own link
+            uint32_t first_dn = 0;
+            bool probe = false;
+            if (H6) {
+                const uint32_t d4 = c4[p & (LZ_C4RING - 1u)];
+                if (d4 != 0u && d4 != delta) { first_dn = delta; delta = d4; probe = true; }
+            }
             if (maxlen >= 4u && delta != 0u) {
                 uint32_t cand = p - delta;
                 uint32_t blen = 3u, bdist = 0u, tail = 0u;
@@ -230,7 +277,9 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel(const uint8_t* __restric
                 for (;;) {
                     const uint32_t r = cand & LZ_WMASK;
                     const uint32_t* w = (const uint32_t*)(win + (r & ~3u));
-                    const uint32_t dn = prev[r];
+                    uint32_t dn = prev[r];
+                    const bool is_probe = H6 && probe;
+                    if (is_probe) { dn = first_dn; probe = false; }
                     const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
                     uint32_t tl = 0;
                     if (blen >= 16u) tl = lz_ring32(win, cand + blen - 3u);
@@ -265,7 +314,7 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel(const uint8_t* __restric
                     if (better && l >= 16u) tail = lz_ring32(win, p + l - 3u);
                     if (better && l >= prm.good_len) chain >>= 1;  // a good match halves the remaining budget
                     const bool stop = better && (l >= prm.nice_len || l >= maxlen);
-                    cand -= dn;
+                    cand = is_probe ? p - dn : cand - dn;  // after the 4-byte probe the walk starts at p's own 6-byte link
                     chain = chain ? chain - 1u : 0u;
                     if (stop || dn == 0u || chain == 0u || p - cand > prm.max_dist) break;
                 }
@@ -273,6 +322,7 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel(const uint8_t* __restric
             }
             mout[p] = res;
         }
+      }
     }
     if (lane == 0) lz_st_rel(&ctl->wmin[wave], 0xFFFFFFFFu);
 }
@@ -281,17 +331,26 @@ extern "C" int zmi_launch_lz77(const uint8_t* d_data, const uint64_t* d_off, con
                                uint32_t n_shards, uint32_t* d_match, uint64_t match_stride, zmi_lz_params prm,
                                hipStream_t stream) {
     if (n_shards == 0) return 0;
-    if (prm.max_dist > LZ_WSIZE - 3u * LZ_T - 16u) prm.max_dist = LZ_WSIZE - 3u * LZ_T - 16u;
+    // ring budget: 32 KiB = max_dist + 2 tiles of producer run-ahead + 2 tiles of slack for the searches in flight
+    if (prm.max_dist > LZ_WSIZE - 4u * LZ_T - 16u) prm.max_dist = LZ_WSIZE - 4u * LZ_T - 16u;
+    if (prm.claim != 128u && prm.claim != 192u && prm.claim != 256u) prm.claim = 64u;
 #ifndef ZMI_EMU
-    // 131 KiB of dynamic LDS: above the 64 KiB default, must be requested explicitly
+    // 152 KiB of dynamic LDS: above the 64 KiB default, must be requested explicitly
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)zmi_lz77_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LZ_SMEM);
+        hipError_t e = hipFuncSetAttribute((const void*)zmi_lz77_kernel_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LZ_SMEM);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)zmi_lz77_kernel_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LZ_SMEM);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
 #endif
-    ZMI_LAUNCH(zmi_lz77_kernel, dim3(n_shards), dim3(1024), LZ_SMEM, stream, d_data, d_off, d_len, first_shard, d_match,
-               match_stride, prm);
+    if (prm.hash6) {
+        ZMI_LAUNCH(zmi_lz77_kernel_t<true>, dim3(n_shards), dim3(1024), LZ_SMEM, stream, d_data, d_off, d_len, first_shard,
+                   d_match, match_stride, prm);
+    } else {
+        ZMI_LAUNCH(zmi_lz77_kernel_t<false>, dim3(n_shards), dim3(1024), LZ_SMEM, stream, d_data, d_off, d_len, first_shard,
+                   d_match, match_stride, prm);
+    }
     return 0;
 }

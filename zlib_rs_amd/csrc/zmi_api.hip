@@ -157,15 +157,15 @@ struct zmi_level_cfg {
 };
 static const zmi_level_cfg kLevels[10] = {
     {0, 0, 0, 0},         // 0: stored
-    {4, 16, 8, 0},        // 1
-    {6, 32, 8, 0},        // 2
-    {8, 32, 8, 4},        // 3
-    {12, 64, 16, 8},      // 4
-    {16, 64, 16, 16},     // 5
-    {24, 128, 32, 16},    // 6
-    {48, 128, 32, 32},    // 7
-    {128, 258, 64, 128},  // 8
-    {256, 258, 128, 258}, // 9
+    {2, 16, 8, 0},        // 1
+    {3, 32, 8, 0},        // 2
+    {4, 32, 8, 4},        // 3
+    {5, 64, 16, 8},       // 4
+    {6, 64, 16, 16},      // 5
+    {8, 128, 32, 16},     // 6
+    {16, 128, 32, 32},    // 7
+    {48, 258, 64, 128},   // 8
+    {128, 258, 128, 258}, // 9
 };
 
 extern "C" int zmi_checksum_batch_dev(zmi_ctx* c, const void* d_data, const uint64_t* d_off, const uint32_t* d_len,
@@ -242,6 +242,14 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     lp.nice_len = L.nice;
     lp.good_len = L.good;
     lp.max_dist = 32768u;  // clamped to the ring-buffer limit by the launcher
+    lp.hash6 = 1u;  // 6-byte-hash chain + one 4-byte probe: ~1.5x fewer chain steps than a 4-byte chain at equal ratio
+    lp.claim = 64u;
+    const char* claim_env = getenv("ZMI_CLAIM");
+    if (claim_env) lp.claim = (uint32_t)atoi(claim_env);
+    const char* md_env = getenv("ZMI_MAXDIST");
+    if (md_env && atoi(md_env) > 0) lp.max_dist = (uint32_t)atoi(md_env);
+    const char* h6_env = getenv("ZMI_HASH6");
+    if (h6_env) lp.hash6 = atoi(h6_env) ? 1u : 0u;
     zmi_enc_params ep;
     ep.max_lazy = L.lazy;
     ep.wrap = (uint32_t)wrap;

@@ -39,15 +39,28 @@ static __device__ __forceinline__ unsigned zmi_mbcnt(uint64_t mask) {
 }
 
 // wave-wide inclusive prefix sum (all 64 lanes must call)
+#ifdef ZMI_EMU
 static __device__ __forceinline__ unsigned zmi_wave_incl_scan(unsigned v) {
     unsigned lane = zmi_lane();
-#pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         unsigned t = __shfl_up(v, d);
         if (lane >= (unsigned)d) v += t;
     }
     return v;
 }
+#else
+// DPP version: row_shr 1/2/4/8 inside each row of 16 lanes, then row_bcast:15 (rows 1,3) and
+// row_bcast:31 (rows 2,3).  Six VALU instructions, no LDS crossbar (ds_bpermute) round trips.
+static __device__ __forceinline__ unsigned zmi_wave_incl_scan(unsigned v) {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+#endif
 static __device__ __forceinline__ unsigned zmi_wave_sum(unsigned v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
