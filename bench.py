@@ -23,6 +23,28 @@ GIB = float(1 << 30)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def usable_cores():
+    """host cores this process may actually use: affinity mask capped by the cgroup CPU quota"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+        except Exception:  # noqa: BLE001
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(shard_bytes, level, budget_s=15.0):
     """oracle level-`level` deflate (C restatement of the reference) of the same synthetic shards on all
     host cores: POSIX threads inside the oracle library (zo_bench_deflate), bounded sample."""
@@ -33,7 +55,7 @@ def cpu_baseline(shard_bytes, level, budget_s=15.0):
         return None
     o.lib.zo_bench_deflate.restype = C.c_double
     o.lib.zo_bench_deflate.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     tot = C.c_uint64(0)
     # single thread: 8 shards (one of each class)
     t1 = o.lib.zo_bench_deflate(0x5A4C4942, 0, 8, shard_bytes, level, 1, C.byref(tot))
@@ -147,6 +169,14 @@ def main():
         shards_per_launch = S / launches_per_step
         algo_bytes = shards_per_launch * B * (1.0 + 1.0 / ratio)
         achieved = algo_bytes / (lz_ms * 1e-3) / 1e9 if lz_ms > 0 else 0.0
+        # measured HBM traffic of the dominant kernel (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes,
+        # tools/prof_final.sh) -- recorded per 2048-shard launch in profiles/, scaled to this run's launch size
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))["zmi_lz77_kernel"]
+            traffic = (tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]) * shards_per_launch / tj["shards_per_launch"]
+        except Exception:  # noqa: BLE001
+            pass
         line = {
             "metric": "GiB/s raw input compressed (level %d, 1 MiB shards)" % args.level,
             "value": value, "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -157,7 +187,7 @@ def main():
                        "parallelism": "shard-parallel x%d (no data-path collective)" % world},
             "ratio": ratio,
             "roofline": {"bound": "hbm", "kernel": "zmi_lz77_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "read_only_frac": value * GIB / 1e9 / HBM_PEAK_GBS,
                          "kernel_ms": {"checksum": sums[0] / max(1, cnts[0]), "lz77": lz_ms, "encode": sums[2] / max(1, cnts[2])},
                          "launches_per_step": int(launches_per_step)},
