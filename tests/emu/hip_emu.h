@@ -99,6 +99,7 @@ using emu::gridDim;
 #define __device__
 #define __host__
 #define __forceinline__ inline
+#define __noinline__ __attribute__((noinline))
 #define __shared__ static
 #define __launch_bounds__(...)
 #define __restrict__ __restrict
@@ -206,6 +207,10 @@ inline unsigned __builtin_amdgcn_mbcnt_hi(unsigned mask, unsigned add) {
 inline unsigned __builtin_amdgcn_alignbyte(unsigned hi, unsigned lo, unsigned sh) {
     uint64_t v = ((uint64_t)hi << 32) | lo;
     return (unsigned)(v >> ((sh & 3) * 8));
+}
+inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh) {
+    uint64_t v = ((uint64_t)hi << 32) | lo;
+    return (unsigned)(v >> (sh & 31));
 }
 inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }

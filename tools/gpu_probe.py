@@ -44,7 +44,7 @@ def main():
     for S in [int(x) for x in os.environ.get("PROBE_S", "256,2048").split(",")]:
         data = e.gen_shards(S, B)
         off, ln = uniform_layout(S, B, e.device)
-        for lvl in (1, 3, 6, 9):
+        for lvl in [int(x) for x in os.environ.get("PROBE_LEVELS", "1,3,6,9").split(",")]:
             out, olen, st = e.deflate_batch(data, off, ln, B, level=lvl)
             torch.cuda.synchronize()
             timing(e)
@@ -83,6 +83,16 @@ def main():
                 sums, cnts = timing(e)
                 print("inflate S=%d: %.2f GiB/s wall  ok=%s  ms: inflate %.2f checksum %.2f" %
                       (S, S * B / 2**30 / dt, bool(torch.equal(back, data)) and int((bst != 0).sum()) == 0, sums[3], sums[0]))
+                if os.environ.get("PROBE_CLASSES"):
+                    for cls in range(8):
+                        idx = torch.arange(cls, S, 8, device=e.device)
+                        a = (coff[idx].contiguous(), olen[idx].contiguous(), back, ooff[idx].contiguous(), cap[idx].contiguous())
+                        e.inflate_batch(out, *a)
+                        torch.cuda.synchronize(); timing(e)
+                        e.inflate_batch(out, *a)
+                        torch.cuda.synchronize()
+                        sm, _ = timing(e)
+                        print("    class %d: inflate %.2f ms for %d streams" % (cls, sm[3], idx.numel()))
         del data
     e.close()
 

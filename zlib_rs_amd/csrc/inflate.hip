@@ -15,9 +15,12 @@
 // MI355X design: the symbol decode of one stream is serial, so the batch supplies the parallelism --
 // one 64-lane wave per stream, its two lookup tables (7.6 KiB) in LDS, ~19 streams resident per CU.
 // The bit buffer and all decode state are wave-uniform; the 64 lanes co-operate on table
-// construction (replicated entries written lane-parallel), on literal stores and on back-reference
-// copies (64 bytes per step, overlap-safe).  Output bytes are produced in place in HBM; a
-// back-reference reads what the same wave stored earlier (same-CU L1, in-order memory pipeline).
+// construction (replicated entries written lane-parallel) and on back-reference copies.
+// Neither side of the symbol loop touches HBM in its dependent chain: compressed input is staged
+// through a 1 KiB LDS chunk (one coalesced load per KiB), and output goes into an LDS ring holding the
+// most recent INF_RING bytes, from which completed 256-byte lines are streamed out with coalesced
+// fire-and-forget stores.  Back-references within the ring are LDS->LDS copies; only the far ones
+// (distance > INF_RING - length) read back what the wave stored to HBM earlier.
 // Algorithmic HBM traffic: (1/ratio) B read + 1 B written per output byte.
 #include "zmi_device.h"
 #include "zmi_kernels.h"
@@ -26,6 +29,13 @@
 #define ZMI_TRAILER_SHORT (-1005)     // gzip: CRC present, ISIZE cut off   -> data error if CRC wrong, else buf error
 #define ZMI_LENGTH_MISMATCH (-1003)   // gzip: ISIZE wrong                  -> data error either way
 #define ZMI_NEED_OUTPUT (-1006)       // output capacity exhausted          -> Z_BUF_ERROR (detail 2)
+#define INF_CHUNK 1024u
+#ifndef INF_RING
+#define INF_RING 8192u               // output history kept in LDS (power of two, >= 1024)
+#endif
+#define INF_RMASK (INF_RING - 1u)
+#define INF_OUTMAX 768u              // output bytes one decode round may produce (>= 258)
+#define INF_NEAR (INF_RING - INF_OUTMAX)  // back-references up to this distance are served from the ring
 #define INF_LROOT 10u
 #define INF_DROOT 9u
 #define INF_LSIZE 1344u
@@ -48,7 +58,25 @@ struct InfShared {
     uint32_t cnt[16];
     uint32_t offs[16];
     uint32_t misc[8];
+    __attribute__((aligned(16))) uint8_t inbuf[INF_CHUNK + 32];  // staged compressed input (one coalesced load per KiB)
+    __attribute__((aligned(16))) uint8_t ring[INF_RING];         // output bytes [opos - INF_RING, opos), index = offset & INF_RMASK
 };
+
+// stream completed 256-byte lines [from, upto) of the ring to HBM (from, upto multiples of 256)
+static __device__ __forceinline__ void inf_flush_lines(const uint8_t* ring, uint8_t* dst, uint32_t from, uint32_t upto,
+                                                       bool aligned4) {
+    const uint32_t lane = zmi_lane();
+    for (uint32_t c = from; c < upto; c += 256u) {
+        uint32_t o = c + 4u * lane;
+        uint32_t w = *(const uint32_t*)(ring + (o & INF_RMASK));
+        if (aligned4) *(uint32_t*)(dst + o) = w;
+        else {
+            dst[o] = (uint8_t)w; dst[o + 1u] = (uint8_t)(w >> 8);
+            dst[o + 2u] = (uint8_t)(w >> 16); dst[o + 3u] = (uint8_t)(w >> 24);
+        }
+    }
+}
+
 
 struct InfBits {
     const uint8_t* src;
@@ -56,28 +84,51 @@ struct InfBits {
     uint32_t ipos;   // next unread input byte
     uint64_t hold;
     uint32_t nbits;
+    uint8_t* inbuf;  // LDS chunk holding input bytes [cbase, cbase + INF_CHUNK)
+    int32_t cbase;   // may be negative for the first chunk of a misaligned stream
 };
 
-// 4 input bytes at an arbitrary address: two aligned dword loads + v_alignbyte (the address is
-// wave-uniform, so the loads can be served by the scalar cache)
-static __device__ __forceinline__ uint32_t inf_load32(const uint8_t* p) {
-    const uintptr_t a = (uintptr_t)p;
-    const uint32_t* q = (const uint32_t*)(a & ~(uintptr_t)3);
-    const uint32_t sh = (uint32_t)(a & 3u);
-    const uint32_t lo = q[0];
-    const uint32_t hi = sh ? q[1] : 0u;
-    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+// (re)load the LDS input chunk so that it starts at the 16-byte aligned address at or below ipos;
+// returns the stream offset of inbuf[0] (negative for the first chunk of a misaligned stream)
+static __device__ __noinline__ int32_t inf_load_chunk(const uint8_t* src, uint32_t n, uint32_t ipos, uint8_t* inbuf) {
+    const uint32_t lane = zmi_lane();
+    const uint32_t mis = (uint32_t)((uintptr_t)(src + ipos) & 15u);
+    const int32_t cbase = (int32_t)ipos - (int32_t)mis;
+    zmi_wave_order();
+    const int32_t so = cbase + (int32_t)(16u * lane);  // stream offset of this lane's 16 bytes
+    uint4 q;
+    q.x = q.y = q.z = q.w = 0u;
+    if (so >= 0 && (uint32_t)so + 16u <= n) {
+        q = *(const uint4*)(src + so);  // 16-byte aligned by construction
+    } else if (so + 16 > 0 && so < (int32_t)n) {
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        for (int j = 0; j < 16; ++j) {
+            int32_t o = so + j;
+            if (o >= 0 && (uint32_t)o < n) w[j >> 2] |= (uint32_t)src[o] << (8 * (j & 3));
+        }
+        q.x = w[0]; q.y = w[1]; q.z = w[2]; q.w = w[3];
+    }
+    *(uint4*)(inbuf + 16u * lane) = q;
+    if (lane < 2u) *(uint4*)(inbuf + INF_CHUNK + 16u * lane) = uint4{0u, 0u, 0u, 0u};
+    zmi_wave_order();
+    return cbase;
 }
-// keep at least 33 valid bits in the buffer while input remains
+static __device__ __forceinline__ uint32_t inf_byte(const InfBits& B, uint32_t i) { return zmi_uniform(B.src[i]); }
+// keep at least 33 valid bits in the buffer while input remains; reads come from the LDS chunk
 static __device__ __forceinline__ void inf_refill(InfBits& B) {
     if (B.nbits <= 32u) {
         if (B.ipos + 4u <= B.n) {
-            B.hold |= (uint64_t)inf_load32(B.src + B.ipos) << B.nbits;
+            uint32_t off = (uint32_t)((int32_t)B.ipos - B.cbase);
+            if (off + 4u > INF_CHUNK) {
+                B.cbase = (int32_t)zmi_uniform((uint32_t)inf_load_chunk(B.src, B.n, B.ipos, B.inbuf));
+                off = (uint32_t)((int32_t)B.ipos - B.cbase);
+            }
+            B.hold |= (uint64_t)zmi_uniform(zmi_load32u(B.inbuf, off)) << B.nbits;
             B.ipos += 4u;
             B.nbits += 32u;
         } else {
             while (B.nbits <= 56u && B.ipos < B.n) {
-                B.hold |= (uint64_t)B.src[B.ipos++] << B.nbits;
+                B.hold |= (uint64_t)inf_byte(B, B.ipos++) << B.nbits;
                 B.nbits += 8u;
             }
         }
@@ -104,7 +155,7 @@ static const __device__ uint8_t inf_dext[32] = {0, 0, 0,  0,  1,  1,  2,  2,  3,
 // kind: 0 = code-length code (symbols are values), 1 = literal/length, 2 = distance
 // Builds a two-level lookup table from S->lens[0..nsym).  Returns 0 ok, 1 over-subscribed /
 // incomplete, 2 table overflow.  All lanes call; `used` receives the entry count.
-static __device__ uint32_t inf_build(InfShared* S, uint32_t kind, uint32_t nsym, uint32_t* tab, uint32_t root,
+static __device__ __noinline__ uint32_t inf_build(InfShared* S, uint32_t kind, uint32_t nsym, uint32_t* tab, uint32_t root,
                                      uint32_t cap) {
     const uint32_t lane = zmi_lane();
     // lane 0: histogram, validity, counting sort of the symbols by (length, index)
@@ -135,9 +186,9 @@ static __device__ uint32_t inf_build(InfShared* S, uint32_t kind, uint32_t nsym,
         S->misc[2] = o;  // number of coded symbols
     }
     zmi_wave_sync();
-    if (S->misc[0]) return 1u;
-    const uint32_t maxl = S->misc[1];
-    const uint32_t ncoded = S->misc[2];
+    if (zmi_uniform(S->misc[0])) return 1u;
+    const uint32_t maxl = zmi_uniform(S->misc[1]);
+    const uint32_t ncoded = zmi_uniform(S->misc[2]);
     const uint32_t rsize = 1u << root;
     for (uint32_t i = lane; i < rsize; i += 64u) tab[i] = INF_ENTRY(0, INF_OP_BAD, 0);
     zmi_wave_sync();
@@ -148,8 +199,8 @@ static __device__ uint32_t inf_build(InfShared* S, uint32_t kind, uint32_t nsym,
     uint32_t used = rsize;   // next free sub-table slot
     uint32_t sub_prefix = 0xFFFFFFFFu, sub_off = 0, sub_bits = 0;
     for (uint32_t k = 0; k < ncoded; ++k) {
-        const uint32_t sym = S->sorted[k];
-        const uint32_t l = S->lens[sym];
+        const uint32_t sym = zmi_uniform(S->sorted[k]);
+        const uint32_t l = zmi_uniform(S->lens[sym]);
         code <<= (l - curlen);
         curlen = l;
         // entry payload
@@ -178,7 +229,7 @@ static __device__ uint32_t inf_build(InfShared* S, uint32_t kind, uint32_t nsym,
                 {
                     uint32_t c = code, cl = l;
                     for (uint32_t k2 = k + 1u; k2 < ncoded; ++k2) {
-                        uint32_t l2 = S->lens[S->sorted[k2]];
+                        uint32_t l2 = zmi_uniform(S->lens[zmi_uniform(S->sorted[k2])]);
                         c = (c + 1u) << (l2 - cl);
                         cl = l2;
                         if ((c >> (cl - root)) != (code >> (l - root))) break;
@@ -206,11 +257,11 @@ static __device__ uint32_t inf_build(InfShared* S, uint32_t kind, uint32_t nsym,
 }
 
 static __device__ __forceinline__ uint32_t inf_lookup(const uint32_t* tab, uint32_t root, const InfBits& B) {
-    uint32_t e = tab[inf_peek(B, root)];
+    uint32_t e = zmi_uniform(tab[inf_peek(B, root)]);
     uint32_t op = (e >> 8) & 0xFFu;
     if (op & INF_OP_LINK) {
         uint32_t sb = op & 0x0Fu;
-        e = tab[(e >> 16) + ((uint32_t)(B.hold >> root) & ((1u << sb) - 1u))];
+        e = zmi_uniform(tab[(e >> 16) + ((uint32_t)(B.hold >> root) & ((1u << sb) - 1u))]);
     }
     return e;
 }
@@ -232,39 +283,43 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
     B.ipos = 0;
     B.hold = 0;
     B.nbits = 0;
+    B.inbuf = S->inbuf;
+    B.cbase = -(int32_t)(2u * INF_CHUNK);  // nothing staged yet: the first refill loads a chunk
     uint8_t* dst = out + out_off[s];
     const uint32_t cap = out_cap[s];
     uint32_t opos = 0;
+    uint32_t flushed = 0;  // multiple of 256: ring bytes below it are already in HBM
+    const bool aligned4 = ((uintptr_t)dst & 3u) == 0u;
     int32_t st = ZMI_OK;
     uint32_t kind_found = wrap;  // resolved wrapper: 0 raw, 1 zlib, 2 gzip
     uint32_t fixed_ready = 0;
 
     // ---- wrapper header ----
-    if (wrap == 3u) kind_found = (B.n >= 2u && B.src[0] == 0x1Fu && B.src[1] == 0x8Bu) ? 2u : 1u;
+    if (wrap == 3u) kind_found = (B.n >= 2u && inf_byte(B, 0) == 0x1Fu && inf_byte(B, 1) == 0x8Bu) ? 2u : 1u;
     if (kind_found == 1u) {
         if (B.n < 2u) st = ZMI_BUF_ERROR;
         else {
-            uint32_t cmf = B.src[0], flg = B.src[1];
+            uint32_t cmf = inf_byte(B, 0), flg = inf_byte(B, 1);
             if ((cmf & 0x0Fu) != 8u || (cmf >> 4) > 7u || ((cmf << 8) | flg) % 31u != 0u) st = ZMI_DATA_ERROR;
             else if (flg & 0x20u) st = 2;  // Z_NEED_DICT: preset dictionaries are not supported in batch mode
             B.ipos = 2;
         }
     } else if (kind_found == 2u) {
         if (B.n < 10u) st = ZMI_BUF_ERROR;
-        else if (B.src[0] != 0x1Fu || B.src[1] != 0x8Bu || B.src[2] != 8u || (B.src[3] & 0xE0u)) st = ZMI_DATA_ERROR;
+        else if (inf_byte(B, 0) != 0x1Fu || inf_byte(B, 1) != 0x8Bu || inf_byte(B, 2) != 8u || (inf_byte(B, 3) & 0xE0u)) st = ZMI_DATA_ERROR;
         else {
-            uint32_t flg = B.src[3];
+            uint32_t flg = inf_byte(B, 3);
             uint32_t p = 10;
             if (flg & 4u) {  // FEXTRA
                 if (p + 2u > B.n) st = ZMI_BUF_ERROR;
-                else { uint32_t xl = B.src[p] | ((uint32_t)B.src[p + 1u] << 8); p += 2u + xl; }
+                else { uint32_t xl = inf_byte(B, p) | ((uint32_t)inf_byte(B, p + 1u) << 8); p += 2u + xl; }
             }
             if (st == ZMI_OK && (flg & 8u)) {  // FNAME
-                while (p < B.n && B.src[p] != 0) ++p;
+                while (p < B.n && inf_byte(B, p) != 0) ++p;
                 ++p;
             }
             if (st == ZMI_OK && (flg & 16u)) {  // FCOMMENT
-                while (p < B.n && B.src[p] != 0) ++p;
+                while (p < B.n && inf_byte(B, p) != 0) ++p;
                 ++p;
             }
             if (st == ZMI_OK && (flg & 2u)) p += 2u;  // FHCRC (not verified)
@@ -288,15 +343,34 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             B.hold = 0;
             B.nbits = 0;
             if (B.ipos + 4u > B.n) { st = ZMI_BUF_ERROR; break; }
-            uint32_t l = B.src[B.ipos] | ((uint32_t)B.src[B.ipos + 1u] << 8);
-            uint32_t nl = B.src[B.ipos + 2u] | ((uint32_t)B.src[B.ipos + 3u] << 8);
+            uint32_t l = inf_byte(B, B.ipos) | ((uint32_t)inf_byte(B, B.ipos + 1u) << 8);
+            uint32_t nl = inf_byte(B, B.ipos + 2u) | ((uint32_t)inf_byte(B, B.ipos + 3u) << 8);
             B.ipos += 4u;
             if ((l ^ 0xFFFFu) != nl) { st = ZMI_DATA_ERROR; break; }   // "invalid stored block lengths"
             if (B.ipos + l > B.n) { st = ZMI_BUF_ERROR; break; }
             if (opos + l > cap) { st = ZMI_NEED_OUTPUT; break; }
-            for (uint32_t i = lane; i < l; i += 64u) dst[opos + i] = B.src[B.ipos + i];
-            zmi_wave_sync();
-            opos += l;
+            // through the ring like everything else (later back-references may point into stored bytes)
+            for (uint32_t base = 0; base < l; base += 256u) {
+                uint32_t nb = l - base < 256u ? l - base : 256u;
+                uint8_t v[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) {
+                    uint32_t i = lane + 64u * j;
+                    v[j] = i < nb ? B.src[B.ipos + base + i] : (uint8_t)0;
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 4u; ++j) {
+                    uint32_t i = lane + 64u * j;
+                    if (i < nb) S->ring[(opos + i) & INF_RMASK] = v[j];
+                }
+                zmi_wave_order();
+                opos += nb;
+                if ((opos & ~255u) != flushed) {
+                    inf_flush_lines(S->ring, dst, flushed, opos & ~255u, aligned4);
+                    flushed = opos & ~255u;
+                    zmi_wave_order();
+                }
+            }
             B.ipos += l;
             continue;
         }
@@ -331,12 +405,12 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             if (st != ZMI_OK) break;
             zmi_wave_sync();
             // code-length code table lives at the start of dtab (128 entries, root 7)
-            if (inf_build(S, 0u, 19u, S->dtab, 7u, INF_DSIZE)) { st = ZMI_DATA_ERROR; break; }  // "invalid code lengths set"
+            if (zmi_uniform(inf_build(S, 0u, 19u, S->dtab, 7u, INF_DSIZE))) { st = ZMI_DATA_ERROR; break; }  // "invalid code lengths set"
             uint32_t have = 0, prevl = 0;
             const uint32_t total = nlen + ndist;
             while (have < total) {
                 inf_refill(B);
-                uint32_t e = S->dtab[inf_peek(B, 7)];
+                uint32_t e = zmi_uniform(S->dtab[inf_peek(B, 7)]);
                 uint32_t eb = e & 0xFFu;
                 if (((e >> 8) & 0xFFu) != INF_OP_LIT || eb == 0u) { st = ZMI_DATA_ERROR; break; }
                 if (B.nbits < eb) { st = ZMI_BUF_ERROR; break; }
@@ -368,78 +442,179 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             zmi_wave_sync();
             for (uint32_t i = lane; i < nlen; i += 64u) S->lens[i] = S->stage[i];
             zmi_wave_sync();
-            if (S->lens[256] == 0) { st = ZMI_DATA_ERROR; break; }  // "invalid code -- missing end-of-block"
-            if (inf_build(S, 1u, nlen, S->ltab, INF_LROOT, INF_LSIZE)) { st = ZMI_DATA_ERROR; break; }  // "invalid literal/lengths set"
+            if (zmi_uniform(S->lens[256]) == 0) { st = ZMI_DATA_ERROR; break; }  // "invalid code -- missing end-of-block"
+            if (zmi_uniform(inf_build(S, 1u, nlen, S->ltab, INF_LROOT, INF_LSIZE))) { st = ZMI_DATA_ERROR; break; }  // "invalid literal/lengths set"
             if (lane < ndist) S->lens[lane] = S->stage[nlen + lane];
             zmi_wave_sync();
-            if (inf_build(S, 2u, ndist, S->dtab, INF_DROOT, INF_DSIZE)) { st = ZMI_DATA_ERROR; break; }  // "invalid distances set"
+            if (zmi_uniform(inf_build(S, 2u, ndist, S->dtab, INF_DROOT, INF_DSIZE))) { st = ZMI_DATA_ERROR; break; }  // "invalid distances set"
         }
 
-        // ---- symbol loop ----
-        // Literals are collected (up to 8, in a wave-uniform register) and stored by one masked store;
-        // back-references flush them first because they may read those bytes.
-        uint64_t litbuf = 0;
-        uint32_t nlit = 0;
-#define INF_FLUSH_LITS()                                                                  \
-        do {                                                                              \
-            if (nlit) {                                                                   \
-                if (lane < nlit) dst[opos - nlit + lane] = (uint8_t)(litbuf >> (8u * lane)); \
-                zmi_wave_sync();                                                          \
-                litbuf = 0; nlit = 0;                                                     \
-            }                                                                             \
-        } while (0)
-        for (;;) {
-            inf_refill(B);
-            uint32_t e = inf_lookup(S->ltab, INF_LROOT, B);
-            uint32_t eb = e & 0xFFu, op = (e >> 8) & 0xFFu;
-            if (op == INF_OP_BAD || eb == 0u) { st = (B.nbits < 15u && B.ipos >= B.n) ? ZMI_BUF_ERROR : ZMI_DATA_ERROR; break; }  // "invalid literal/length code"
-            if (eb > B.nbits) { st = ZMI_BUF_ERROR; break; }
-            inf_drop(B, eb);
-            if (op == INF_OP_LIT) {
-                if (opos >= cap) { st = ZMI_NEED_OUTPUT; break; }
-                litbuf |= (uint64_t)(e >> 16) << (8u * nlit);
-                ++nlit;
-                ++opos;
-                if (nlit == 8u) INF_FLUSH_LITS();
-                continue;
-            }
-            if (op == INF_OP_EOB) break;
-            // length
-            uint32_t xb = op & 0x0Fu;
-            if (xb > B.nbits) { st = ZMI_BUF_ERROR; break; }
-            uint32_t mlen = (e >> 16) + inf_peek(B, xb);
-            inf_drop(B, xb);
-            inf_refill(B);
-            e = inf_lookup(S->dtab, INF_DROOT, B);
-            eb = e & 0xFFu; op = (e >> 8) & 0xFFu;
-            if (op == INF_OP_BAD || eb == 0u || !(op & INF_OP_BASE)) { st = (B.nbits < 15u && B.ipos >= B.n) ? ZMI_BUF_ERROR : ZMI_DATA_ERROR; break; }  // "invalid distance code"
-            xb = op & 0x0Fu;
-            if (eb + xb > B.nbits) { st = ZMI_BUF_ERROR; break; }
-            inf_drop(B, eb);
-            uint32_t dist = (e >> 16) + inf_peek(B, xb);
-            inf_drop(B, xb);
-            if (dist > opos) { st = ZMI_DATA_ERROR; break; }  // "invalid distance too far back"
-            if (opos + mlen > cap) { st = ZMI_NEED_OUTPUT; break; }
-            INF_FLUSH_LITS();
-            if (dist >= mlen || dist >= 64u) {
-                for (uint32_t base = 0; base < mlen; base += 64u) {
-                    uint32_t i = base + lane;
-                    if (i < mlen) dst[opos + i] = dst[opos + i - dist];
-                    zmi_wave_sync();
+        // ---- symbol rounds ----
+        // Lane i decodes, speculatively, the complete token (literal, end-of-block, or length + distance
+        // with their extra bits: at most 48 bits) that would start at bit P + i.  The real token chain
+        // is then walked from lane 0 with scalar lane reads (each hop is a handful of SALU
+        // instructions), a wave scan places the outputs, literals are written in parallel and the
+        // round's back-references are copied in order.  One round costs about as much as two serially
+        // decoded symbols and yields every token that starts inside the 64-bit window.
+        {
+            uint64_t P = 8ull * B.ipos - B.nbits;   // bit position of the next token
+            const uint64_t Pend = 8ull * B.n;
+            const uint32_t* iw = (const uint32_t*)B.inbuf;
+            bool eob = false;
+            while (!eob && st == ZMI_OK) {
+                uint32_t ib = (uint32_t)(P >> 3);
+                uint32_t relbyte = (uint32_t)((int32_t)ib - B.cbase);
+                // the window reads up to 19 bytes past its first byte; the serial reader may also have
+                // moved the chunk past bits it still held when it handed over
+                if ((int32_t)relbyte < 0 || relbyte + 20u > INF_CHUNK) {
+                    B.cbase = (int32_t)zmi_uniform((uint32_t)inf_load_chunk(B.src, B.n, ib, B.inbuf));
+                    relbyte = (uint32_t)((int32_t)ib - B.cbase);
                 }
-            } else {
-                // overlapping run shorter than a wave: replicate the dist-byte period
-                for (uint32_t base = 0; base < mlen; base += 64u) {
-                    uint32_t i = base + lane;
-                    if (i < mlen) dst[opos + i] = dst[opos - dist + (i % dist)];
+                const uint32_t bo = ((relbyte << 3) | ((uint32_t)P & 7u)) + lane;   // my bit offset inside inbuf
+                const uint32_t wi = bo >> 5, sh = bo & 31u;
+                const uint32_t d0 = iw[wi], d1 = iw[wi + 1u], d2 = iw[wi + 2u];
+                const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh);
+                const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+                const uint64_t left = Pend - P;   // input bits from P to the end of the stream
+                const int32_t rem = (int32_t)(left > 0x40000000ull ? 0x40000000u : (uint32_t)left) - (int32_t)lane;
+
+                // literal / length code
+                uint32_t e = S->ltab[lo & ((1u << INF_LROOT) - 1u)];
+                if ((e >> 8) & INF_OP_LINK) {
+                    uint32_t sb = (e >> 8) & 0x0Fu;
+                    e = S->ltab[(e >> 16) + ((lo >> INF_LROOT) & ((1u << sb) - 1u))];
                 }
-                zmi_wave_sync();
+                const uint32_t bits = e & 0xFFu, op = (e >> 8) & 0xFFu;
+                uint32_t t = bits;          // token length in bits
+                uint32_t kind = 0;          // 0 literal, 1 back-reference, 2 end of block
+                uint32_t err = 0;           // 1: more input needed, 2: invalid data
+                uint32_t val = e >> 16;     // literal byte | match length
+                uint32_t dist = 0;
+                if (op == INF_OP_BAD || bits == 0u) err = rem < 15 ? 1u : 2u;   // "invalid literal/length code"
+                else if ((int32_t)bits > rem) err = 1u;
+                else if (op == INF_OP_EOB) kind = 2u;
+                else if (op != INF_OP_LIT) {
+                    const uint32_t xb = op & 0x0Fu;
+                    const uint32_t used = bits + xb;   // <= 20
+                    val += (lo >> bits) & ((1u << xb) - 1u);
+                    const uint32_t rest = __builtin_amdgcn_alignbit(hi, lo, used);
+                    uint32_t d = S->dtab[rest & ((1u << INF_DROOT) - 1u)];
+                    if ((d >> 8) & INF_OP_LINK) {
+                        uint32_t sb = (d >> 8) & 0x0Fu;
+                        d = S->dtab[(d >> 16) + ((rest >> INF_DROOT) & ((1u << sb) - 1u))];
+                    }
+                    const uint32_t dbits = d & 0xFFu, dop = (d >> 8) & 0xFFu;
+                    kind = 1u;
+                    if ((int32_t)used > rem) err = 1u;
+                    else if (dop == INF_OP_BAD || dbits == 0u || !(dop & INF_OP_BASE)) err = (rem - (int32_t)used) < 15 ? 1u : 2u;   // "invalid distance code"
+                    else {
+                        const uint32_t dxb = dop & 0x0Fu;
+                        dist = (d >> 16) + ((rest >> dbits) & ((1u << dxb) - 1u));
+                        t = used + dbits + dxb;   // <= 48
+                        if ((int32_t)t > rem) err = 1u;
+                    }
+                }
+                const uint32_t tw = t | (kind << 6) | (err << 8);
+
+                // walk the chain of real tokens
+                uint32_t pos = 0;
+                uint64_t M = 0;
+                int32_t rst = ZMI_OK;
+                while (pos < 64u) {
+                    const uint32_t w = zmi_readlane(tw, pos);
+                    const uint32_t we = w >> 8;
+                    if (we) { rst = we == 1u ? ZMI_BUF_ERROR : ZMI_DATA_ERROR; break; }
+                    M |= 1ull << pos;
+                    pos += w & 63u;
+                    if (((w >> 6) & 3u) == 2u) { eob = true; break; }
+                }
+
+                // place the outputs
+                bool on = (M >> lane) & 1ull;
+                const uint32_t outlen = on ? (kind == 0u ? 1u : (kind == 1u ? val : 0u)) : 0u;
+                const uint32_t incl = zmi_wave_incl_scan(outlen);
+                const uint32_t excl = incl - outlen;
+                const bool far_back = on && kind == 1u && dist > opos + excl;        // "invalid distance too far back"
+                const bool no_room = on && outlen != 0u && opos + incl > cap;
+                const bool too_much = on && incl > INF_OUTMAX;
+                const uint64_t cut = __ballot(far_back || no_room || too_much);
+                uint32_t tot;
+                if (cut) {
+                    // the round ends in front of token k; whatever the walk found behind it is not reached
+                    const uint32_t k = (uint32_t)__ffsll((unsigned long long)cut) - 1u;
+                    const uint32_t fb = (uint32_t)((__ballot(far_back) >> k) & 1ull);
+                    const uint32_t nr = (uint32_t)((__ballot(no_room) >> k) & 1ull);
+                    M &= (1ull << k) - 1ull;
+                    on = (M >> lane) & 1ull;
+                    tot = zmi_readlane(excl, k);
+                    pos = k;
+                    eob = false;
+                    rst = fb ? ZMI_DATA_ERROR : (nr ? ZMI_NEED_OUTPUT : ZMI_OK);
+                } else {
+                    tot = zmi_readlane(incl, 63u);
+                }
+                if (on && kind == 0u) S->ring[(opos + excl) & INF_RMASK] = (uint8_t)val;
+                uint64_t Tm = __ballot(on && kind == 1u);
+                const uint32_t mpack = val | (dist << 16);   // dist <= 32768 needs 16 bits, val <= 258
+                while (Tm) {
+                    const uint32_t k = (uint32_t)__ffsll((unsigned long long)Tm) - 1u;
+                    Tm &= Tm - 1ull;
+                    const uint32_t mp = zmi_readlane(mpack, k);
+                    const uint32_t mlen = mp & 0xFFFFu, md = mp >> 16;
+                    const uint32_t mo = opos + zmi_readlane(excl, k);
+                    const uint32_t s0 = mo - md;
+                    zmi_wave_order();
+                    if (md <= INF_NEAR) {
+                        // source still in the ring; byte i of the copy is source byte (i mod md), all original
+                        if (md >= mlen) {
+                            if (mlen <= 64u) {
+                                if (lane < mlen) S->ring[(mo + lane) & INF_RMASK] = S->ring[(s0 + lane) & INF_RMASK];
+                            } else {
+                                uint8_t v[5];
+#pragma unroll
+                                for (uint32_t j = 0; j < 5u; ++j) {
+                                    uint32_t i = lane + 64u * j;
+                                    v[j] = i < mlen ? S->ring[(s0 + i) & INF_RMASK] : (uint8_t)0;
+                                }
+#pragma unroll
+                                for (uint32_t j = 0; j < 5u; ++j) {
+                                    uint32_t i = lane + 64u * j;
+                                    if (i < mlen) S->ring[(mo + i) & INF_RMASK] = v[j];
+                                }
+                            }
+                        } else {
+                            for (uint32_t i = lane; i < mlen; i += 64u)
+                                S->ring[(mo + i) & INF_RMASK] = S->ring[(s0 + i % md) & INF_RMASK];
+                        }
+                    } else {
+                        // far: the whole source was streamed to HBM by this wave in an earlier round
+                        for (uint32_t i = lane; i < mlen; i += 64u) S->ring[(mo + i) & INF_RMASK] = dst[s0 + i];
+                    }
+                }
+                opos += tot;
+                P += pos;
+                if ((opos & ~255u) != flushed) {
+                    zmi_wave_order();
+                    inf_flush_lines(S->ring, dst, flushed, opos & ~255u, aligned4);
+                    flushed = opos & ~255u;
+                }
+                zmi_wave_order();
+                if (rst != ZMI_OK) st = rst;
             }
-            opos += mlen;
+            // hand the bit position back to the serial reader (block headers, stored blocks, trailer)
+            B.ipos = (uint32_t)(P >> 3);
+            B.hold = 0;
+            B.nbits = 0;
+            if (st == ZMI_OK) {
+                inf_refill(B);
+                inf_drop(B, (uint32_t)P & 7u);
+            }
         }
-        INF_FLUSH_LITS();
-#undef INF_FLUSH_LITS
     }
+    // whatever is in the ring beyond the last full line (also on errors: the reference leaves the bytes
+    // it produced before the error in the output buffer)
+    zmi_wave_order();
+    for (uint32_t i = flushed + lane; i < opos; i += 64u) dst[i] = S->ring[i & INF_RMASK];
 
     // ---- trailer ----
     uint32_t chk = 0;
@@ -449,8 +624,8 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
         if (kind_found == 1u) {
             if (B.ipos + 4u > B.n) st = ZMI_BUF_ERROR;
             else {
-                chk = ((uint32_t)B.src[B.ipos] << 24) | ((uint32_t)B.src[B.ipos + 1u] << 16) |
-                      ((uint32_t)B.src[B.ipos + 2u] << 8) | B.src[B.ipos + 3u];
+                chk = ((uint32_t)inf_byte(B, B.ipos) << 24) | ((uint32_t)inf_byte(B, B.ipos + 1u) << 16) |
+                      ((uint32_t)inf_byte(B, B.ipos + 2u) << 8) | inf_byte(B, B.ipos + 3u);
                 B.ipos += 4u;
             }
         } else if (kind_found == 2u) {
@@ -458,13 +633,13 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             // CRC mismatch as a data error, as the reference's streaming state machine does
             if (B.ipos + 4u > B.n) st = ZMI_BUF_ERROR;
             else {
-                chk = B.src[B.ipos] | ((uint32_t)B.src[B.ipos + 1u] << 8) | ((uint32_t)B.src[B.ipos + 2u] << 16) |
-                      ((uint32_t)B.src[B.ipos + 3u] << 24);
+                chk = inf_byte(B, B.ipos) | ((uint32_t)inf_byte(B, B.ipos + 1u) << 8) | ((uint32_t)inf_byte(B, B.ipos + 2u) << 16) |
+                      ((uint32_t)inf_byte(B, B.ipos + 3u) << 24);
                 B.ipos += 4u;
                 if (B.ipos + 4u > B.n) st = ZMI_TRAILER_SHORT;
                 else {
-                    uint32_t isize = B.src[B.ipos] | ((uint32_t)B.src[B.ipos + 1u] << 8) |
-                                     ((uint32_t)B.src[B.ipos + 2u] << 16) | ((uint32_t)B.src[B.ipos + 3u] << 24);
+                    uint32_t isize = inf_byte(B, B.ipos) | ((uint32_t)inf_byte(B, B.ipos + 1u) << 8) |
+                                     ((uint32_t)inf_byte(B, B.ipos + 2u) << 16) | ((uint32_t)inf_byte(B, B.ipos + 3u) << 24);
                     B.ipos += 4u;
                     if (isize != opos) st = ZMI_LENGTH_MISMATCH;  // "incorrect length check" (after the CRC check)
                 }

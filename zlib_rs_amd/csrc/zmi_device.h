@@ -23,10 +23,30 @@
 // hardware, so this only has to stop the compiler from moving memory operations across it).
 #ifdef ZMI_EMU
 static inline void zmi_wave_sync() { emu::wave_rendezvous(0, false); }
+static inline void zmi_wave_order() { emu::wave_rendezvous(0, false); }
 #else
+// program-order point for cross-lane traffic through LDS or through this wave's own global stores: the
+// hardware executes a wave's memory instructions in order, so only the compiler has to be held back
+static __device__ __forceinline__ void zmi_wave_order() { __builtin_amdgcn_wave_barrier(); }
 static __device__ __forceinline__ void zmi_wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+#endif
+
+// tell the compiler a value is the same in every lane (it then lives in an SGPR and branches on it are scalar)
+#ifdef ZMI_EMU
+static inline uint32_t zmi_uniform(uint32_t v) { return v; }
+#else
+static __device__ __forceinline__ uint32_t zmi_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+#endif
+
+// value of `v` in lane `k` (k wave-uniform), as a scalar
+#ifdef ZMI_EMU
+static inline uint32_t zmi_readlane(uint32_t v, uint32_t k) { return (uint32_t)__shfl((int)v, (int)k); }
+#else
+static __device__ __forceinline__ uint32_t zmi_readlane(uint32_t v, uint32_t k) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)k);
 }
 #endif
 
