@@ -51,9 +51,13 @@ int zmi_ctx_create(zmi_ctx** ctx, int device);
 int zmi_ctx_destroy(zmi_ctx* ctx);
 /* upper bound of scratch the context may allocate on the device (default 8 GiB; env ZMI_SCRATCH_MB) */
 int zmi_ctx_set_scratch_limit(zmi_ctx* ctx, uint64_t bytes);
+/* total output capacity (sum of d_out_cap) one inflate batch may cover.  Inflate keeps 1 bit of scratch
+ * per output byte; the capacities live on the device, so the bound comes from here (default: the scratch
+ * limit, i.e. 8 GiB of output -> 1 GiB of bitmap).  Streams beyond it report Z_MEM_ERROR (-4). */
+int zmi_ctx_set_inflate_out_limit(zmi_ctx* ctx, uint64_t bytes);
 
-/* per-kernel HIP-event timing for benchmarking: kernels 0 checksum, 1 lz77, 2 encode, 3 inflate,
- * 4 verify.  zmi_ctx_get_timing synchronises, returns the sums (ms) / launch counts since the
+/* per-kernel HIP-event timing for benchmarking: kernels 0 checksum, 1 lz77, 2 encode, 3 inflate (decode),
+ * 4 verify, 6 inflate (resolve).  zmi_ctx_get_timing synchronises, returns the sums (ms) / launch counts since the
  * previous call (arrays of 8) and resets them. */
 int zmi_ctx_set_timing(zmi_ctx* ctx, int on);
 int zmi_ctx_get_timing(zmi_ctx* ctx, double* ms_sums, uint32_t* counts);

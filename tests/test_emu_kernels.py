@@ -94,3 +94,50 @@ def test_inflate_kernel_errors(eng, o):
     outs, st = eng.inflate([good, bytes(bad), bytes(badchk), good[:700], good, b"\x78\x9c\x07"], [len(d)] * 4 + [100, 10], 1)
     assert st[0] == 0 and outs[0] == d
     assert st[1] in (-3, -5) and st[2] == -3 and st[3] == -5 and st[4] == -5 and st[5] == -3
+
+
+def test_inflate_many_small_blocks(eng, o):
+    """block headers, empty stored blocks and the 1 KiB input chunk boundary meet in every alignment"""
+    d = o.gen_shard(0, 12000) + o.gen_shard(6, 9000)
+    for flush in (zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH):
+        for step in (37, 211):
+            co = zlib.compressobj(6, zlib.DEFLATED, 15)
+            s = b"".join(co.compress(d[i:i + step]) + co.flush(flush) for i in range(0, len(d), step)) + co.flush()
+            assert zlib.decompress(s) == d
+            outs, st = eng.inflate([s], [len(d)], 1)
+            assert st == [0] and outs[0] == d
+
+
+def test_inflate_long_distances_and_runs(eng, o):
+    r = o.prng_bytes(11, 32768, 1)
+    blobs = [r + r + r[:700],                       # distance 32768, maximal lengths
+             bytes(70000),                          # distance 1 runs across many 258-byte copies
+             b"ab" * 20000 + b"xyz" * 9000,         # short periods
+             r[:5000] + bytes(300) + r[:5000] + o.gen_shard(3, 1 << 15)]
+    for level in (1, 9):
+        streams = [zlib.compress(b, level) for b in blobs]
+        outs, st = eng.inflate(streams, [len(b) for b in blobs], 1)
+        assert st == [0] * len(blobs)
+        assert outs == blobs
+
+
+def test_inflate_unaligned_layout_and_scratch_limit(eng, o):
+    blobs = [o.gen_shard(1, 5000), o.gen_shard(4, 3001), b"q" * 777 + o.gen_shard(6, 2000), o.gen_shard(2, 4097)]
+    streams = [zlib.compress(b, 6) for b in blobs]
+    caps = [len(b) for b in blobs]
+    ioff, ooff, a, b_ = [], [], 3, 5
+    for s, c in zip(streams, caps):
+        ioff.append(a); a += len(s) + 7
+        ooff.append(b_); b_ += c + 3          # odd offsets: the 4- and 16-byte aligned paths are not taken
+    outs, st, guard = eng.inflate_dev(streams, caps, ioff, ooff, 1, out_limit=1 << 20)
+    assert st == [0, 0, 0, 0] and outs == blobs
+    assert all(g == b"\xee" for g in guard)   # nothing written past a stream's capacity
+    # a context whose bitmap scratch covers only part of the batch: the rest reports Z_MEM_ERROR, never garbage
+    big = [o.gen_shard(0, 1 << 17)] * 12
+    sb = [zlib.compress(x, 1) for x in big]
+    off_i = [sum(len(x) for x in sb[:i]) for i in range(len(sb))]
+    off_o = [i << 17 for i in range(len(sb))]
+    outs, st, _ = eng.inflate_dev(sb, [1 << 17] * len(sb), off_i, off_o, 1, out_limit=1 << 20)
+    assert st[0] == 0 and outs[0] == big[0]
+    assert -4 in st and all(x in (0, -4) for x in st)
+    assert all(o_ == big[0] for o_, x in zip(outs, st) if x == 0)

@@ -23,6 +23,9 @@ def _bind(lib):
                                       C.c_void_p, C.c_uint64, u32p, i32p]
     lib.zmi_inflate_batch.argtypes = [C.c_void_p, C.c_void_p, u64p, u32p, C.c_uint32, C.c_int, C.c_void_p, u64p, u32p,
                                       u32p, i32p]
+    vp = C.c_void_p
+    lib.zmi_inflate_batch_dev.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int, vp, vp, vp, vp, vp, vp]
+    lib.zmi_ctx_set_inflate_out_limit.argtypes = [vp, C.c_uint64]
     return lib
 
 
@@ -95,3 +98,28 @@ class Engine:
         if rc != 0:
             raise RuntimeError("zmi_inflate_batch failed: %d %s" % (rc, self.lib.zmi_last_error().decode()))
         return [bytes(out[int(ooff[i]):int(ooff[i]) + min(int(olen[i]), int(ocap[i]))]) for i in range(n)], [int(x) for x in st[:n]]
+
+    def inflate_dev(self, streams, caps, in_offsets, out_offsets, wrap=1, out_limit=None):
+        """EMULATOR ONLY (its "device" memory is host memory): the device-pointer entry point with an
+        arbitrary input / output layout -> (list of bytes, list of status)"""
+        n = len(streams)
+        lens = np.array([len(s) for s in streams], dtype=np.uint32)
+        ioff = np.array(in_offsets, dtype=np.uint64)
+        ooff = np.array(out_offsets, dtype=np.uint64)
+        ocap = np.array(caps, dtype=np.uint32)
+        blob = np.zeros(int(max(int(o) + len(s) for o, s in zip(in_offsets, streams))) + 64, dtype=np.uint8)
+        for o, s_ in zip(in_offsets, streams):
+            blob[int(o):int(o) + len(s_)] = np.frombuffer(s_, dtype=np.uint8)
+        out = np.full(int(max(int(o) + int(c) for o, c in zip(out_offsets, caps))) + 64, 0xEE, dtype=np.uint8)
+        olen = np.zeros(n, dtype=np.uint32)
+        st = np.zeros(n, dtype=np.int32)
+        if out_limit is not None:
+            self.lib.zmi_ctx_set_inflate_out_limit(self.ctx, int(out_limit))
+        rc = self.lib.zmi_inflate_batch_dev(self.ctx, blob.ctypes.data, ioff.ctypes.data, lens.ctypes.data, n, wrap,
+                                            out.ctypes.data, ooff.ctypes.data, ocap.ctypes.data, olen.ctypes.data,
+                                            st.ctypes.data, None)
+        if rc != 0:
+            raise RuntimeError("zmi_inflate_batch_dev failed: %d %s" % (rc, self.lib.zmi_last_error().decode()))
+        res = [bytes(out[int(ooff[i]):int(ooff[i]) + min(int(olen[i]), int(ocap[i]))]) for i in range(n)]
+        guard = [bytes(out[int(ooff[i]) + int(ocap[i]):int(ooff[i]) + int(ocap[i]) + 1]) for i in range(n)]
+        return res, [int(x) for x in st], guard

@@ -81,8 +81,8 @@ def main():
                 torch.cuda.synchronize()
                 dt = time.perf_counter() - t
                 sums, cnts = timing(e)
-                print("inflate S=%d: %.2f GiB/s wall  ok=%s  ms: inflate %.2f checksum %.2f" %
-                      (S, S * B / 2**30 / dt, bool(torch.equal(back, data)) and int((bst != 0).sum()) == 0, sums[3], sums[0]))
+                print("inflate S=%d: %.2f GiB/s wall  ok=%s  ms: decode %.2f resolve %.2f checksum %.2f" %
+                      (S, S * B / 2**30 / dt, bool(torch.equal(back, data)) and int((bst != 0).sum()) == 0, sums[3], sums[6], sums[0]))
                 if os.environ.get("PROBE_CLASSES"):
                     for cls in range(8):
                         idx = torch.arange(cls, S, 8, device=e.device)
@@ -92,7 +92,7 @@ def main():
                         e.inflate_batch(out, *a)
                         torch.cuda.synchronize()
                         sm, _ = timing(e)
-                        print("    class %d: inflate %.2f ms for %d streams" % (cls, sm[3], idx.numel()))
+                        print("    class %d: decode %.2f resolve %.2f ms for %d streams" % (cls, sm[3], sm[6], idx.numel()))
         del data
     e.close()
 

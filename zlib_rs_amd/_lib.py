@@ -22,6 +22,7 @@ def lib():
     L.zmi_ctx_create.argtypes = [C.POINTER(vp), i32]
     L.zmi_ctx_destroy.argtypes = [vp]
     L.zmi_ctx_set_scratch_limit.argtypes = [vp, u64]
+    L.zmi_ctx_set_inflate_out_limit.argtypes = [vp, u64]
     L.zmi_deflate_bound.restype = u64
     L.zmi_deflate_bound.argtypes = [u64, i32]
     L.zmi_deflate_batch_dev.argtypes = [vp, vp, vp, vp, u32, u32, i32, i32, i32, vp, u64, vp, vp, vp]

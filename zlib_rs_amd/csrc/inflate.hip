@@ -12,16 +12,19 @@
 // literal/length or distance code, distance too far back) and Z_BUF_ERROR for truncated input
 // or a too-small output buffer.
 //
-// MI355X design: the symbol decode of one stream is serial, so the batch supplies the parallelism --
-// one 64-lane wave per stream, its two lookup tables (7.6 KiB) in LDS, ~19 streams resident per CU.
-// The bit buffer and all decode state are wave-uniform; the 64 lanes co-operate on table
-// construction (replicated entries written lane-parallel) and on back-reference copies.
-// Neither side of the symbol loop touches HBM in its dependent chain: compressed input is staged
-// through a 1 KiB LDS chunk (one coalesced load per KiB), and output goes into an LDS ring holding the
-// most recent INF_RING bytes, from which completed 256-byte lines are streamed out with coalesced
-// fire-and-forget stores.  Back-references within the ring are LDS->LDS copies; only the far ones
-// (distance > INF_RING - length) read back what the wave stored to HBM earlier.
-// Algorithmic HBM traffic: (1/ratio) B read + 1 B written per output byte.
+// MI355X design: the symbol decode of one stream is serial in its bit position, so the batch supplies the
+// parallelism -- one 64-lane wave per stream -- and the work of a stream is split so that no HBM round
+// trip sits in a dependent chain:
+//   decode  (zmi_inflate_kernel)          Huffman decoding only.  64 lanes decode the tokens starting at 64
+//           consecutive bit positions speculatively, the real chain is walked with scalar lane reads, a wave
+//           scan places the outputs.  Literals go straight to their final place in HBM; a back-reference
+//           leaves a 3-byte record (length, distance) in the first bytes of the hole it will fill and sets a
+//           bit in a per-stream bitmap (1 bit per output byte).  No window is needed, so a wave holds only
+//           its lookup tables and a 1 KiB input chunk in LDS (~10 KiB, 15 streams per CU).
+//   resolve (zmi_inflate_resolve_kernel)  streams the output once through a 64 KiB LDS ring and fills the
+//           holes in order; every source lies in the ring (distance <= 32 KiB), so copies are LDS -> LDS.
+// Algorithmic HBM traffic: (1/ratio) B read + 1 B written per output byte; the two-pass split adds one more
+// read and write of the output plus the bitmap (1/8 B per byte).
 #include "zmi_device.h"
 #include "zmi_kernels.h"
 
@@ -30,12 +33,10 @@
 #define ZMI_LENGTH_MISMATCH (-1003)   // gzip: ISIZE wrong                  -> data error either way
 #define ZMI_NEED_OUTPUT (-1006)       // output capacity exhausted          -> Z_BUF_ERROR (detail 2)
 #define INF_CHUNK 1024u
-#ifndef INF_RING
-#define INF_RING 8192u               // output history kept in LDS (power of two, >= 1024)
-#endif
-#define INF_RMASK (INF_RING - 1u)
-#define INF_OUTMAX 768u              // output bytes one decode round may produce (>= 258)
-#define INF_NEAR (INF_RING - INF_OUTMAX)  // back-references up to this distance are served from the ring
+#define RES_RING 65536u              // resolve pass: output history kept in LDS (power of two, > 32768 + 258 + RES_BLK)
+#define RES_MASK (RES_RING - 1u)
+#define RES_BLK 1024u                // resolve pass: bytes staged per load step
+#define ZMI_NO_SCRATCH (-4)          // Z_MEM_ERROR: the bitmap scratch of the context does not cover this stream
 #define INF_LROOT 10u
 #define INF_DROOT 9u
 #define INF_LSIZE 1344u
@@ -59,24 +60,7 @@ struct InfShared {
     uint32_t offs[16];
     uint32_t misc[8];
     __attribute__((aligned(16))) uint8_t inbuf[INF_CHUNK + 32];  // staged compressed input (one coalesced load per KiB)
-    __attribute__((aligned(16))) uint8_t ring[INF_RING];         // output bytes [opos - INF_RING, opos), index = offset & INF_RMASK
 };
-
-// stream completed 256-byte lines [from, upto) of the ring to HBM (from, upto multiples of 256)
-static __device__ __forceinline__ void inf_flush_lines(const uint8_t* ring, uint8_t* dst, uint32_t from, uint32_t upto,
-                                                       bool aligned4) {
-    const uint32_t lane = zmi_lane();
-    for (uint32_t c = from; c < upto; c += 256u) {
-        uint32_t o = c + 4u * lane;
-        uint32_t w = *(const uint32_t*)(ring + (o & INF_RMASK));
-        if (aligned4) *(uint32_t*)(dst + o) = w;
-        else {
-            dst[o] = (uint8_t)w; dst[o + 1u] = (uint8_t)(w >> 8);
-            dst[o + 2u] = (uint8_t)(w >> 16); dst[o + 3u] = (uint8_t)(w >> 24);
-        }
-    }
-}
-
 
 struct InfBits {
     const uint8_t* src;
@@ -272,7 +256,8 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                                                          uint8_t* out, const uint64_t* __restrict__ out_off,
                                                          const uint32_t* __restrict__ out_cap,
                                                          uint32_t* __restrict__ out_len, uint32_t* __restrict__ in_used,
-                                                         uint32_t* __restrict__ check, int32_t* __restrict__ status) {
+                                                         uint32_t* __restrict__ check, int32_t* __restrict__ status,
+                                                         uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ bm_off) {
     __shared__ InfShared Sh;
     InfShared* S = &Sh;
     const uint32_t lane = zmi_lane();
@@ -288,9 +273,13 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
     uint8_t* dst = out + out_off[s];
     const uint32_t cap = out_cap[s];
     uint32_t opos = 0;
-    uint32_t flushed = 0;  // multiple of 256: ring bytes below it are already in HBM
-    const bool aligned4 = ((uintptr_t)dst & 3u) == 0u;
     int32_t st = ZMI_OK;
+    const uint64_t bmo = bm_off[s];
+    uint32_t* bm32 = (uint32_t*)(bitmap + (bmo == ~0ull ? 0ull : bmo));   // bit p set: a back-reference starts at output byte p
+    if (bmo == ~0ull) {
+        if (lane == 0) { out_len[s] = 0; in_used[s] = 0; check[s] = 0; status[s] = ZMI_NO_SCRATCH; }
+        return;
+    }
     uint32_t kind_found = wrap;  // resolved wrapper: 0 raw, 1 zlib, 2 gzip
     uint32_t fixed_ready = 0;
 
@@ -349,28 +338,8 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             if ((l ^ 0xFFFFu) != nl) { st = ZMI_DATA_ERROR; break; }   // "invalid stored block lengths"
             if (B.ipos + l > B.n) { st = ZMI_BUF_ERROR; break; }
             if (opos + l > cap) { st = ZMI_NEED_OUTPUT; break; }
-            // through the ring like everything else (later back-references may point into stored bytes)
-            for (uint32_t base = 0; base < l; base += 256u) {
-                uint32_t nb = l - base < 256u ? l - base : 256u;
-                uint8_t v[4];
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; ++j) {
-                    uint32_t i = lane + 64u * j;
-                    v[j] = i < nb ? B.src[B.ipos + base + i] : (uint8_t)0;
-                }
-#pragma unroll
-                for (uint32_t j = 0; j < 4u; ++j) {
-                    uint32_t i = lane + 64u * j;
-                    if (i < nb) S->ring[(opos + i) & INF_RMASK] = v[j];
-                }
-                zmi_wave_order();
-                opos += nb;
-                if ((opos & ~255u) != flushed) {
-                    inf_flush_lines(S->ring, dst, flushed, opos & ~255u, aligned4);
-                    flushed = opos & ~255u;
-                    zmi_wave_order();
-                }
-            }
+            for (uint32_t i = lane; i < l; i += 64u) dst[opos + i] = B.src[B.ipos + i];
+            opos += l;
             B.ipos += l;
             continue;
         }
@@ -453,9 +422,8 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
         // Lane i decodes, speculatively, the complete token (literal, end-of-block, or length + distance
         // with their extra bits: at most 48 bits) that would start at bit P + i.  The real token chain
         // is then walked from lane 0 with scalar lane reads (each hop is a handful of SALU
-        // instructions), a wave scan places the outputs, literals are written in parallel and the
-        // round's back-references are copied in order.  One round costs about as much as two serially
-        // decoded symbols and yields every token that starts inside the 64-bit window.
+        // instructions), a wave scan places the outputs, and every lane on the chain stores its own
+        // token: the literal byte, or the back-reference record + bitmap bit for the resolve pass.
         {
             uint64_t P = 8ull * B.ipos - B.nbits;   // bit position of the next token
             const uint64_t Pend = 8ull * B.n;
@@ -514,19 +482,22 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                         if ((int32_t)t > rem) err = 1u;
                     }
                 }
-                const uint32_t tw = t | (kind << 6) | (err << 8);
+                // bits 0-5 token length; anything above 63 stops the walk: 64 = end of block, 128 / 256 = error
+                const uint32_t tw = err ? (err << 7) : (t | (kind == 2u ? 64u : 0u));
 
                 // walk the chain of real tokens
-                uint32_t pos = 0;
+                uint32_t pos = 0, w;
                 uint64_t M = 0;
                 int32_t rst = ZMI_OK;
-                while (pos < 64u) {
-                    const uint32_t w = zmi_readlane(tw, pos);
-                    const uint32_t we = w >> 8;
-                    if (we) { rst = we == 1u ? ZMI_BUF_ERROR : ZMI_DATA_ERROR; break; }
+                do {
+                    w = zmi_readlane(tw, pos);
+                    if (w > 63u) break;
                     M |= 1ull << pos;
-                    pos += w & 63u;
-                    if (((w >> 6) & 3u) == 2u) { eob = true; break; }
+                    pos += w;
+                } while (pos < 64u);
+                if (pos < 64u) {
+                    if (w & 64u) { M |= 1ull << pos; pos += w & 63u; eob = true; }
+                    else rst = (w & 128u) ? ZMI_BUF_ERROR : ZMI_DATA_ERROR;
                 }
 
                 // place the outputs
@@ -536,69 +507,32 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                 const uint32_t excl = incl - outlen;
                 const bool far_back = on && kind == 1u && dist > opos + excl;        // "invalid distance too far back"
                 const bool no_room = on && outlen != 0u && opos + incl > cap;
-                const bool too_much = on && incl > INF_OUTMAX;
-                const uint64_t cut = __ballot(far_back || no_room || too_much);
+                const uint64_t cut = __ballot(far_back || no_room);
                 uint32_t tot;
                 if (cut) {
                     // the round ends in front of token k; whatever the walk found behind it is not reached
                     const uint32_t k = (uint32_t)__ffsll((unsigned long long)cut) - 1u;
                     const uint32_t fb = (uint32_t)((__ballot(far_back) >> k) & 1ull);
-                    const uint32_t nr = (uint32_t)((__ballot(no_room) >> k) & 1ull);
                     M &= (1ull << k) - 1ull;
                     on = (M >> lane) & 1ull;
                     tot = zmi_readlane(excl, k);
                     pos = k;
                     eob = false;
-                    rst = fb ? ZMI_DATA_ERROR : (nr ? ZMI_NEED_OUTPUT : ZMI_OK);
+                    rst = fb ? ZMI_DATA_ERROR : ZMI_NEED_OUTPUT;
                 } else {
                     tot = zmi_readlane(incl, 63u);
                 }
-                if (on && kind == 0u) S->ring[(opos + excl) & INF_RMASK] = (uint8_t)val;
-                uint64_t Tm = __ballot(on && kind == 1u);
-                const uint32_t mpack = val | (dist << 16);   // dist <= 32768 needs 16 bits, val <= 258
-                while (Tm) {
-                    const uint32_t k = (uint32_t)__ffsll((unsigned long long)Tm) - 1u;
-                    Tm &= Tm - 1ull;
-                    const uint32_t mp = zmi_readlane(mpack, k);
-                    const uint32_t mlen = mp & 0xFFFFu, md = mp >> 16;
-                    const uint32_t mo = opos + zmi_readlane(excl, k);
-                    const uint32_t s0 = mo - md;
-                    zmi_wave_order();
-                    if (md <= INF_NEAR) {
-                        // source still in the ring; byte i of the copy is source byte (i mod md), all original
-                        if (md >= mlen) {
-                            if (mlen <= 64u) {
-                                if (lane < mlen) S->ring[(mo + lane) & INF_RMASK] = S->ring[(s0 + lane) & INF_RMASK];
-                            } else {
-                                uint8_t v[5];
-#pragma unroll
-                                for (uint32_t j = 0; j < 5u; ++j) {
-                                    uint32_t i = lane + 64u * j;
-                                    v[j] = i < mlen ? S->ring[(s0 + i) & INF_RMASK] : (uint8_t)0;
-                                }
-#pragma unroll
-                                for (uint32_t j = 0; j < 5u; ++j) {
-                                    uint32_t i = lane + 64u * j;
-                                    if (i < mlen) S->ring[(mo + i) & INF_RMASK] = v[j];
-                                }
-                            }
-                        } else {
-                            for (uint32_t i = lane; i < mlen; i += 64u)
-                                S->ring[(mo + i) & INF_RMASK] = S->ring[(s0 + i % md) & INF_RMASK];
-                        }
-                    } else {
-                        // far: the whole source was streamed to HBM by this wave in an earlier round
-                        for (uint32_t i = lane; i < mlen; i += 64u) S->ring[(mo + i) & INF_RMASK] = dst[s0 + i];
-                    }
+                const uint32_t off = opos + excl;
+                if (on && kind == 0u) dst[off] = (uint8_t)val;
+                if (on && kind == 1u) {
+                    const uint32_t rec = (dist - 1u) | ((val - 3u) << 15);   // 15 + 8 bits, fits the smallest hole
+                    dst[off] = (uint8_t)rec;
+                    dst[off + 1u] = (uint8_t)(rec >> 8);
+                    dst[off + 2u] = (uint8_t)(rec >> 16);
+                    atomicOr(&bm32[off >> 5], 1u << (off & 31u));
                 }
                 opos += tot;
                 P += pos;
-                if ((opos & ~255u) != flushed) {
-                    zmi_wave_order();
-                    inf_flush_lines(S->ring, dst, flushed, opos & ~255u, aligned4);
-                    flushed = opos & ~255u;
-                }
-                zmi_wave_order();
                 if (rst != ZMI_OK) st = rst;
             }
             // hand the bit position back to the serial reader (block headers, stored blocks, trailer)
@@ -611,11 +545,6 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             }
         }
     }
-    // whatever is in the ring beyond the last full line (also on errors: the reference leaves the bytes
-    // it produced before the error in the output buffer)
-    zmi_wave_order();
-    for (uint32_t i = flushed + lane; i < opos; i += 64u) dst[i] = S->ring[i & INF_RMASK];
-
     // ---- trailer ----
     uint32_t chk = 0;
     if (st == ZMI_OK) {
@@ -654,6 +583,160 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
     }
 }
 
+// ---- bitmap planning: stream s owns the 64-bit words [bm_off[s], bm_off[s] + cap/64 + 2) of the scratch ----
+// Exclusive scan over the word counts by one workgroup; a stream that does not fit gets ~0 (its decode
+// reports Z_MEM_ERROR) -- the host cannot know the capacities without a synchronisation.
+__global__ void __launch_bounds__(1024) zmi_inflate_plan_kernel(const uint32_t* __restrict__ out_cap, uint32_t n,
+                                                                 uint64_t cap_words, uint64_t* __restrict__ bm_off) {
+    __shared__ uint64_t part[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (n + 1023u) / 1024u;
+    const uint32_t lo = t * per, hi = lo + per < n ? lo + per : n;
+    uint64_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += (uint64_t)(out_cap[i] >> 6) + 2ull;
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        uint64_t v = t >= d ? part[t - d] : 0ull;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint64_t o = part[t] - sum;
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint64_t w = (uint64_t)(out_cap[i] >> 6) + 2ull;
+        bm_off[i] = o + w <= cap_words ? o : ~0ull;
+        o += w;
+    }
+}
+
+__global__ void __launch_bounds__(256) zmi_inflate_clear_kernel(const uint32_t* __restrict__ out_cap, const uint64_t* __restrict__ bm_off,
+                                                                 uint64_t* __restrict__ bitmap) {
+    const uint32_t s = blockIdx.x;
+    const uint64_t o = bm_off[s];
+    if (o == ~0ull) return;
+    const uint64_t w = (uint64_t)(out_cap[s] >> 6) + 2ull;
+    for (uint64_t i = threadIdx.x; i < w; i += 256u) bitmap[o + i] = 0ull;
+}
+
+// ---- resolve pass: fill the back-reference holes of one stream, in order, inside an LDS ring ----
+// ring[x & RES_MASK] holds output byte x for x in [loaded - RES_RING, loaded).  Lines are staged from HBM
+// strictly in order (they carry the literals and the 3-byte records the decode pass left in the holes),
+// a hole is filled from the ring, and lines that can no longer change are streamed back.
+static __device__ __forceinline__ void res_stage(uint8_t* ring, const uint8_t* dst, uint32_t n_out, uint32_t& loaded, uint32_t upto,
+                                                 bool aligned16) {
+    const uint32_t lane = zmi_lane();
+    if (upto > loaded + RES_RING - 2048u) loaded = (upto - 32768u - 2u * RES_BLK) & ~(RES_BLK - 1u);   // a long stretch without holes: only the window matters
+    while (loaded < upto) {
+        const uint32_t so = loaded + 16u * lane;
+        uint4 q;
+        q.x = q.y = q.z = q.w = 0u;
+        if (aligned16 && so + 16u <= n_out) q = *(const uint4*)(dst + so);
+        else if (so < n_out) {
+            uint32_t w[4] = {0u, 0u, 0u, 0u};
+            for (uint32_t j = 0; j < 16u; ++j)
+                if (so + j < n_out) w[j >> 2] |= (uint32_t)dst[so + j] << (8u * (j & 3u));
+            q.x = w[0]; q.y = w[1]; q.z = w[2]; q.w = w[3];
+        }
+        *(uint4*)(ring + (so & RES_MASK)) = q;
+        loaded += RES_BLK;
+    }
+    zmi_wave_order();
+}
+static __device__ __forceinline__ void res_writeback(const uint8_t* ring, uint8_t* dst, uint32_t n_out, uint32_t from, uint32_t upto,
+                                                     bool aligned4) {
+    const uint32_t lane = zmi_lane();
+    zmi_wave_order();
+    for (uint32_t c = from; c < upto; c += 256u) {
+        const uint32_t o = c + 4u * lane;
+        const uint32_t w = *(const uint32_t*)(ring + (o & RES_MASK));
+        if (aligned4 && o + 4u <= n_out) *(uint32_t*)(dst + o) = w;
+        else
+            for (uint32_t j = 0; j < 4u; ++j)
+                if (o + j < n_out) dst[o + j] = (uint8_t)(w >> (8u * j));
+    }
+}
+
+__global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, const uint64_t* __restrict__ out_off,
+                                                                 const uint32_t* __restrict__ out_len,
+                                                                 const uint64_t* __restrict__ bitmap,
+                                                                 const uint64_t* __restrict__ bm_off) {
+    ZMI_DYN_SMEM(ring);
+    const uint32_t lane = zmi_lane();
+    const uint32_t s = blockIdx.x;
+    const uint64_t bmo = bm_off[s];
+    const uint32_t n_out = out_len[s];
+    if (bmo == ~0ull || n_out == 0u) return;
+    const uint64_t* bm = bitmap + bmo;
+    const uint32_t nwords = (n_out + 63u) >> 6;
+    uint8_t* dst = out + out_off[s];
+    const bool aligned16 = ((uintptr_t)dst & 15u) == 0u, aligned4 = ((uintptr_t)dst & 3u) == 0u;
+
+    uint32_t loaded = 0, wb = 0;
+    bool any = false;
+    for (uint32_t cbase = 0; cbase < nwords; cbase += 64u) {
+        const uint32_t idx = cbase + lane;
+        const uint64_t v = idx < nwords ? bm[idx] : 0ull;
+        const uint32_t vlo = (uint32_t)v, vhi = (uint32_t)(v >> 32);
+        uint64_t nz = __ballot(v != 0ull);
+        while (nz) {
+            const uint32_t j = (uint32_t)__ffsll((unsigned long long)nz) - 1u;
+            nz &= nz - 1ull;
+            uint64_t bits = (uint64_t)zmi_readlane(vlo, j) | ((uint64_t)zmi_readlane(vhi, j) << 32);
+            const uint32_t wbase = (cbase + j) << 6;
+            if (!any) {
+                // first hole of the stream: everything in front of it is final already; start one window back
+                any = true;
+                loaded = wbase > 32768u ? (wbase - 32768u) & ~(RES_BLK - 1u) : 0u;
+                wb = wbase & ~255u;
+            }
+            // lines in front of this word can no longer change
+            {
+                const uint32_t fin = wbase & ~255u, have = loaded < fin ? loaded : fin;
+                if (have > wb) res_writeback(ring, dst, n_out, wb, have, aligned4);
+                if (fin > wb) wb = fin;
+            }
+            while (bits) {
+                const uint32_t p = wbase + (uint32_t)__ffsll((unsigned long long)bits) - 1u;
+                bits &= bits - 1ull;
+                if (p + 3u > loaded) res_stage(ring, dst, n_out, loaded, p + 3u, aligned16);
+                const uint32_t a = p & RES_MASK;
+                const uint32_t r0 = *(const uint32_t*)(ring + (a & ~3u)), r1 = *(const uint32_t*)(ring + ((a + 4u) & RES_MASK & ~3u));
+                const uint32_t rec = zmi_uniform(__builtin_amdgcn_alignbyte(r1, r0, a & 3u)) & 0xFFFFFFu;
+                const uint32_t mlen = (rec >> 15) + 3u, md = (rec & 0x7FFFu) + 1u;
+                if (p + mlen > loaded) res_stage(ring, dst, n_out, loaded, p + mlen, aligned16);
+                const uint32_t s0 = p - md;
+                zmi_wave_order();
+                // byte i of the copy is source byte (i mod md), all of them original
+                if (md >= mlen) {
+                    if (mlen <= 64u) {
+                        if (lane < mlen) ring[(p + lane) & RES_MASK] = ring[(s0 + lane) & RES_MASK];
+                    } else {
+                        uint8_t v5[5];
+#pragma unroll
+                        for (uint32_t k = 0; k < 5u; ++k) {
+                            uint32_t i = lane + 64u * k;
+                            v5[k] = i < mlen ? ring[(s0 + i) & RES_MASK] : (uint8_t)0;
+                        }
+#pragma unroll
+                        for (uint32_t k = 0; k < 5u; ++k) {
+                            uint32_t i = lane + 64u * k;
+                            if (i < mlen) ring[(p + i) & RES_MASK] = v5[k];
+                        }
+                    }
+                } else {
+                    for (uint32_t i = lane; i < mlen; i += 64u) ring[(p + i) & RES_MASK] = ring[(s0 + i % md) & RES_MASK];
+                }
+                zmi_wave_order();
+            }
+        }
+    }
+    if (any) {
+        const uint32_t end = (n_out + 255u) & ~255u, have = loaded < end ? loaded : end;
+        if (have > wb) res_writeback(ring, dst, n_out, wb, have, aligned4);
+    }
+}
+
 // after the checksum kernel: compare trailer values with the checksums of the produced bytes and
 // resolve the internal status codes to zlib's numbering.  detail (optional): 0 none, 1 more input
 // needed, 2 more output space needed.
@@ -686,10 +769,27 @@ __global__ void __launch_bounds__(256) zmi_inflate_verify_kernel(const uint8_t* 
 extern "C" int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n_streams,
                                   uint32_t wrap, uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                                   uint32_t* d_out_len, uint32_t* d_in_used, uint32_t* d_check, int32_t* d_status,
-                                  hipStream_t stream) {
+                                  uint64_t* d_bitmap, uint64_t bitmap_words, uint64_t* d_bm_off, hipStream_t stream) {
     if (n_streams == 0) return 0;
+    ZMI_LAUNCH(zmi_inflate_plan_kernel, dim3(1), dim3(1024), 0, stream, d_out_cap, n_streams, bitmap_words, d_bm_off);
+    ZMI_LAUNCH(zmi_inflate_clear_kernel, dim3(n_streams), dim3(256), 0, stream, d_out_cap, (const uint64_t*)d_bm_off, d_bitmap);
     ZMI_LAUNCH(zmi_inflate_kernel, dim3(n_streams), dim3(64), 0, stream, d_in, d_in_off, d_in_len, wrap, d_out, d_out_off,
-               d_out_cap, d_out_len, d_in_used, d_check, d_status);
+               d_out_cap, d_out_len, d_in_used, d_check, d_status, d_bitmap, (const uint64_t*)d_bm_off);
+    return 0;
+}
+
+extern "C" int zmi_launch_inflate_resolve(uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_len, uint32_t n_streams,
+                                          const uint64_t* d_bitmap, const uint64_t* d_bm_off, hipStream_t stream) {
+    if (n_streams == 0) return 0;
+#ifndef ZMI_EMU
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)zmi_inflate_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_RING);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+#endif
+    ZMI_LAUNCH(zmi_inflate_resolve_kernel, dim3(n_streams), dim3(64), RES_RING, stream, d_out, d_out_off, d_out_len, d_bitmap, d_bm_off);
     return 0;
 }
 

@@ -21,6 +21,7 @@
 extern "C" int zmi_deflate_chain_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                      uint32_t n, uint32_t max_len, int level, int strategy, int finish, void* d_out,
                                      uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_);
+extern "C" int zmi_ctx_set_inflate_out_limit(zmi_ctx* c, uint64_t bytes);
 extern "C" int zmi_inflate_batch_dev_ex(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                         uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                                         uint32_t* d_out_len, int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail,
@@ -180,6 +181,7 @@ int gpu_inflate_stream(const uint8_t* in, size_t n, int wrap, std::vector<uint8_
     uint8_t* m = (uint8_t*)d_meta.p;
     if (hipMemcpy(m, offs, 16, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
     if (hipMemcpy(m + 16, lens, 8, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
+    (void)zmi_ctx_set_inflate_out_limit(c, (uint64_t)cap + 4096u);
     if (zmi_inflate_batch_dev_ex(c, d_in.p, (const uint64_t*)m, (const uint32_t*)(m + 16), 1, wrap, d_out.p,
                                  (const uint64_t*)(m + 8), (const uint32_t*)(m + 20), (uint32_t*)(m + 24), (int32_t*)(m + 28),
                                  (uint32_t*)(m + 32), (int32_t*)(m + 36), nullptr) != 0)

@@ -41,7 +41,7 @@ struct zmi_timer {
     hipEvent_t a, b;
     int kernel;
 };
-enum { ZMI_K_CHECKSUM = 0, ZMI_K_LZ77 = 1, ZMI_K_ENCODE = 2, ZMI_K_INFLATE = 3, ZMI_K_VERIFY = 4, ZMI_K_GEN = 5 };
+enum { ZMI_K_CHECKSUM = 0, ZMI_K_LZ77 = 1, ZMI_K_ENCODE = 2, ZMI_K_INFLATE = 3, ZMI_K_VERIFY = 4, ZMI_K_GEN = 5, ZMI_K_RESOLVE = 6 };
 
 struct zmi_ctx {
     bool timing = false;
@@ -51,7 +51,9 @@ struct zmi_ctx {
     zmi_buf match;    // u32 per position of the current group
     zmi_buf sums;     // adler[n] crc[n]
     zmi_buf pieces;   // per shard x piece compressed length
-    zmi_buf inf_tmp;  // in_used[n] check[n] adler[n] crc[n]
+    zmi_buf inf_tmp;  // in_used[n] check[n] adler[n] crc[n] bm_off[n] (u64)
+    zmi_buf inf_bm;   // inflate: 1 bit per output byte of the batch (where back-references start)
+    uint64_t inflate_out_limit = 0;  // output bytes one inflate batch may cover; 0 = scratch_limit
 };
 
 static int zmi_reserve(zmi_buf& b, size_t bytes) {
@@ -88,6 +90,7 @@ extern "C" int zmi_ctx_destroy(zmi_ctx* c) {
     if (c->sums.p) (void)hipFree(c->sums.p);
     if (c->pieces.p) (void)hipFree(c->pieces.p);
     if (c->inf_tmp.p) (void)hipFree(c->inf_tmp.p);
+    if (c->inf_bm.p) (void)hipFree(c->inf_bm.p);
     delete c;
     return ZMI_E_OK;
 }
@@ -138,6 +141,12 @@ extern "C" int zmi_ctx_get_timing(zmi_ctx* c, double* sums, uint32_t* counts) {
 extern "C" int zmi_ctx_set_scratch_limit(zmi_ctx* c, uint64_t bytes) {
     if (!c || bytes < (64ull << 20)) return zmi_fail(ZMI_E_ARG, "scratch limit must be >= 64 MiB");
     c->scratch_limit = bytes;
+    return ZMI_E_OK;
+}
+
+extern "C" int zmi_ctx_set_inflate_out_limit(zmi_ctx* c, uint64_t bytes) {
+    if (!c) return zmi_fail(ZMI_E_ARG, "null context");
+    c->inflate_out_limit = bytes < (1ull << 20) ? (1ull << 20) : bytes;
     return ZMI_E_OK;
 }
 
@@ -320,17 +329,30 @@ extern "C" int zmi_inflate_batch_dev_ex(zmi_ctx* c, const void* d_in, const uint
     if (n == 0) return ZMI_E_OK;
     hipStream_t stream = (hipStream_t)stream_;
     ZMI_HIP(hipSetDevice(c->device));
-    int rc = zmi_reserve(c->inf_tmp, (size_t)n * 16u);
+    int rc = zmi_reserve(c->inf_tmp, (size_t)n * 24u);
     if (rc) return rc;
-    uint32_t* d_used = (uint32_t*)c->inf_tmp.p;
+    uint64_t* d_bm_off = (uint64_t*)c->inf_tmp.p;
+    uint32_t* d_used = (uint32_t*)(d_bm_off + n);
     uint32_t* d_check = d_used + n;
     uint32_t* d_adler = d_check + n;
     uint32_t* d_crc = d_adler + n;
     if (d_in_used) d_used = d_in_used;
+    // bitmap scratch: 1 bit per byte of output capacity (+2 words per stream).  The capacities live on the
+    // device, so the size comes from the context's limit; streams beyond it report Z_MEM_ERROR.
+    const uint64_t out_limit = c->inflate_out_limit ? c->inflate_out_limit : c->scratch_limit;
+    rc = zmi_reserve(c->inf_bm, (size_t)(out_limit / 8u) + (size_t)n * 16u);
+    if (rc) return rc;
+    const uint64_t bm_words = ((out_limit / 8u) + (uint64_t)n * 16u) / 8u;
     {
         zmi_scope_timer tm(c, ZMI_K_INFLATE, stream);
-        zmi_launch_inflate((const uint8_t*)d_in, d_in_off, d_in_len, n, (uint32_t)wrap, (uint8_t*)d_out, d_out_off, d_out_cap,
-                           d_out_len, d_used, d_check, d_status, stream);
+        int lrc = zmi_launch_inflate((const uint8_t*)d_in, d_in_off, d_in_len, n, (uint32_t)wrap, (uint8_t*)d_out, d_out_off, d_out_cap,
+                                     d_out_len, d_used, d_check, d_status, (uint64_t*)c->inf_bm.p, bm_words, d_bm_off, stream);
+        if (lrc) return zmi_fail(ZMI_E_HIP, "inflate launch setup", (hipError_t)lrc);
+    }
+    {
+        zmi_scope_timer tm(c, ZMI_K_RESOLVE, stream);
+        int lrc = zmi_launch_inflate_resolve((uint8_t*)d_out, d_out_off, d_out_len, n, (const uint64_t*)c->inf_bm.p, d_bm_off, stream);
+        if (lrc) return zmi_fail(ZMI_E_HIP, "inflate resolve launch setup", (hipError_t)lrc);
     }
     if (wrap != ZMI_WRAP_RAW) {
         uint32_t kind = wrap == ZMI_WRAP_ZLIB ? 1u : (wrap == ZMI_WRAP_GZIP ? 2u : 3u);
@@ -421,6 +443,9 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         dooff[i] = tout;
         tout += ((uint64_t)out_cap[i] + 15u) & ~15ull;
     }
+    const uint64_t saved_limit = c->inflate_out_limit;
+    c->inflate_out_limit = tout + (1ull << 20);   // the capacities are known here: size the bitmap scratch exactly
+    struct restore { zmi_ctx* c; uint64_t v; ~restore() { c->inflate_out_limit = v; } } restore_limit{c, saved_limit};
     zmi_dev_alloc A;
     uint8_t* d_in = (uint8_t*)A.get(tin + 16);
     uint8_t* d_out = (uint8_t*)A.get(tout + 16);

@@ -78,6 +78,8 @@ class Engine:
             out_len = torch.empty(n, dtype=torch.int32, device=self.device)
         if status is None:
             status = torch.empty(n, dtype=torch.int32, device=self.device)
+        # inflate keeps 1 bit of scratch per byte of output capacity; the capacities are device data, `out` bounds them
+        _lib.check(self.L.zmi_ctx_set_inflate_out_limit(self._ctx, int(out.numel()) + (1 << 20)), "zmi_ctx_set_inflate_out_limit")
         _lib.check(self.L.zmi_inflate_batch_dev(self._ctx, data.data_ptr(), offsets.data_ptr(), lengths.data_ptr(), n,
                                                 int(wrap), out.data_ptr(), out_offsets.data_ptr(), out_caps.data_ptr(),
                                                 out_len.data_ptr(), status.data_ptr(), _stream_ptr()),
