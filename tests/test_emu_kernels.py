@@ -113,7 +113,9 @@ def test_inflate_long_distances_and_runs(eng, o):
     blobs = [r + r + r[:700],                       # distance 32768, maximal lengths
              bytes(70000),                          # distance 1 runs across many 258-byte copies
              b"ab" * 20000 + b"xyz" * 9000,         # short periods
-             r[:5000] + bytes(300) + r[:5000] + o.gen_shard(3, 1 << 15)]
+             r[:5000] + bytes(300) + r[:5000] + o.gen_shard(3, 1 << 15),
+             # a hole-free stretch longer than the resolve ring between two regions with back-references
+             o.gen_shard(0, 5000) + o.prng_bytes(5, 90000, 1) + o.gen_shard(0, 5000) + r[100:900]]
     for level in (1, 9):
         streams = [zlib.compress(b, level) for b in blobs]
         outs, st = eng.inflate(streams, [len(b) for b in blobs], 1)

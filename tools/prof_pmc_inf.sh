@@ -7,11 +7,11 @@ export PROBE_LEVELS=6 PROBE_S=${PROBE_S:-1024}
 run() { n=$1; shift; mkdir -p $O/pmc_$TAG/$n; rocprofv3 --pmc "$@" -d $O/pmc_$TAG/$n -o p -- python tools/gpu_probe.py > $O/pmc_$TAG/$n.log 2>&1; }
 run a SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS
 run b SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA
-run c SQ_IFETCH SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_INSTS_FLAT SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_EXP_GDS SQ_ACTIVE_INST_MISC
+run c SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_BRANCH SQ_INST_CYCLES_SALU SQ_INSTS_FLAT SQ_ACTIVE_INST_FLAT SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_MISC
 python3 - <<PY
 import sqlite3, glob
 for db in sorted(glob.glob("$O/pmc_$TAG/*/*.db")):
     con=sqlite3.connect(db); cur=con.cursor()
-    for r in cur.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection where kernel_name like '%zmi_inflate_kernel%' group by kernel_name, counter_name"):
+    for r in cur.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection where kernel_name like '%zmi_inflate_kernel%' or kernel_name like '%zmi_inflate_resolve%' group by kernel_name, counter_name"):
         print('%s,%s,%.0f,%d'%(r[0].split('(')[0],r[1],r[2],r[3]))
 PY

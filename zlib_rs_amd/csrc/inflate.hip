@@ -3,7 +3,7 @@
 // Reference semantics being reproduced:
 //   header / trailer state machine   zlib-rs/src/inflate.rs:927-1275,1398-1430,1814-1831
 //   block type, stored, dynamic      zlib-rs/src/inflate.rs:1287-1349,1604-1777
-//   code tables                      zlib-rs/src/inflate/inftrees.rs:42-245 (root 10 / 9 / 7; ENOUGH 1332 + 592,
+//   code tables                      zlib-rs/src/inflate/inftrees.rs:42-245 (root 9 / 8 / 7 here; ENOUGH 852 + 592 there,
 //                                    zlib-rs/src/lib.rs:88-102)
 //   hot loop                         zlib-rs/src/inflate.rs:1918-2158 (inflate_fast_help_impl)
 //   match copy                       zlib-rs/src/inflate/writer.rs:266-300
@@ -21,7 +21,7 @@
 //           leaves a 3-byte record (length, distance) in the first bytes of the hole it will fill and sets a
 //           bit in a per-stream bitmap (1 bit per output byte).  No window is needed, so a wave holds only
 //           its lookup tables and a 1 KiB input chunk in LDS (~10 KiB, 15 streams per CU).
-//   resolve (zmi_inflate_resolve_kernel)  streams the output once through a 64 KiB LDS ring and fills the
+//   resolve (zmi_inflate_resolve_kernel)  streams the output once through a 36 KiB LDS ring and fills the
 //           holes in order; every source lies in the ring (distance <= 32 KiB), so copies are LDS -> LDS.
 // Algorithmic HBM traffic: (1/ratio) B read + 1 B written per output byte; the two-pass split adds one more
 // read and write of the output plus the bitmap (1/8 B per byte).
@@ -33,14 +33,17 @@
 #define ZMI_LENGTH_MISMATCH (-1003)   // gzip: ISIZE wrong                  -> data error either way
 #define ZMI_NEED_OUTPUT (-1006)       // output capacity exhausted          -> Z_BUF_ERROR (detail 2)
 #define INF_CHUNK 1024u
-#define RES_RING 65536u              // resolve pass: output history kept in LDS (power of two, > 32768 + 258 + RES_BLK)
-#define RES_MASK (RES_RING - 1u)
+#define RES_RING 36864u              // resolve pass: output history kept in LDS: 32768 + RES_SPAN + 258 + RES_BLK and slack; a
+                                     // multiple of RES_BLK; with the chunk tables 39.5 KiB per stream, four streams per CU
 #define RES_BLK 1024u                // resolve pass: bytes staged per load step
+#define RES_SPAN 2048u               // resolve pass: output bytes one batch of holes may span
 #define ZMI_NO_SCRATCH (-4)          // Z_MEM_ERROR: the bitmap scratch of the context does not cover this stream
-#define INF_LROOT 10u
-#define INF_DROOT 9u
-#define INF_LSIZE 1344u
-#define INF_DSIZE 592u
+// roots 9 / 8: worst-case table sizes 852 (zlib's ENOUGH_LENS, inftrees.h) and 400 (exhaustive search over all
+// complete 30-symbol codes with the exact-fit sub-tables inf_build makes; root 6 gives zlib's 592)
+#define INF_LROOT 9u
+#define INF_DROOT 8u
+#define INF_LSIZE 852u
+#define INF_DSIZE 400u
 
 // table entry: val << 16 | op << 8 | bits
 #define INF_OP_LIT 0x00u
@@ -489,12 +492,31 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                 uint32_t pos = 0, w;
                 uint64_t M = 0;
                 int32_t rst = ZMI_OK;
+#ifdef ZMI_EMU
                 do {
                     w = zmi_readlane(tw, pos);
                     if (w > 63u) break;
                     M |= 1ull << pos;
                     pos += w;
                 } while (pos < 64u);
+#else
+                // six scalar instructions and one lane read per token (the compiler's version of the loop
+                // above needs twelve and a third branch); `pos` is written by SALU only, so the lane select
+                // of v_readlane has no VALU->SGPR hazard
+                asm volatile(
+                    "1:\n\t"
+                    "v_readlane_b32 %[w], %[tw], %[pos]\n\t"
+                    "s_cmp_gt_u32 %[w], 63\n\t"
+                    "s_cbranch_scc1 2f\n\t"
+                    "s_bitset1_b64 %[M], %[pos]\n\t"
+                    "s_add_u32 %[pos], %[pos], %[w]\n\t"
+                    "s_cmp_lt_u32 %[pos], 64\n\t"
+                    "s_cbranch_scc1 1b\n\t"
+                    "2:"
+                    : [w] "=&s"(w), [pos] "+s"(pos), [M] "+s"(M)
+                    : [tw] "v"(tw)
+                    : "scc");
+#endif
                 if (pos < 64u) {
                     if (w & 64u) { M |= 1ull << pos; pos += w & 63u; eob = true; }
                     else rst = (w & 128u) ? ZMI_BUF_ERROR : ZMI_DATA_ERROR;
@@ -623,33 +645,58 @@ __global__ void __launch_bounds__(256) zmi_inflate_clear_kernel(const uint32_t* 
 // ring[x & RES_MASK] holds output byte x for x in [loaded - RES_RING, loaded).  Lines are staged from HBM
 // strictly in order (they carry the literals and the 3-byte records the decode pass left in the holes),
 // a hole is filled from the ring, and lines that can no longer change are streamed back.
-static __device__ __forceinline__ void res_stage(uint8_t* ring, const uint8_t* dst, uint32_t n_out, uint32_t& loaded, uint32_t upto,
-                                                 bool aligned16) {
-    const uint32_t lane = zmi_lane();
-    if (upto > loaded + RES_RING - 2048u) loaded = (upto - 32768u - 2u * RES_BLK) & ~(RES_BLK - 1u);   // a long stretch without holes: only the window matters
-    while (loaded < upto) {
-        const uint32_t so = loaded + 16u * lane;
-        uint4 q;
-        q.x = q.y = q.z = q.w = 0u;
-        if (aligned16 && so + 16u <= n_out) q = *(const uint4*)(dst + so);
-        else if (so < n_out) {
-            uint32_t w[4] = {0u, 0u, 0u, 0u};
-            for (uint32_t j = 0; j < 16u; ++j)
-                if (so + j < n_out) w[j >> 2] |= (uint32_t)dst[so + j] << (8u * (j & 3u));
-            q.x = w[0]; q.y = w[1]; q.z = w[2]; q.w = w[3];
-        }
-        *(uint4*)(ring + (so & RES_MASK)) = q;
-        loaded += RES_BLK;
+// ring index of output byte x; rb = start of the ring lap the load frontier is in (x within one lap of it)
+static __device__ __forceinline__ uint32_t res_ri(uint32_t x, uint32_t rb) {
+    int32_t i = (int32_t)(x - rb);
+    i -= i >= (int32_t)RES_RING ? (int32_t)RES_RING : 0;
+    i += i < 0 ? (int32_t)RES_RING : 0;
+    return (uint32_t)i;
+}
+static __device__ __forceinline__ uint32_t res_inc(uint32_t i, uint32_t d) {
+    i += d;
+    return i >= RES_RING ? i - RES_RING : i;
+}
+static __device__ __forceinline__ uint4 res_fetch(const uint8_t* dst, uint32_t n_out, uint32_t at, bool aligned16) {
+    const uint32_t so = at + 16u * zmi_lane();
+    uint4 q;
+    q.x = q.y = q.z = q.w = 0u;
+    if (aligned16 && so + 16u <= n_out) q = *(const uint4*)(dst + so);
+    else if (so < n_out) {
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        for (uint32_t j = 0; j < 16u; ++j)
+            if (so + j < n_out) w[j >> 2] |= (uint32_t)dst[so + j] << (8u * (j & 3u));
+        q.x = w[0]; q.y = w[1]; q.z = w[2]; q.w = w[3];
     }
+    return q;
+}
+// `pre` holds block [loaded, loaded + RES_BLK) when `have` is set: the load of the next block is always in
+// flight while the holes of the current one are filled
+static __device__ __forceinline__ void res_stage(uint8_t* ring, const uint8_t* dst, uint32_t n_out, uint32_t& loaded, uint32_t upto,
+                                                 bool aligned16, uint4& pre, bool& have, uint32_t& rb) {
+    const uint32_t lane = zmi_lane();
+    zmi_wave_order();   // ring reads issued so far (write-back of final lines) stay in front of the stores below
+    if (upto > loaded + RES_RING - 2048u) {   // a long stretch without holes: only the window matters
+        loaded = (upto - 32768u - 2u * RES_BLK) & ~(RES_BLK - 1u);
+        have = false;
+    }
+    while (loaded < upto) {
+        if (!have) pre = res_fetch(dst, n_out, loaded, aligned16);
+        rb = (loaded / RES_RING) * RES_RING;
+        *(uint4*)(ring + (loaded - rb) + 16u * lane) = pre;   // RES_RING is a multiple of RES_BLK: a block never wraps
+        loaded += RES_BLK;
+        pre = res_fetch(dst, n_out, loaded, aligned16);
+        have = true;
+    }
+    rb = (loaded / RES_RING) * RES_RING;
     zmi_wave_order();
 }
 static __device__ __forceinline__ void res_writeback(const uint8_t* ring, uint8_t* dst, uint32_t n_out, uint32_t from, uint32_t upto,
-                                                     bool aligned4) {
+                                                     bool aligned4, uint32_t rb) {
     const uint32_t lane = zmi_lane();
     zmi_wave_order();
     for (uint32_t c = from; c < upto; c += 256u) {
         const uint32_t o = c + 4u * lane;
-        const uint32_t w = *(const uint32_t*)(ring + (o & RES_MASK));
+        const uint32_t w = *(const uint32_t*)(ring + res_ri(o, rb));
         if (aligned4 && o + 4u <= n_out) *(uint32_t*)(dst + o) = w;
         else
             for (uint32_t j = 0; j < 4u; ++j)
@@ -657,11 +704,25 @@ static __device__ __forceinline__ void res_writeback(const uint8_t* ring, uint8_
     }
 }
 
+// One chunk = 64 bitmap words = 4096 output bytes.  Its holes are listed in LDS and taken 64 at a time, one
+// hole per lane.  A hole may be filled once every earlier hole that starts below the end of its source is
+// done; `need` is that count, found by ranking the source end in the chunk's bitmap.  Short, non-overlapping
+// holes that are ready are filled together (lane-per-hole, 16 bytes per step); self-overlapping ones are
+// filled by the whole wave when they are the first unfinished hole.  Text-like data finishes a batch in 3-5 steps.
+#define RES_SHORT 16u
+struct ResChunk {
+    uint64_t cw[64];       // bitmap words of the chunk
+    uint32_t cex[64];      // holes in the chunk before word w
+    uint16_t list[1408];   // hole positions relative to the chunk (a hole is >= 3 bytes: <= 22 per word)
+};
+
 __global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, const uint64_t* __restrict__ out_off,
                                                                  const uint32_t* __restrict__ out_len,
                                                                  const uint64_t* __restrict__ bitmap,
                                                                  const uint64_t* __restrict__ bm_off) {
-    ZMI_DYN_SMEM(ring);
+    ZMI_DYN_SMEM(smem);
+    uint8_t* ring = smem;
+    ResChunk* C = (ResChunk*)(smem + RES_RING);
     const uint32_t lane = zmi_lane();
     const uint32_t s = blockIdx.x;
     const uint64_t bmo = bm_off[s];
@@ -672,68 +733,143 @@ __global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, c
     uint8_t* dst = out + out_off[s];
     const bool aligned16 = ((uintptr_t)dst & 15u) == 0u, aligned4 = ((uintptr_t)dst & 3u) == 0u;
 
-    uint32_t loaded = 0, wb = 0;
-    bool any = false;
+    uint32_t loaded = 0, wb = 0, rb = 0;
+    bool any = false, have = false;
+    uint4 pre;
+    pre.x = pre.y = pre.z = pre.w = 0u;
     for (uint32_t cbase = 0; cbase < nwords; cbase += 64u) {
         const uint32_t idx = cbase + lane;
         const uint64_t v = idx < nwords ? bm[idx] : 0ull;
-        const uint32_t vlo = (uint32_t)v, vhi = (uint32_t)(v >> 32);
-        uint64_t nz = __ballot(v != 0ull);
-        while (nz) {
-            const uint32_t j = (uint32_t)__ffsll((unsigned long long)nz) - 1u;
-            nz &= nz - 1ull;
-            uint64_t bits = (uint64_t)zmi_readlane(vlo, j) | ((uint64_t)zmi_readlane(vhi, j) << 32);
-            const uint32_t wbase = (cbase + j) << 6;
+        const uint32_t pc = (uint32_t)__popcll(v);
+        const uint32_t incl = zmi_wave_incl_scan(pc);
+        const uint32_t total = zmi_readlane(incl, 63u);
+        if (total == 0u) continue;
+        const uint32_t chunk0 = cbase << 6;
+        zmi_wave_order();
+        C->cw[lane] = v;
+        C->cex[lane] = incl - pc;
+        {
+            uint64_t t = v;
+            uint32_t k = incl - pc;
+            while (t) {
+                C->list[k++] = (uint16_t)(lane * 64u + (uint32_t)__ffsll((unsigned long long)t) - 1u);
+                t &= t - 1ull;
+            }
+        }
+        zmi_wave_order();
+        for (uint32_t b0 = 0, nb = 0; b0 < total; b0 += nb) {
+            const uint32_t cand = total - b0 < 64u ? total - b0 : 64u;
+            const uint32_t rel = lane < cand ? C->list[b0 + lane] : 0u;
+            // the batch ends where the holes (sorted) get further than RES_SPAN from its first one
+            const uint32_t rel0 = zmi_readlane(rel, 0u);
+            nb = (uint32_t)__popcll(__ballot(lane < cand && rel - rel0 <= RES_SPAN));
+            const bool active = lane < nb;
+            const uint32_t p = chunk0 + rel;
+            const uint32_t p_first = chunk0 + rel0, p_last = chunk0 + zmi_readlane(rel, nb - 1u);
             if (!any) {
                 // first hole of the stream: everything in front of it is final already; start one window back
                 any = true;
-                loaded = wbase > 32768u ? (wbase - 32768u) & ~(RES_BLK - 1u) : 0u;
-                wb = wbase & ~255u;
+                loaded = p_first > 32768u ? (p_first - 32768u) & ~(RES_BLK - 1u) : 0u;
+                wb = p_first & ~255u;
             }
-            // lines in front of this word can no longer change
-            {
-                const uint32_t fin = wbase & ~255u, have = loaded < fin ? loaded : fin;
-                if (have > wb) res_writeback(ring, dst, n_out, wb, have, aligned4);
+            {   // lines in front of this batch can no longer change
+                const uint32_t fin = p_first & ~255u, upto = loaded < fin ? loaded : fin;
+                if (upto > wb) res_writeback(ring, dst, n_out, wb, upto, aligned4, rb);
                 if (fin > wb) wb = fin;
             }
-            while (bits) {
-                const uint32_t p = wbase + (uint32_t)__ffsll((unsigned long long)bits) - 1u;
-                bits &= bits - 1ull;
-                if (p + 3u > loaded) res_stage(ring, dst, n_out, loaded, p + 3u, aligned16);
-                const uint32_t a = p & RES_MASK;
-                const uint32_t r0 = *(const uint32_t*)(ring + (a & ~3u)), r1 = *(const uint32_t*)(ring + ((a + 4u) & RES_MASK & ~3u));
-                const uint32_t rec = zmi_uniform(__builtin_amdgcn_alignbyte(r1, r0, a & 3u)) & 0xFFFFFFu;
-                const uint32_t mlen = (rec >> 15) + 3u, md = (rec & 0x7FFFu) + 1u;
-                if (p + mlen > loaded) res_stage(ring, dst, n_out, loaded, p + mlen, aligned16);
-                const uint32_t s0 = p - md;
-                zmi_wave_order();
-                // byte i of the copy is source byte (i mod md), all of them original
-                if (md >= mlen) {
-                    if (mlen <= 64u) {
-                        if (lane < mlen) ring[(p + lane) & RES_MASK] = ring[(s0 + lane) & RES_MASK];
-                    } else {
+            if (p_last + 3u > loaded) res_stage(ring, dst, n_out, loaded, p_last + 3u, aligned16, pre, have, rb);
+            uint32_t rec = 0;
+            if (active) {
+                const uint32_t a = res_ri(p, rb);
+                const uint32_t r0 = *(const uint32_t*)(ring + (a & ~3u)), r1 = *(const uint32_t*)(ring + res_inc(a & ~3u, 4u));
+                rec = __builtin_amdgcn_alignbyte(r1, r0, a & 3u) & 0xFFFFFFu;
+            }
+            const uint32_t mlen = (rec >> 15) + 3u, md = (rec & 0x7FFFu) + 1u;
+            const uint32_t last_end = p_last + zmi_readlane(mlen, nb - 1u);
+            if (last_end > loaded) res_stage(ring, dst, n_out, loaded, last_end, aligned16, pre, have, rb);
+            const uint32_t s0 = p - md;
+            const uint32_t e = s0 + (mlen < md ? mlen : md);   // end of the bytes this hole reads
+            uint32_t need = 0;                                  // holes of this batch that must be finished first
+            if (active && e > p_first) {
+                const uint32_t er = e - chunk0;                 // chunk0 <= p_first < e <= p
+                const uint64_t below = C->cw[er >> 6] & ((1ull << (er & 63u)) - 1ull);
+                need = C->cex[er >> 6] + (uint32_t)__popcll(below) - b0;
+            }
+            const bool coop = md < mlen;   // a hole that reads its own output goes through the whole-wave path
+            const uint32_t mpack = mlen | (md << 16);
+            uint64_t done = nb == 64u ? 0ull : ~0ull << nb;
+            zmi_wave_order();
+            while (~done) {
+                const uint32_t D = (uint32_t)__ffsll((unsigned long long)~done) - 1u;   // first unfinished hole
+                const uint64_t R = __ballot(active && !((done >> lane) & 1ull) && !coop && need <= D);
+                if ((R >> D) & 1ull) {
+                    // lane-per-hole, RES_SHORT bytes per step: sources are final and disjoint from every destination
+                    const bool mine = (R >> lane) & 1ull;
+                    const uint32_t lim = mine ? mlen : 0u;
+                    for (uint32_t base = 0; __ballot(base < lim); base += RES_SHORT) {
+                        uint32_t w[4] = {0u, 0u, 0u, 0u};
+                        if (base < lim) {
+                            const uint32_t a = res_ri(s0 + base, rb), a4 = a & ~3u, sh = a & 3u;
+                            uint32_t q0, q1, q2, q3, q4;
+                            if (a4 + 20u <= RES_RING) {
+                                const uint32_t* q = (const uint32_t*)(ring + a4);
+                                q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; q4 = q[4];
+                            } else {   // the 20 bytes wrap around the end of the ring
+                                q0 = *(const uint32_t*)(ring + a4);
+                                q1 = *(const uint32_t*)(ring + res_inc(a4, 4u));
+                                q2 = *(const uint32_t*)(ring + res_inc(a4, 8u));
+                                q3 = *(const uint32_t*)(ring + res_inc(a4, 12u));
+                                q4 = *(const uint32_t*)(ring + res_inc(a4, 16u));
+                            }
+                            w[0] = __builtin_amdgcn_alignbyte(q1, q0, sh);
+                            w[1] = __builtin_amdgcn_alignbyte(q2, q1, sh);
+                            w[2] = __builtin_amdgcn_alignbyte(q3, q2, sh);
+                            w[3] = __builtin_amdgcn_alignbyte(q4, q3, sh);
+                        }
+                        const uint32_t left = base < lim ? lim - base : 0u;
+                        const uint32_t ip = res_ri(p + base, rb);
+                        if (ip + RES_SHORT <= RES_RING) {
+#pragma unroll
+                            for (uint32_t j = 0; j < RES_SHORT; ++j)
+                                if (j < left) ring[ip + j] = (uint8_t)(w[j >> 2] >> (8u * (j & 3u)));
+                        } else {
+#pragma unroll
+                            for (uint32_t j = 0; j < RES_SHORT; ++j)
+                                if (j < left) ring[res_inc(ip, j)] = (uint8_t)(w[j >> 2] >> (8u * (j & 3u)));
+                        }
+                    }
+                    done |= R;
+                } else {
+                    // the first unfinished hole is long or overlaps itself: the whole wave fills it
+                    const uint32_t mp = zmi_readlane(mpack, D);
+                    const uint32_t cl = mp & 0xFFFFu, cd = mp >> 16;
+                    const uint32_t cp = chunk0 + zmi_readlane(rel, D);
+                    const uint32_t cs = cp - cd;
+                    // byte i of the copy is source byte (i mod cd), all of them original
+                    if (cd >= cl) {
                         uint8_t v5[5];
 #pragma unroll
                         for (uint32_t k = 0; k < 5u; ++k) {
                             uint32_t i = lane + 64u * k;
-                            v5[k] = i < mlen ? ring[(s0 + i) & RES_MASK] : (uint8_t)0;
+                            v5[k] = i < cl ? ring[res_ri(cs + i, rb)] : (uint8_t)0;
                         }
 #pragma unroll
                         for (uint32_t k = 0; k < 5u; ++k) {
                             uint32_t i = lane + 64u * k;
-                            if (i < mlen) ring[(p + i) & RES_MASK] = v5[k];
+                            if (i < cl) ring[res_ri(cp + i, rb)] = v5[k];
                         }
+                    } else {
+                        for (uint32_t i = lane; i < cl; i += 64u) ring[res_ri(cp + i, rb)] = ring[res_ri(cs + i % cd, rb)];
                     }
-                } else {
-                    for (uint32_t i = lane; i < mlen; i += 64u) ring[(p + i) & RES_MASK] = ring[(s0 + i % md) & RES_MASK];
+                    done |= 1ull << D;
                 }
                 zmi_wave_order();
             }
         }
     }
     if (any) {
-        const uint32_t end = (n_out + 255u) & ~255u, have = loaded < end ? loaded : end;
-        if (have > wb) res_writeback(ring, dst, n_out, wb, have, aligned4);
+        const uint32_t end = (n_out + 255u) & ~255u, upto = loaded < end ? loaded : end;
+        if (upto > wb) res_writeback(ring, dst, n_out, wb, upto, aligned4, rb);
     }
 }
 
@@ -784,12 +920,12 @@ extern "C" int zmi_launch_inflate_resolve(uint8_t* d_out, const uint64_t* d_out_
 #ifndef ZMI_EMU
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)zmi_inflate_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_RING);
+        hipError_t e = hipFuncSetAttribute((const void*)zmi_inflate_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(RES_RING + sizeof(ResChunk)));
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
 #endif
-    ZMI_LAUNCH(zmi_inflate_resolve_kernel, dim3(n_streams), dim3(64), RES_RING, stream, d_out, d_out_off, d_out_len, d_bitmap, d_bm_off);
+    ZMI_LAUNCH(zmi_inflate_resolve_kernel, dim3(n_streams), dim3(64), RES_RING + sizeof(ResChunk), stream, d_out, d_out_off, d_out_len, d_bitmap, d_bm_off);
     return 0;
 }
 
