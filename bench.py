@@ -80,6 +80,10 @@ def main():
     ap.add_argument("--shard-bytes", type=int, default=1 << 20)
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--verify", type=int, default=64, help="shards checked on the host with the oracle after timing")
+    ap.add_argument("--inflate-streams", type=int, default=4096,
+                    help="streams of the step's own output inflated on the GPU afterwards (BASELINE.json configs[3]: 4096 x 1 MiB)")
+    ap.add_argument("--scratch-gib", type=float, default=float(os.environ.get("ZMI_BENCH_SCRATCH_GIB", 34)),
+                    help="device scratch of the engine (4 B per input byte of one launch group): 34 GiB = 8192 shards per launch")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -94,7 +98,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
-    e = Engine(local)
+    e = Engine(local, scratch_bytes=int(args.scratch_gib * GIB))
     S, B = args.shards, args.shard_bytes
     first = rank * S
 
@@ -152,15 +156,31 @@ def main():
             comp = bytes(out[i, :int(hl[i])].cpu().numpy())
             rc, back, _, msg = o.inflate(comp, B, 1)
             assert rc == 1 and back == o.gen_shard(first + i, B), "round trip failed for shard %d: rc=%d %s" % (i, rc, msg)
-    # on-device round trip of a slice with the GPU inflater
-    nv = min(S, 1024)
+    # on-device round trip with the GPU inflater: the compressed shards of the step, back to their input (bit-exact);
+    # timed separately (second pass), reported in the "inflate" object -- it is not part of `value`
+    nv = max(1, min(S, args.inflate_streams))
     back = torch.empty(nv * B, dtype=torch.uint8, device=dev)
     cap = torch.full((nv,), B, dtype=torch.int32, device=dev)
     ooff = torch.arange(nv, dtype=torch.int64, device=dev) * B
     coff = torch.arange(nv, dtype=torch.int64, device=dev) * out.stride(0)
-    blen, bst = e.inflate_batch(out, coff, olen[:nv].contiguous(), back, ooff, cap, wrap=WRAP_ZLIB)
+    olen_v = olen[:nv].contiguous()
+    blen, bst = e.inflate_batch(out, coff, olen_v, back, ooff, cap, wrap=WRAP_ZLIB)
     torch.cuda.synchronize()
     assert int((bst != 0).sum().item()) == 0 and torch.equal(back, data[:nv * B]), "device round trip failed"
+    e.L.zmi_ctx_set_timing(e._ctx, 1)
+    torch.cuda.synchronize()
+    ti = time.perf_counter()
+    e.inflate_batch(out, coff, olen_v, back, ooff, cap, wrap=WRAP_ZLIB, out_len=blen, status=bst)
+    torch.cuda.synchronize()
+    inf_s = time.perf_counter() - ti
+    isums = (C.c_double * 8)()
+    icnts = (C.c_uint32 * 8)()
+    e.L.zmi_ctx_get_timing(e._ctx, isums, icnts)
+    e.L.zmi_ctx_set_timing(e._ctx, 0)
+    inflate_obj = {"streams": nv, "stream_bytes": B, "value": nv * B / GIB / inf_s, "unit": "GiB/s of output", "ms": inf_s * 1e3,
+                   "kernel_ms": {"decode": isums[3], "resolve": isums[6], "checksum": isums[0], "verify": isums[4]},
+                   "input": "the step's own level-%d zlib streams, output compared bit-exactly with the shards" % args.level}
+    del back
 
     if rank == 0:
         value = raw_total * args.steps / GIB / elapsed
@@ -191,6 +211,7 @@ def main():
                          "read_only_frac": value * GIB / 1e9 / HBM_PEAK_GBS,
                          "kernel_ms": {"checksum": sums[0] / max(1, cnts[0]), "lz77": lz_ms, "encode": sums[2] / max(1, cnts[2])},
                          "launches_per_step": int(launches_per_step)},
+            "inflate": inflate_obj,
         }
         if world == 1 and not args.no_cpu:
             cb = cpu_baseline(B, args.level)

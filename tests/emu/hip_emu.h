@@ -212,6 +212,7 @@ inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh)
     uint64_t v = ((uint64_t)hi << 32) | lo;
     return (unsigned)(v >> (sh & 31));
 }
+inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __ffsll(uint64_t v) { return __builtin_ffsll((long long)v); }

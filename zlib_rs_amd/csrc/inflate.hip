@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
     __shared__ InfShared Sh;
     InfShared* S = &Sh;
     const uint32_t lane = zmi_lane();
-    const uint32_t s = blockIdx.x;
+    const uint32_t s = zmi_xcd_spread(blockIdx.x, gridDim.x);
     InfBits B;
     B.src = in + in_off[s];
     B.n = in_len[s];
@@ -449,42 +449,43 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                 const uint64_t left = Pend - P;   // input bits from P to the end of the stream
                 const int32_t rem = (int32_t)(left > 0x40000000ull ? 0x40000000u : (uint32_t)left) - (int32_t)lane;
 
-                // literal / length code
+                // literal / length code, then (speculatively, for every lane) the distance code behind it.
+                // Branch-free apart from the second-level lookups: selects cost two VALU instructions, a
+                // divergent branch costs exec-mask bookkeeping on the scalar unit, which is the busier one.
                 uint32_t e = S->ltab[lo & ((1u << INF_LROOT) - 1u)];
                 if ((e >> 8) & INF_OP_LINK) {
                     uint32_t sb = (e >> 8) & 0x0Fu;
                     e = S->ltab[(e >> 16) + ((lo >> INF_LROOT) & ((1u << sb) - 1u))];
                 }
                 const uint32_t bits = e & 0xFFu, op = (e >> 8) & 0xFFu;
-                uint32_t t = bits;          // token length in bits
-                uint32_t kind = 0;          // 0 literal, 1 back-reference, 2 end of block
-                uint32_t err = 0;           // 1: more input needed, 2: invalid data
-                uint32_t val = e >> 16;     // literal byte | match length
-                uint32_t dist = 0;
-                if (op == INF_OP_BAD || bits == 0u) err = rem < 15 ? 1u : 2u;   // "invalid literal/length code"
-                else if ((int32_t)bits > rem) err = 1u;
-                else if (op == INF_OP_EOB) kind = 2u;
-                else if (op != INF_OP_LIT) {
-                    const uint32_t xb = op & 0x0Fu;
-                    const uint32_t used = bits + xb;   // <= 20
-                    val += (lo >> bits) & ((1u << xb) - 1u);
+                const bool bad = op == INF_OP_BAD || bits == 0u;                  // "invalid literal/length code"
+                const bool is_eob = op == INF_OP_EOB;
+                const bool is_len = (op & INF_OP_BASE) != 0u;
+                const uint32_t xb = is_len ? (op & 0x0Fu) : 0u;
+                const uint32_t used = bits + xb;                                    // <= 20
+                const uint32_t val = (e >> 16) + ((lo >> bits) & ((1u << xb) - 1u));   // literal byte | match length
+                // distance code: skipped by a scalar branch when no lane holds a length code (literal-only data)
+                uint32_t dist = 0, dlen = 0;
+                bool dbad = false;
+                if (__ballot(is_len)) {
                     const uint32_t rest = __builtin_amdgcn_alignbit(hi, lo, used);
                     uint32_t d = S->dtab[rest & ((1u << INF_DROOT) - 1u)];
-                    if ((d >> 8) & INF_OP_LINK) {
+                    if (is_len && ((d >> 8) & INF_OP_LINK)) {
                         uint32_t sb = (d >> 8) & 0x0Fu;
                         d = S->dtab[(d >> 16) + ((rest >> INF_DROOT) & ((1u << sb) - 1u))];
                     }
                     const uint32_t dbits = d & 0xFFu, dop = (d >> 8) & 0xFFu;
-                    kind = 1u;
-                    if ((int32_t)used > rem) err = 1u;
-                    else if (dop == INF_OP_BAD || dbits == 0u || !(dop & INF_OP_BASE)) err = (rem - (int32_t)used) < 15 ? 1u : 2u;   // "invalid distance code"
-                    else {
-                        const uint32_t dxb = dop & 0x0Fu;
-                        dist = (d >> 16) + ((rest >> dbits) & ((1u << dxb) - 1u));
-                        t = used + dbits + dxb;   // <= 48
-                        if ((int32_t)t > rem) err = 1u;
-                    }
+                    dbad = dop == INF_OP_BAD || dbits == 0u || !(dop & INF_OP_BASE);   // "invalid distance code"
+                    const uint32_t dxb = dop & 0x0Fu;
+                    dist = (d >> 16) + ((rest >> dbits) & ((1u << dxb) - 1u));
+                    dlen = dbits + dxb;
                 }
+                const uint32_t t = is_len ? used + dlen : bits;             // token length in bits, <= 48
+                const uint32_t kind = is_len ? 1u : (is_eob ? 2u : 0u);            // 0 literal, 1 back-reference, 2 end of block
+                // 1: more input needed, 2: invalid data (the reference decides by the bits that are left)
+                const uint32_t err_len = (int32_t)used > rem ? 1u
+                                         : (dbad ? ((rem - (int32_t)used) < 15 ? 1u : 2u) : ((int32_t)t > rem ? 1u : 0u));
+                const uint32_t err = bad ? (rem < 15 ? 1u : 2u) : ((int32_t)bits > rem ? 1u : (is_len ? err_len : 0u));
                 // bits 0-5 token length; anything above 63 stops the walk: 64 = end of block, 128 / 256 = error
                 const uint32_t tw = err ? (err << 7) : (t | (kind == 2u ? 64u : 0u));
 
@@ -724,7 +725,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, c
     uint8_t* ring = smem;
     ResChunk* C = (ResChunk*)(smem + RES_RING);
     const uint32_t lane = zmi_lane();
-    const uint32_t s = blockIdx.x;
+    const uint32_t s = zmi_xcd_spread(blockIdx.x, gridDim.x);
     const uint64_t bmo = bm_off[s];
     const uint32_t n_out = out_len[s];
     if (bmo == ~0ull || n_out == 0u) return;

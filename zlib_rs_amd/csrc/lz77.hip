@@ -112,24 +112,39 @@ static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_
         if (H6) {
             uint32_t lo, hi;
             lz_ring64(win, p, lo, hi);
-            uint64_t x = ((uint64_t)(hi & 0xFFFFu) << 32) | lo;
-            hv[s] = (uint32_t)((x * 0x9E3779B185EBCA87ull) >> (64 - LZ_HBITS));
-            h4[s] = (lo * 2654435761u) >> (32 - LZ_H4BITS);
+            // full-rate 24 x 24 bit multiplies (v_mul_u32_u24) instead of the quarter-rate 32-bit ones a 64-bit
+            // multiplicative hash needs: bytes 0-2, 3-5 (and byte 3 alone for the 4-byte hash) are scrambled
+            // separately and summed; the top bits of the sum depend on every input bit
+            const uint32_t a = lo & 0xFFFFFFu, b = (lo >> 24) | ((hi & 0xFFFFu) << 8);
+            const uint32_t ma = __umul24(a, 0x9E3779u);
+            hv[s] = (ma + __umul24(b, 0x85EBCBu)) >> (32 - LZ_HBITS);
+            h4[s] = (ma + __umul24(lo >> 24, 0xC2B2AFu)) >> (32 - LZ_H4BITS);
         } else {
             uint32_t v = lz_ring32(win, p);
             hv[s] = (v * 2654435761u) >> (32 - LZ_HBITS);  // multiplier as hash_calc.rs:30-33
             h4[s] = 0;
         }
     }
+    if ((tile + 1u) * LZ_T + 6u <= n) {
+        // every position of the tile has its 6 bytes: no per-lane bounds checks (all tiles but the last)
 #pragma unroll
-    for (uint32_t s = 0; s < LZ_SUB; ++s) {
-        uint32_t p = tile * LZ_T + s * 64u + lane;
-        uint32_t old = 0, old4 = 0;
-        if (p + (H6 ? 6u : 4u) <= n) old = atomicMax(&head[hv[s]], p + 1u);
-        if (H6 && p + 4u <= n) old4 = atomicMax(&head4[h4[s]], p + 1u);
-        hv[s] = old;
-        h4[s] = old4;
-        zmi_wave_sync();  // steps are position-ordered (no-op on hardware: one wave, in-order LDS)
+        for (uint32_t s = 0; s < LZ_SUB; ++s) {
+            uint32_t p = tile * LZ_T + s * 64u + lane;
+            hv[s] = atomicMax(&head[hv[s]], p + 1u);
+            if (H6) h4[s] = atomicMax(&head4[h4[s]], p + 1u);
+            zmi_wave_sync();  // steps are position-ordered (no-op on hardware: one wave, in-order LDS)
+        }
+    } else {
+#pragma unroll
+        for (uint32_t s = 0; s < LZ_SUB; ++s) {
+            uint32_t p = tile * LZ_T + s * 64u + lane;
+            uint32_t old = 0, old4 = 0;
+            if (p + (H6 ? 6u : 4u) <= n) old = atomicMax(&head[hv[s]], p + 1u);
+            if (H6 && p + 4u <= n) old4 = atomicMax(&head4[h4[s]], p + 1u);
+            hv[s] = old;
+            h4[s] = old4;
+            zmi_wave_sync();
+        }
     }
 #pragma unroll
     for (uint32_t s = 0; s < LZ_SUB; ++s) {
@@ -167,10 +182,11 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
     const uint32_t t = threadIdx.x;
     const uint32_t lane = zmi_lane();
     const uint32_t wave = zmi_wave();
-    const uint32_t s = first_shard + blockIdx.x;
+    const uint32_t local = zmi_xcd_spread(blockIdx.x, gridDim.x);
+    const uint32_t s = first_shard + local;
     const uint8_t* src = data + off[s];
     const uint32_t n = len[s];
-    uint32_t* mout = match + (uint64_t)blockIdx.x * match_stride;
+    uint32_t* mout = match + (uint64_t)local * match_stride;
     const bool aligned = (((uintptr_t)src) & 15u) == 0;
     const uint32_t ntiles = (n + LZ_T - 1u) / LZ_T;
     if (ntiles == 0) return;
@@ -183,6 +199,11 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
 
     if (wave == 0) {
         // ---------------- producer ----------------
+        // The whole workgroup waits on this one wave and it shares its SIMD with three searcher waves:
+        // raise its issue priority so the arbiter serves it first.
+#ifndef ZMI_EMU
+        __builtin_amdgcn_s_setprio(3);
+#endif
         // The HBM load of the chunk needed NEXT round is issued at the top of the round and consumed
         // at the top of the following one, so its latency hides behind the throttle wait and the
         // hash inserts of the current tile.

@@ -50,6 +50,15 @@ static __device__ __forceinline__ uint32_t zmi_readlane(uint32_t v, uint32_t k) 
 }
 #endif
 
+// Workgroup -> work item.  The dispatcher deals consecutive workgroups round-robin over the 8 XCDs, so with
+// one workgroup per shard XCD x would get exactly the shards with index = x (mod 8) -- and any cost pattern of
+// period 8 in the batch (the benchmark's eight data classes are one) would load the XCDs unevenly while the
+// launch waits for the slowest.  Rotating the assignment inside every group of eight gives each XCD every
+// residue in turn and keeps neighbouring shards on neighbouring workgroups.  n = items in the launch.
+static __device__ __forceinline__ unsigned zmi_xcd_spread(unsigned b, unsigned n) {
+    return b < (n & ~7u) ? ((b & ~7u) | ((b + (b >> 3)) & 7u)) : b;
+}
+
 static __device__ __forceinline__ unsigned zmi_lane() { return threadIdx.x & 63u; }
 static __device__ __forceinline__ unsigned zmi_wave() { return threadIdx.x >> 6; }
 
