@@ -339,7 +339,10 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                     chain = chain ? chain - 1u : 0u;
                     if (stop || dn == 0u || chain == 0u || p - cand > prm.max_dist) break;
                 }
-                if (blen >= 4u) res |= (blen << 8) | ((bdist - 1u) << 17);
+                // the shortest matches are not worth a far distance: their length + distance codes cost more
+                // bits than the literals they replace
+                const bool too_far = (blen == 4u && bdist > prm.far4) || (blen == 5u && bdist > prm.far5);
+                if (blen >= 4u && !too_far) res |= (blen << 8) | ((bdist - 1u) << 17);
             }
             mout[p] = res;
         }
