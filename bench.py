@@ -82,8 +82,8 @@ def main():
     ap.add_argument("--verify", type=int, default=64, help="shards checked on the host with the oracle after timing")
     ap.add_argument("--inflate-streams", type=int, default=4096,
                     help="streams of the step's own output inflated on the GPU afterwards (BASELINE.json configs[3]: 4096 x 1 MiB)")
-    ap.add_argument("--scratch-gib", type=float, default=float(os.environ.get("ZMI_BENCH_SCRATCH_GIB", 34)),
-                    help="device scratch of the engine (4 B per input byte of one launch group): 34 GiB = 8192 shards per launch")
+    ap.add_argument("--scratch-gib", type=float, default=float(os.environ.get("ZMI_BENCH_SCRATCH_GIB", 70)),
+                    help="device scratch of the engine (4 B per input byte of one launch group): 70 GiB = 16384 shards per launch")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 

@@ -50,13 +50,16 @@ static __device__ __forceinline__ uint32_t zmi_readlane(uint32_t v, uint32_t k) 
 }
 #endif
 
-// Workgroup -> work item.  The dispatcher deals consecutive workgroups round-robin over the 8 XCDs, so with
-// one workgroup per shard XCD x would get exactly the shards with index = x (mod 8) -- and any cost pattern of
-// period 8 in the batch (the benchmark's eight data classes are one) would load the XCDs unevenly while the
-// launch waits for the slowest.  Rotating the assignment inside every group of eight gives each XCD every
-// residue in turn and keeps neighbouring shards on neighbouring workgroups.  n = items in the launch.
+// Workgroup -> work item.  The dispatcher deals consecutive workgroups round-robin over the 8 XCDs and, inside
+// an XCD, round-robin over its 4 shader engines (measured: with one workgroup per shard and eight data classes
+// laid out with period 8, launch time followed the slowest class pair).  So with the identity mapping every
+// XCD / shader engine would see only a few residues of the shard index, and any cost pattern with a small
+// period in the batch would load them unevenly while the launch waits for the slowest.  Each group of eight
+// consecutive workgroups therefore takes its eight shards in an order rotated by a hash of the group number:
+// every XCD and every shader engine sees all residues, neighbouring shards stay on neighbouring workgroups.
 static __device__ __forceinline__ unsigned zmi_xcd_spread(unsigned b, unsigned n) {
-    return b < (n & ~7u) ? ((b & ~7u) | ((b + (b >> 3)) & 7u)) : b;
+    const unsigned rot = ((b >> 3) * 0x9E3779B1u) >> 29;
+    return b < (n & ~7u) ? ((b & ~7u) | ((b + rot) & 7u)) : b;
 }
 
 static __device__ __forceinline__ unsigned zmi_lane() { return threadIdx.x & 63u; }
