@@ -302,18 +302,22 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                     const bool is_probe = H6 && probe;
                     if (is_probe) { dn = first_dn; probe = false; }
                     const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
-                    uint32_t tl = 0;
-                    if (blen >= 16u) tl = lz_ring32(win, cand + blen - 3u);
                     const uint32_t sh = r & 3u;
-                    const uint64_t xa = ((uint64_t)(__builtin_amdgcn_alignbyte(w2, w1, sh) ^ myhi) << 32) |
-                                        (__builtin_amdgcn_alignbyte(w1, w0, sh) ^ mylo);
-                    const uint64_t xb = ((uint64_t)(__builtin_amdgcn_alignbyte(w4, w3, sh) ^ my3) << 32) |
-                                        (__builtin_amdgcn_alignbyte(w3, w2, sh) ^ my2);
-                    uint32_t la = (uint32_t)(__ffsll((unsigned long long)xa) - 1) >> 3;  // 0x1FFFFFFF when equal
-                    uint32_t lb = (uint32_t)(__ffsll((unsigned long long)xb) - 1) >> 3;
-                    lb = lb > 8u ? 8u : lb;
-                    uint32_t l = la > 8u ? 8u + lb : la;
-                    if (blen >= 16u && !(l == 16u && tl == tail)) l = 0u;
+                    // first differing byte of the 16: v_ffbl gives -1 for an all-equal dword, so OR-ing in the dword's
+                    // bit offset keeps that "infinite" and a three-way minimum picks the first mismatch
+                    const uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sh) ^ mylo, x1 = __builtin_amdgcn_alignbyte(w2, w1, sh) ^ myhi;
+                    const uint32_t x2 = __builtin_amdgcn_alignbyte(w3, w2, sh) ^ my2, x3 = __builtin_amdgcn_alignbyte(w4, w3, sh) ^ my3;
+                    const uint32_t c0 = zmi_ffbl(x0), c1 = zmi_ffbl(x1) | 32u;
+                    const uint32_t c2 = zmi_ffbl(x2) | 64u, c3 = zmi_ffbl(x3) | 96u;
+                    uint32_t m3 = c0 < c1 ? c0 : c1;
+                    m3 = m3 < c2 ? m3 : c2;
+                    m3 = m3 < c3 ? m3 : c3;
+                    uint32_t l = m3 >> 3;        // 0..15, or 0x1FFFFFFF when all 16 bytes are equal
+                    l = l > 16u ? 16u : l;
+                    // (a candidate that differs inside its first 16 bytes cannot beat a best match of 16+: nothing to do)
+                    // rare: all 16 bytes equal.  With a best match of 16+ already, the 4 bytes ending at the best length
+                    // decide first whether this candidate can be longer at all.
+                    if (l == 16u && blen >= 16u && lz_ring32(win, cand + blen - 3u) != tail) l = 0u;
                     if (l == 16u && maxlen > 16u) {
                         // extend 16 bytes per round
                         for (;;) {
@@ -336,8 +340,8 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                     if (better && l >= prm.good_len) chain >>= 1;  // a good match halves the remaining budget
                     const bool stop = better && (l >= prm.nice_len || l >= maxlen);
                     cand = is_probe ? p - dn : cand - dn;  // after the 4-byte probe the walk starts at p's own 6-byte link
-                    chain = chain ? chain - 1u : 0u;
-                    if (stop || dn == 0u || chain == 0u || p - cand > prm.max_dist) break;
+                    chain -= 1u;   // may wrap below zero after the halving: compared as signed
+                    if (stop || dn == 0u || (int32_t)chain <= 0 || p - cand > prm.max_dist) break;
                 }
                 // the shortest matches are not worth a far distance: their length + distance codes cost more
                 // bits than the literals they replace

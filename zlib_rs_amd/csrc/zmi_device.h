@@ -41,6 +41,18 @@ static inline uint32_t zmi_uniform(uint32_t v) { return v; }
 static __device__ __forceinline__ uint32_t zmi_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 #endif
 
+// index of the lowest set bit, 0xFFFFFFFF for 0 (v_ffbl_b32's native result; written as asm because the compiler's
+// own ctz forms either add a compare + select for the zero case or make it undefined)
+#ifdef ZMI_EMU
+static inline uint32_t zmi_ffbl(uint32_t x) { return x ? (uint32_t)__builtin_ctz(x) : 0xFFFFFFFFu; }
+#else
+static __device__ __forceinline__ uint32_t zmi_ffbl(uint32_t x) {
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+#endif
+
 // value of `v` in lane `k` (k wave-uniform), as a scalar
 #ifdef ZMI_EMU
 static inline uint32_t zmi_readlane(uint32_t v, uint32_t k) { return (uint32_t)__shfl((int)v, (int)k); }
