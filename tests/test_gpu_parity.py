@@ -191,6 +191,41 @@ def test_inflate_errors(engine):
     assert st[6] == -3                  # invalid block type (BTYPE=3)
 
 
+def test_inflate_unaligned_layout_and_patterns(engine):
+    """odd input / output offsets (the 4- and 16-byte aligned paths are not taken), guard bytes behind every
+    stream's capacity, long distances, self-overlapping runs, many tiny blocks, a hole-free stretch longer than
+    the resolve ring between regions with back-references"""
+    import torch
+    rng = np.random.default_rng(7)
+    r = rng.integers(0, 256, 32768, dtype=np.uint8).tobytes()
+    text = _gen(engine, 1, 1 << 16)[0]
+    co = zlib.compressobj(6, zlib.DEFLATED, 15)
+    tiny = b"".join(co.compress(text[i:i + 97]) + co.flush(zlib.Z_SYNC_FLUSH) for i in range(0, 30000, 97)) + co.flush()
+    blobs = [r + r + r[:700], bytes(70000), b"ab" * 20000 + b"xyz" * 9000,
+             text[:5000] + rng.integers(0, 256, 90000, dtype=np.uint8).tobytes() + text[:5000] + r[100:900], text[:30000]]
+    streams = [zlib.compress(b, 9) for b in blobs[:4]] + [tiny]
+    caps = [len(b) for b in blobs]
+    ioff, ooff, a, o = [], [], 3, 5
+    for s_, c in zip(streams, caps):
+        ioff.append(a); a += len(s_) + 7
+        ooff.append(o); o += c + 3
+    d = torch.zeros(a + 64, dtype=torch.uint8)
+    for off_, s_ in zip(ioff, streams):
+        d[off_:off_ + len(s_)] = torch.frombuffer(bytearray(s_), dtype=torch.uint8)
+    d = d.to(engine.device)
+    out = torch.full((o + 64,), 0xEE, dtype=torch.uint8, device=engine.device)
+    olen, st = engine.inflate_batch(d, torch.tensor(ioff, dtype=torch.int64, device=engine.device),
+                                    torch.tensor([len(s_) for s_ in streams], dtype=torch.int32, device=engine.device), out,
+                                    torch.tensor(ooff, dtype=torch.int64, device=engine.device),
+                                    torch.tensor(caps, dtype=torch.int32, device=engine.device), wrap=1)
+    torch.cuda.synchronize()
+    assert st.cpu().tolist() == [0] * len(blobs)
+    h = out.cpu().numpy()
+    for off_, c, b in zip(ooff, caps, blobs):
+        assert bytes(h[off_:off_ + c]) == b
+        assert bytes(h[off_ + c:off_ + c + 3]) == b"\xee\xee\xee"   # nothing written past the capacity
+
+
 def test_checksums(engine):
     import torch
     blobs = [b"", b"a", b"abc", bytes(range(256)) * 300] + _gen(engine, 4, 1 << 16) + _gen(engine, 2)

@@ -253,6 +253,95 @@ static __device__ __forceinline__ uint32_t inf_lookup(const uint32_t* tab, uint3
     return e;
 }
 
+// One speculative token: the literal / length code at the low end of (hi:lo) and, if it is a length, the
+// distance code behind it.  rem = input bits left from this token's first bit.  Branch-free apart from the
+// second-level lookups: selects cost two VALU instructions, a divergent branch costs exec-mask bookkeeping on
+// the scalar unit, which is the busier one.
+struct InfTok {
+    uint32_t tw;     // bits 0-5 token length in bits; above 63 it stops the chain walk: 64 = end of block, 128 / 256 = error
+    uint32_t kind;   // 0 literal, 1 back-reference, 2 end of block
+    uint32_t val;    // literal byte | match length
+    uint32_t dist;
+};
+static __device__ __forceinline__ InfTok inf_tok(const InfShared* S, uint32_t lo, uint32_t hi, int32_t rem) {
+    uint32_t e = S->ltab[lo & ((1u << INF_LROOT) - 1u)];
+    if ((e >> 8) & INF_OP_LINK) {
+        uint32_t sb = (e >> 8) & 0x0Fu;
+        e = S->ltab[(e >> 16) + ((lo >> INF_LROOT) & ((1u << sb) - 1u))];
+    }
+    const uint32_t bits = e & 0xFFu, op = (e >> 8) & 0xFFu;
+    const bool bad = op == INF_OP_BAD || bits == 0u;                  // "invalid literal/length code"
+    const bool is_eob = op == INF_OP_EOB;
+    const bool is_len = (op & INF_OP_BASE) != 0u;
+    const uint32_t xb = is_len ? (op & 0x0Fu) : 0u;
+    const uint32_t used = bits + xb;                                    // <= 20
+    InfTok T;
+    T.val = (e >> 16) + ((lo >> bits) & ((1u << xb) - 1u));
+    // distance code: skipped by a scalar branch when no lane holds a length code (literal-only data)
+    uint32_t dlen = 0;
+    bool dbad = false;
+    T.dist = 0;
+    if (__ballot(is_len)) {
+        const uint32_t rest = __builtin_amdgcn_alignbit(hi, lo, used);
+        uint32_t d = S->dtab[rest & ((1u << INF_DROOT) - 1u)];
+        if (is_len && ((d >> 8) & INF_OP_LINK)) {
+            uint32_t sb = (d >> 8) & 0x0Fu;
+            d = S->dtab[(d >> 16) + ((rest >> INF_DROOT) & ((1u << sb) - 1u))];
+        }
+        const uint32_t dbits = d & 0xFFu, dop = (d >> 8) & 0xFFu;
+        dbad = dop == INF_OP_BAD || dbits == 0u || !(dop & INF_OP_BASE);   // "invalid distance code"
+        const uint32_t dxb = dop & 0x0Fu;
+        T.dist = (d >> 16) + ((rest >> dbits) & ((1u << dxb) - 1u));
+        dlen = dbits + dxb;
+    }
+    const uint32_t t = is_len ? used + dlen : bits;                     // <= 48
+    T.kind = is_len ? 1u : (is_eob ? 2u : 0u);
+    // 1: more input needed, 2: invalid data (the reference decides by the bits that are left)
+    const uint32_t err_len = (int32_t)used > rem ? 1u : (dbad ? ((rem - (int32_t)used) < 15 ? 1u : 2u) : ((int32_t)t > rem ? 1u : 0u));
+    const uint32_t err = bad ? (rem < 15 ? 1u : 2u) : ((int32_t)bits > rem ? 1u : (is_len ? err_len : 0u));
+    T.tw = err ? (err << 7) : (t | (is_eob ? 64u : 0u));
+    return T;
+}
+// walk the token chain through one 64-position window: sets the bit of every token start in M, leaves in w the
+// word that stopped it (> 63) or the last hop, in pos the position reached (>= 64: ran off the window)
+static __device__ __forceinline__ void inf_walk(uint32_t tw, uint32_t& pos, uint64_t& M, uint32_t& w) {
+#ifdef ZMI_EMU
+    do {
+        w = zmi_readlane(tw, pos);
+        if (w > 63u) break;
+        M |= 1ull << pos;
+        pos += w;
+    } while (pos < 64u);
+#else
+    // six scalar instructions and one lane read per token (the compiler's version of the loop above needs twelve
+    // and a third branch); `pos` is written by SALU only, so the lane select of v_readlane has no VALU->SGPR hazard
+    asm volatile(
+        "1:\n\t"
+        "v_readlane_b32 %[w], %[tw], %[pos]\n\t"
+        "s_cmp_gt_u32 %[w], 63\n\t"
+        "s_cbranch_scc1 2f\n\t"
+        "s_bitset1_b64 %[M], %[pos]\n\t"
+        "s_add_u32 %[pos], %[pos], %[w]\n\t"
+        "s_cmp_lt_u32 %[pos], 64\n\t"
+        "s_cbranch_scc1 1b\n\t"
+        "2:"
+        : [w] "=&s"(w), [pos] "+s"(pos), [M] "+s"(M)
+        : [tw] "v"(tw)
+        : "scc");
+#endif
+}
+// every lane on the chain stores its own token: the literal byte, or the back-reference record + bitmap bit
+static __device__ __forceinline__ void inf_emit(uint8_t* dst, uint32_t* bm32, bool on, const InfTok& T, uint32_t off) {
+    if (on && T.kind == 0u) dst[off] = (uint8_t)T.val;
+    if (on && T.kind == 1u) {
+        const uint32_t rec = (T.dist - 1u) | ((T.val - 3u) << 15);   // 15 + 8 bits, fits the smallest hole
+        dst[off] = (uint8_t)rec;
+        dst[off + 1u] = (uint8_t)(rec >> 8);
+        dst[off + 2u] = (uint8_t)(rec >> 16);
+        atomicOr(&bm32[off >> 5], 1u << (off & 31u));
+    }
+}
+
 // wrap: 0 raw, 1 zlib, 2 gzip, 3 auto (zlib or gzip by magic)
 __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                          const uint32_t* __restrict__ in_len, uint32_t wrap,
@@ -422,11 +511,11 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
         }
 
         // ---- symbol rounds ----
-        // Lane i decodes, speculatively, the complete token (literal, end-of-block, or length + distance
-        // with their extra bits: at most 48 bits) that would start at bit P + i.  The real token chain
-        // is then walked from lane 0 with scalar lane reads (each hop is a handful of SALU
-        // instructions), a wave scan places the outputs, and every lane on the chain stores its own
-        // token: the literal byte, or the back-reference record + bitmap bit for the resolve pass.
+        // Lane i decodes, speculatively, the complete tokens (literal, end-of-block, or length + distance with
+        // their extra bits: at most 48 bits) that would start at bits P + i and P + 64 + i: two windows per round,
+        // so that their LDS round trips overlap and the per-round scalar work is spread over twice the tokens.
+        // The real token chain is then walked from bit P with scalar lane reads, a wave scan places the outputs,
+        // and every lane on the chain stores its own token(s).
         {
             uint64_t P = 8ull * B.ipos - B.nbits;   // bit position of the next token
             const uint64_t Pend = 8ull * B.n;
@@ -435,125 +524,80 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             while (!eob && st == ZMI_OK) {
                 uint32_t ib = (uint32_t)(P >> 3);
                 uint32_t relbyte = (uint32_t)((int32_t)ib - B.cbase);
-                // the window reads up to 19 bytes past its first byte; the serial reader may also have
+                // the two windows read up to 27 bytes past their first byte; the serial reader may also have
                 // moved the chunk past bits it still held when it handed over
-                if ((int32_t)relbyte < 0 || relbyte + 20u > INF_CHUNK) {
+                if ((int32_t)relbyte < 0 || relbyte + 28u > INF_CHUNK) {
                     B.cbase = (int32_t)zmi_uniform((uint32_t)inf_load_chunk(B.src, B.n, ib, B.inbuf));
                     relbyte = (uint32_t)((int32_t)ib - B.cbase);
                 }
                 const uint32_t bo = ((relbyte << 3) | ((uint32_t)P & 7u)) + lane;   // my bit offset inside inbuf
                 const uint32_t wi = bo >> 5, sh = bo & 31u;
-                const uint32_t d0 = iw[wi], d1 = iw[wi + 1u], d2 = iw[wi + 2u];
-                const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh);
-                const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+                const uint32_t d0 = iw[wi], d1 = iw[wi + 1u], d2 = iw[wi + 2u], d3 = iw[wi + 3u], d4 = iw[wi + 4u];
                 const uint64_t left = Pend - P;   // input bits from P to the end of the stream
                 const int32_t rem = (int32_t)(left > 0x40000000ull ? 0x40000000u : (uint32_t)left) - (int32_t)lane;
+                const InfTok TA = inf_tok(S, __builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh), rem);
+                const InfTok TB = inf_tok(S, __builtin_amdgcn_alignbit(d3, d2, sh), __builtin_amdgcn_alignbit(d4, d3, sh), rem - 64);
 
-                // literal / length code, then (speculatively, for every lane) the distance code behind it.
-                // Branch-free apart from the second-level lookups: selects cost two VALU instructions, a
-                // divergent branch costs exec-mask bookkeeping on the scalar unit, which is the busier one.
-                uint32_t e = S->ltab[lo & ((1u << INF_LROOT) - 1u)];
-                if ((e >> 8) & INF_OP_LINK) {
-                    uint32_t sb = (e >> 8) & 0x0Fu;
-                    e = S->ltab[(e >> 16) + ((lo >> INF_LROOT) & ((1u << sb) - 1u))];
-                }
-                const uint32_t bits = e & 0xFFu, op = (e >> 8) & 0xFFu;
-                const bool bad = op == INF_OP_BAD || bits == 0u;                  // "invalid literal/length code"
-                const bool is_eob = op == INF_OP_EOB;
-                const bool is_len = (op & INF_OP_BASE) != 0u;
-                const uint32_t xb = is_len ? (op & 0x0Fu) : 0u;
-                const uint32_t used = bits + xb;                                    // <= 20
-                const uint32_t val = (e >> 16) + ((lo >> bits) & ((1u << xb) - 1u));   // literal byte | match length
-                // distance code: skipped by a scalar branch when no lane holds a length code (literal-only data)
-                uint32_t dist = 0, dlen = 0;
-                bool dbad = false;
-                if (__ballot(is_len)) {
-                    const uint32_t rest = __builtin_amdgcn_alignbit(hi, lo, used);
-                    uint32_t d = S->dtab[rest & ((1u << INF_DROOT) - 1u)];
-                    if (is_len && ((d >> 8) & INF_OP_LINK)) {
-                        uint32_t sb = (d >> 8) & 0x0Fu;
-                        d = S->dtab[(d >> 16) + ((rest >> INF_DROOT) & ((1u << sb) - 1u))];
-                    }
-                    const uint32_t dbits = d & 0xFFu, dop = (d >> 8) & 0xFFu;
-                    dbad = dop == INF_OP_BAD || dbits == 0u || !(dop & INF_OP_BASE);   // "invalid distance code"
-                    const uint32_t dxb = dop & 0x0Fu;
-                    dist = (d >> 16) + ((rest >> dbits) & ((1u << dxb) - 1u));
-                    dlen = dbits + dxb;
-                }
-                const uint32_t t = is_len ? used + dlen : bits;             // token length in bits, <= 48
-                const uint32_t kind = is_len ? 1u : (is_eob ? 2u : 0u);            // 0 literal, 1 back-reference, 2 end of block
-                // 1: more input needed, 2: invalid data (the reference decides by the bits that are left)
-                const uint32_t err_len = (int32_t)used > rem ? 1u
-                                         : (dbad ? ((rem - (int32_t)used) < 15 ? 1u : 2u) : ((int32_t)t > rem ? 1u : 0u));
-                const uint32_t err = bad ? (rem < 15 ? 1u : 2u) : ((int32_t)bits > rem ? 1u : (is_len ? err_len : 0u));
-                // bits 0-5 token length; anything above 63 stops the walk: 64 = end of block, 128 / 256 = error
-                const uint32_t tw = err ? (err << 7) : (t | (kind == 2u ? 64u : 0u));
-
-                // walk the chain of real tokens
-                uint32_t pos = 0, w;
-                uint64_t M = 0;
+                // walk the chain of real tokens through both windows
+                uint32_t pos = 0, w = 0;
+                uint64_t MA = 0, MB = 0;
                 int32_t rst = ZMI_OK;
-#ifdef ZMI_EMU
-                do {
-                    w = zmi_readlane(tw, pos);
-                    if (w > 63u) break;
-                    M |= 1ull << pos;
-                    pos += w;
-                } while (pos < 64u);
-#else
-                // six scalar instructions and one lane read per token (the compiler's version of the loop
-                // above needs twelve and a third branch); `pos` is written by SALU only, so the lane select
-                // of v_readlane has no VALU->SGPR hazard
-                asm volatile(
-                    "1:\n\t"
-                    "v_readlane_b32 %[w], %[tw], %[pos]\n\t"
-                    "s_cmp_gt_u32 %[w], 63\n\t"
-                    "s_cbranch_scc1 2f\n\t"
-                    "s_bitset1_b64 %[M], %[pos]\n\t"
-                    "s_add_u32 %[pos], %[pos], %[w]\n\t"
-                    "s_cmp_lt_u32 %[pos], 64\n\t"
-                    "s_cbranch_scc1 1b\n\t"
-                    "2:"
-                    : [w] "=&s"(w), [pos] "+s"(pos), [M] "+s"(M)
-                    : [tw] "v"(tw)
-                    : "scc");
-#endif
-                if (pos < 64u) {
-                    if (w & 64u) { M |= 1ull << pos; pos += w & 63u; eob = true; }
-                    else rst = (w & 128u) ? ZMI_BUF_ERROR : ZMI_DATA_ERROR;
+                inf_walk(TA.tw, pos, MA, w);
+                bool inB = false;
+                if (pos >= 64u) {
+                    pos -= 64u;
+                    inB = true;
+                    inf_walk(TB.tw, pos, MB, w);
                 }
+                if (pos < 64u) {   // stopped by an end-of-block or an error token
+                    if (w & 64u) {
+                        if (inB) MB |= 1ull << pos; else MA |= 1ull << pos;
+                        pos += w & 63u;
+                        eob = true;
+                    } else rst = (w & 128u) ? ZMI_BUF_ERROR : ZMI_DATA_ERROR;
+                }
+                if (inB) pos += 64u;   // bits consumed
 
                 // place the outputs
-                bool on = (M >> lane) & 1ull;
-                const uint32_t outlen = on ? (kind == 0u ? 1u : (kind == 1u ? val : 0u)) : 0u;
-                const uint32_t incl = zmi_wave_incl_scan(outlen);
-                const uint32_t excl = incl - outlen;
-                const bool far_back = on && kind == 1u && dist > opos + excl;        // "invalid distance too far back"
-                const bool no_room = on && outlen != 0u && opos + incl > cap;
-                const uint64_t cut = __ballot(far_back || no_room);
+                bool onA = (MA >> lane) & 1ull, onB = (MB >> lane) & 1ull;
+                const uint32_t lenA = onA ? (TA.kind == 0u ? 1u : (TA.kind == 1u ? TA.val : 0u)) : 0u;
+                const uint32_t lenB = onB ? (TB.kind == 0u ? 1u : (TB.kind == 1u ? TB.val : 0u)) : 0u;
+                const uint32_t inclA = zmi_wave_incl_scan(lenA);
+                const uint32_t totA = zmi_readlane(inclA, 63u);
+                const uint32_t inclB = zmi_wave_incl_scan(lenB) + totA;
+                const uint32_t exclA = inclA - lenA, exclB = inclB - lenB;
+                const bool farA = onA && TA.kind == 1u && TA.dist > opos + exclA;   // "invalid distance too far back"
+                const bool farB = onB && TB.kind == 1u && TB.dist > opos + exclB;
+                const bool fullA = onA && lenA != 0u && opos + inclA > cap;
+                const bool fullB = onB && lenB != 0u && opos + inclB > cap;
+                const uint64_t cutA = __ballot(farA || fullA), cutB = __ballot(farB || fullB);
                 uint32_t tot;
-                if (cut) {
+                if (cutA | cutB) {
                     // the round ends in front of token k; whatever the walk found behind it is not reached
-                    const uint32_t k = (uint32_t)__ffsll((unsigned long long)cut) - 1u;
-                    const uint32_t fb = (uint32_t)((__ballot(far_back) >> k) & 1ull);
-                    M &= (1ull << k) - 1ull;
-                    on = (M >> lane) & 1ull;
-                    tot = zmi_readlane(excl, k);
-                    pos = k;
+                    uint32_t fb;
+                    if (cutA) {
+                        const uint32_t k = (uint32_t)__ffsll((unsigned long long)cutA) - 1u;
+                        fb = (uint32_t)((__ballot(farA) >> k) & 1ull);
+                        MA &= (1ull << k) - 1ull;
+                        MB = 0;
+                        tot = zmi_readlane(exclA, k);
+                        pos = k;
+                    } else {
+                        const uint32_t k = (uint32_t)__ffsll((unsigned long long)cutB) - 1u;
+                        fb = (uint32_t)((__ballot(farB) >> k) & 1ull);
+                        MB &= (1ull << k) - 1ull;
+                        tot = zmi_readlane(exclB, k);
+                        pos = 64u + k;
+                    }
+                    onA = (MA >> lane) & 1ull;
+                    onB = (MB >> lane) & 1ull;
                     eob = false;
                     rst = fb ? ZMI_DATA_ERROR : ZMI_NEED_OUTPUT;
                 } else {
-                    tot = zmi_readlane(incl, 63u);
+                    tot = zmi_readlane(inclB, 63u);
                 }
-                const uint32_t off = opos + excl;
-                if (on && kind == 0u) dst[off] = (uint8_t)val;
-                if (on && kind == 1u) {
-                    const uint32_t rec = (dist - 1u) | ((val - 3u) << 15);   // 15 + 8 bits, fits the smallest hole
-                    dst[off] = (uint8_t)rec;
-                    dst[off + 1u] = (uint8_t)(rec >> 8);
-                    dst[off + 2u] = (uint8_t)(rec >> 16);
-                    atomicOr(&bm32[off >> 5], 1u << (off & 31u));
-                }
+                inf_emit(dst, bm32, onA, TA, opos + exclA);
+                inf_emit(dst, bm32, onB, TB, opos + exclB);
                 opos += tot;
                 P += pos;
                 if (rst != ZMI_OK) st = rst;
