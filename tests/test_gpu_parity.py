@@ -202,7 +202,8 @@ def test_inflate_unaligned_layout_and_patterns(engine):
     co = zlib.compressobj(6, zlib.DEFLATED, 15)
     tiny = b"".join(co.compress(text[i:i + 97]) + co.flush(zlib.Z_SYNC_FLUSH) for i in range(0, 30000, 97)) + co.flush()
     blobs = [r + r + r[:700], bytes(70000), b"ab" * 20000 + b"xyz" * 9000,
-             text[:5000] + rng.integers(0, 256, 90000, dtype=np.uint8).tobytes() + text[:5000] + r[100:900], text[:30000]]
+             text[:5000] + rng.integers(0, 256, 90000, dtype=np.uint8).tobytes() + text[:5000] + r[100:900],
+             text[:97 * len(range(0, 30000, 97))]]
     streams = [zlib.compress(b, 9) for b in blobs[:4]] + [tiny]
     caps = [len(b) for b in blobs]
     ioff, ooff, a, o = [], [], 3, 5
