@@ -10,10 +10,12 @@
  *
  * Stream semantics on the GPU (documented deviations that stay inside zlib's contract):
  *   deflate()  consumes and buffers input; compressed data is produced when the caller flushes or
- *              finishes (or 64 MiB are pending).  The input is compressed in 1 MiB segments with
- *              Z_FULL_FLUSH semantics between them (history reset, byte aligned,
- *              zlib-rs/src/deflate.rs:2739-2752), the way the reference's own split_deflate test
- *              stitches independently compressed parts (zlib-rs/src/deflate.rs:4149-4221).
+ *              finishes (or 64 MiB are pending).  The input is compressed in 1 MiB segments, one
+ *              workgroup each, that start byte aligned (the empty stored block of Z_SYNC_FLUSH,
+ *              zlib-rs/src/deflate.rs:2733-2738) and keep the window: a segment matches into the
+ *              28 KiB in front of it, like a preset dictionary (deflate.rs:499-564).  Across
+ *              separate flushes by the caller the history starts empty (Z_FULL_FLUSH semantics,
+ *              deflate.rs:2739-2752).
  *   inflate()  buffers input and decodes once the stream is complete (one wave per stream); output
  *              is then handed out across as many calls as the caller's buffers need.
  * Not implemented (Z_STREAM_ERROR): preset dictionaries, deflatePrime/inflatePrime, inflateBack*,

@@ -12,3 +12,24 @@ def test_zlib_abi_on_emulator(monkeypatch):
     zmi_ctypes.load_emu()
     lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
     H.run_abi_checks(lib, oracle_lib.load(), sizes=(0, 1, 100, 5000, 20000))
+
+
+def test_window_carry_over_between_segments(monkeypatch):
+    """a stream split into chained segments keeps its window: a segment matches into the bytes in front of it,
+    so the split costs (almost) nothing; ZMI_CARRY=0 gives the cold-start variant (Z_FULL_FLUSH semantics)"""
+    import zlib
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    o = oracle_lib.load()
+    data = o.gen_shard(0, 40000)
+    sizes = {}
+    for carry in ("1", "0"):
+        monkeypatch.setenv("ZMI_ABI_SEGMENT", "4096")
+        monkeypatch.setenv("ZMI_CARRY", carry)
+        comp = H.deflate_stream(lib, data, level=6, wbits=15)
+        assert zlib.decompress(comp) == data
+        sizes[carry] = len(comp)
+    monkeypatch.setenv("ZMI_ABI_SEGMENT", "65536")
+    whole = len(H.deflate_stream(lib, data, level=6, wbits=15))
+    assert sizes["1"] < sizes["0"] * 0.93, sizes          # ten 4 KiB cold starts cost > 7 % on this text
+    assert sizes["1"] < whole * 1.03, (sizes, whole)       # with the window carried the split is nearly free

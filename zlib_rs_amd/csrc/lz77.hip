@@ -184,16 +184,25 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
     const uint32_t wave = zmi_wave();
     const uint32_t local = zmi_xcd_spread(blockIdx.x, gridDim.x);
     const uint32_t s = first_shard + local;
-    const uint8_t* src = data + off[s];
-    const uint32_t n = len[s];
-    uint32_t* mout = match + (uint64_t)local * match_stride;
+    // window carry-over: the bytes in front of a segment that belong to the same stream become `hist` extra
+    // positions at the start of the shard; they are hashed (producer) but not searched, so every position index
+    // in this kernel is "virtual" = hist + position in the segment, and results are stored at index - hist
+    uint32_t hist = 0;
+    if (prm.carry && s > 0u) {
+        const uint64_t before = off[s] - off[0];
+        const uint32_t reach = prm.max_dist & ~(LZ_T - 1u);
+        hist = before < reach ? (uint32_t)before & ~(LZ_T - 1u) : reach;
+    }
+    const uint8_t* src = data + off[s] - hist;
+    const uint32_t n = len[s] + hist;
+    uint32_t* mout = match + (uint64_t)local * match_stride - hist;
     const bool aligned = (((uintptr_t)src) & 15u) == 0;
     const uint32_t ntiles = (n + LZ_T - 1u) / LZ_T;
     if (ntiles == 0) return;
 
     for (uint32_t i = t; i < LZ_HSIZE; i += 1024u) head[i] = 0u;
     for (uint32_t i = t; i < LZ_H4SIZE; i += 1024u) head4[i] = 0u;
-    if (t == 0) { ctl->ready = 0u; ctl->next = 0u; }
+    if (t == 0) { ctl->ready = 0u; ctl->next = hist; }
     if (t < LZ_NW) ctl->wmin[t] = 0xFFFFFFFFu;
     __syncthreads();
 

@@ -212,9 +212,10 @@ extern "C" int zmi_deflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_
                             d_status, stream_);
 }
 
-// The shards are consecutive segments of ONE raw deflate stream (each starts with an empty history
-// and a byte-aligned position, exactly what Z_FULL_FLUSH produces in the reference,
-// zlib-rs/src/deflate.rs:2739-2752); `finish` != 0 makes the last shard end the stream (BFINAL).
+// The shards are consecutive segments of ONE raw deflate stream, contiguous in d_in (d_in_off[i+1] = d_in_off[i] +
+// d_in_len[i]).  Every segment starts byte aligned (the empty stored block of Z_SYNC_FLUSH,
+// zlib-rs/src/deflate.rs:2733-2738) and may match into the up to 28 KiB in front of it (window carry-over), so
+// splitting a stream costs no cold start; `finish` != 0 makes the last shard end the stream (BFINAL).
 extern "C" int zmi_deflate_chain_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                      uint32_t n, uint32_t max_len, int level, int strategy, int finish, void* d_out,
                                      uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_) {
@@ -281,6 +282,8 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     if (nice_env && atoi(nice_env) > 0) lp.nice_len = (uint32_t)atoi(nice_env);
     const char* lazy_env = getenv("ZMI_LAZY");
     if (lazy_env && atoi(lazy_env) >= 0) ep.max_lazy = (uint32_t)atoi(lazy_env);
+    lp.carry = chain_mode != 0u ? 1u : 0u;   // segments of one stream: a segment sees the window in front of it
+    if (const char* cv = getenv("ZMI_CARRY")) lp.carry = (chain_mode != 0u && atoi(cv)) ? 1u : 0u;
     lp.far4 = 1024u;
     lp.far5 = 8192u;
     if (const char* f4 = getenv("ZMI_FAR4")) lp.far4 = (uint32_t)atoi(f4);

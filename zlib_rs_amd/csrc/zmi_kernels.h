@@ -17,6 +17,8 @@ struct zmi_lz_params {
     uint32_t max_dist;   // farthest back-reference (<= 32768 - 3*1024 - 16, ring-buffer constraint)
     uint32_t claim;      // positions a searcher wave claims at once (64, 128, 192 or 256)
     uint32_t hash6;      // 1: chain keyed by a 6-byte hash + one most-recent 4-byte probe; 0: 4-byte hash chain
+    uint32_t carry;      // 1: the shards are consecutive segments of one stream; a segment may match into the up to 28 KiB
+                         // in front of it (window carry-over, what a preset dictionary is in deflate.rs:499-564)
     uint32_t far4, far5; // a 4- (5-) byte match further back than this costs more bits than its literals: dropped
                          // (classic zlib's TOO_FAR idea; the reference itself only drops matches <= 5 under
                          // Z_FILTERED, zlib-rs/src/deflate/algorithm/slow.rs:69-74)
