@@ -84,17 +84,32 @@ int zmi_inflate_batch_dev(zmi_ctx* ctx, const void* d_in, const uint64_t* d_in_o
                           const uint32_t* d_out_cap, uint32_t* d_out_len, int32_t* d_status, void* stream);
 
 /* Chained form used by the zlib stream ABI (libz_mi355.so): the shards are consecutive segments of
- * ONE raw deflate stream, each byte aligned with an empty history (what Z_FULL_FLUSH produces,
- * zlib-rs/src/deflate.rs:2739-2752); finish != 0 makes the last shard end the stream. */
+ * ONE raw deflate stream, contiguous in d_in.  Each starts byte aligned (the empty stored block of
+ * Z_SYNC_FLUSH, zlib-rs/src/deflate.rs:2733-2738) and matches into the up to 27 KiB in front of it
+ * (window carry-over); finish != 0 makes the last shard end the stream.  The _dict form also treats the
+ * dict_len bytes in front of the first segment as history: a preset dictionary (deflateSetDictionary,
+ * deflate.rs:499-564) or the tail of the input of an earlier call on the same stream. */
 int zmi_deflate_chain_dev(zmi_ctx* ctx, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                           uint32_t n_shards, uint32_t max_len, int level, int strategy, int finish, void* d_out,
                           uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream);
+int zmi_deflate_chain_dict_dev(zmi_ctx* ctx, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                               uint32_t n_shards, uint32_t max_len, int level, int strategy, int finish,
+                               uint32_t dict_len, void* d_out, uint64_t out_stride, uint32_t* d_out_len,
+                               int32_t* d_status, void* stream);
 /* As zmi_inflate_batch_dev, additionally reporting the consumed input bytes and why a stream
  * stopped (d_detail: 0 done/error, 1 needs more input, 2 needs more output space). */
 int zmi_inflate_batch_dev_ex(zmi_ctx* ctx, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                              uint32_t n_streams, int wrap, void* d_out, const uint64_t* d_out_off,
                              const uint32_t* d_out_cap, uint32_t* d_out_len, int32_t* d_status, uint32_t* d_in_used,
                              int32_t* d_detail, void* stream);
+/* As zmi_inflate_batch_dev_ex with preset dictionaries: d_out_hist[i] (array may be NULL) bytes directly in front
+ * of stream i's output region are history the stream may refer to (inflateSetDictionary,
+ * zlib-rs/src/inflate.rs:2492-2536).  A zlib stream with FDICT set reports Z_NEED_DICT (2) when its entry is 0;
+ * checking its DICTID against the dictionary is the caller's job. */
+int zmi_inflate_batch_dict_dev(zmi_ctx* ctx, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                               uint32_t n_streams, int wrap, void* d_out, const uint64_t* d_out_off,
+                               const uint32_t* d_out_cap, const uint32_t* d_out_hist, uint32_t* d_out_len,
+                               int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail, void* stream);
 
 /* Adler-32 (kind bit 0) and/or CRC-32 (kind bit 1) of every shard (zlib-rs/src/adler32.rs:19, crc32.rs:19) */
 int zmi_checksum_batch_dev(zmi_ctx* ctx, const void* d_data, const uint64_t* d_off, const uint32_t* d_len,

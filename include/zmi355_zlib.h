@@ -18,8 +18,10 @@
  *              deflate.rs:2739-2752).
  *   inflate()  buffers input and decodes once the stream is complete (one wave per stream); output
  *              is then handed out across as many calls as the caller's buffers need.
- * Not implemented (Z_STREAM_ERROR): preset dictionaries, deflatePrime/inflatePrime, inflateBack*,
- * inflateSync, gzip header get/set, gz* file API ("next").
+ * Preset dictionaries (deflateSetDictionary / inflateSetDictionary, incl. Z_NEED_DICT and the DICTID check) are
+ * supported: the dictionary is the window in front of the first segment.
+ * Not implemented (Z_STREAM_ERROR): deflatePrime/inflatePrime, inflateBack*, inflateSync, gzip header get/set,
+ * gz* file API ("next").
  */
 #ifndef ZMI355_ZLIB_H
 #define ZMI355_ZLIB_H
@@ -112,7 +114,7 @@ int deflateTune(z_streamp strm, int good_length, int max_lazy, int nice_length, 
 uLong deflateBound(z_streamp strm, uLong sourceLen);                                     /* lib.rs:1364 */
 z_size_t deflateBound_z(z_streamp strm, z_size_t sourceLen);                             /* lib.rs:1345 */
 int deflatePending(z_streamp strm, unsigned* pending, int* bits);                        /* lib.rs:1757 */
-int deflateSetDictionary(z_streamp strm, const Bytef* dictionary, uInt dictLength);      /* lib.rs:1689, unsupported */
+int deflateSetDictionary(z_streamp strm, const Bytef* dictionary, uInt dictLength);      /* lib.rs:1689 */
 int deflatePrime(z_streamp strm, int bits, int value);                                   /* lib.rs:1725, unsupported */
 
 int inflateInit_(z_streamp strm, const char* version, int stream_size);                  /* lib.rs:935 */
@@ -121,7 +123,7 @@ int inflate(z_streamp strm, int flush);                                         
 int inflateEnd(z_streamp strm);                                                          /* lib.rs:660 */
 int inflateReset(z_streamp strm);                                                        /* lib.rs:1055 */
 int inflateReset2(z_streamp strm, int windowBits);                                       /* lib.rs:1082 */
-int inflateSetDictionary(z_streamp strm, const Bytef* dictionary, uInt dictLength);      /* lib.rs:1121, unsupported */
+int inflateSetDictionary(z_streamp strm, const Bytef* dictionary, uInt dictLength);      /* lib.rs:1121 */
 int inflateSync(z_streamp strm);                                                         /* lib.rs:884, unsupported */
 
 int compress(Bytef* dest, uLongf* destLen, const Bytef* source, uLong sourceLen);        /* lib.rs:1447 */

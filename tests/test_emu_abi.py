@@ -33,3 +33,20 @@ def test_window_carry_over_between_segments(monkeypatch):
     whole = len(H.deflate_stream(lib, data, level=6, wbits=15))
     assert sizes["1"] < sizes["0"] * 0.93, sizes          # ten 4 KiB cold starts cost > 7 % on this text
     assert sizes["1"] < whole * 1.03, (sizes, whole)       # with the window carried the split is nearly free
+
+
+def test_preset_dictionary_and_history_across_calls(monkeypatch):
+    import zlib
+    monkeypatch.setenv("ZMI_ABI_SEGMENT", "8192")
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    o = oracle_lib.load()
+    text = o.gen_shard(1, 60000)
+    H.dictionary_checks(lib, text[40000:52000], text[:33000])      # dictionary longer than the window: its tail is used
+    H.dictionary_checks(lib, text[3000:9000], text[:1500])         # short dictionary, unaligned length
+    # history survives Z_SYNC_FLUSH between deflate() calls (only Z_FULL_FLUSH forgets it, deflate.rs:2739-2752)
+    data = text[:30000]
+    one = H.deflate_stream(lib, data, level=6, wbits=15)
+    chunked = H.deflate_stream(lib, data, level=6, wbits=15, chunk_in=3000, flush_every=1)
+    assert zlib.decompress(chunked) == data
+    assert len(chunked) < len(one) * 1.06, (len(chunked), len(one))   # ten flushes: markers + block headers only

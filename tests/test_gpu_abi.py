@@ -20,6 +20,23 @@ def test_zlib_abi_on_gpu():
     H.run_abi_checks(lib, oracle_lib.load(rebuild=False), sizes=(0, 1, 100, 5000, 70000, 3 << 20))
 
 
+def test_preset_dictionary_and_window_carry_on_gpu():
+    import zlib
+    from zlib_rs_amd import _build
+    lib = H.bind(C.CDLL(_build.ABI_LIB))
+    o = oracle_lib.load(rebuild=False)
+    text = o.gen_shard(1, 3 << 20)
+    H.dictionary_checks(lib, text[100000:1400000], text[:40000])   # > 1 MiB of data: two chained segments behind the dictionary
+    H.dictionary_checks(lib, text[3000:9000], text[:1500])
+    # a 3 MiB stream = three 1 MiB segments compressed in parallel with the window carried over; fed in pieces with
+    # Z_SYNC_FLUSH in between the history also survives across deflate() calls
+    one = H.deflate_stream(lib, text, level=6, wbits=15)
+    assert zlib.decompress(one) == text
+    chunked = H.deflate_stream(lib, text, level=6, wbits=15, chunk_in=300000, flush_every=1)
+    assert zlib.decompress(chunked) == text
+    assert len(chunked) < len(one) * 1.01, (len(chunked), len(one))
+
+
 def test_c_program_links_and_roundtrips(tmp_path):
     from zlib_rs_amd import _build
     exe = str(tmp_path / "abi_smoke")

@@ -37,6 +37,8 @@ def bind(lib):
     for f in ("adler32", "crc32"):
         getattr(lib, f).restype = C.c_ulong
         getattr(lib, f).argtypes = [C.c_ulong, C.c_void_p, C.c_uint]
+    lib.deflateSetDictionary.argtypes = [C.POINTER(ZStream), C.c_char_p, C.c_uint]
+    lib.inflateSetDictionary.argtypes = [C.POINTER(ZStream), C.c_char_p, C.c_uint]
     lib.crc32_combine.restype = C.c_ulong
     lib.crc32_combine.argtypes = [C.c_ulong, C.c_ulong, C.c_long]
     lib.adler32_combine.restype = C.c_ulong
@@ -151,3 +153,52 @@ def run_abi_checks(lib, o, sizes=(0, 1, 100, 5000, 70000)):
     bad[50] ^= 0xFF
     rc, out, unused = inflate_stream(lib, bytes(bad), 15)
     assert rc == Z_DATA_ERROR
+
+
+def dictionary_checks(lib, data, zdict):
+    """deflateSetDictionary / inflateSetDictionary (libz-rs-sys/src/lib.rs:1689, :1121) against system zlib"""
+    import zlib
+    Z_NEED_DICT = 2
+    for wbits in (15, -15):
+        strm = ZStream()
+        assert lib.deflateInit2_(C.byref(strm), 6, 8, wbits, 8, 0, lib.zlibVersion(), C.sizeof(ZStream)) == Z_OK
+        assert lib.deflateSetDictionary(C.byref(strm), zdict, len(zdict)) == Z_OK
+        if wbits > 0:
+            assert strm.adler == zlib.adler32(zdict)
+        src = C.create_string_buffer(data, len(data))
+        cap = len(data) + 4096
+        dst = C.create_string_buffer(cap)
+        strm.next_in, strm.avail_in = C.addressof(src), len(data)
+        strm.next_out, strm.avail_out = C.addressof(dst), cap
+        assert lib.deflate(C.byref(strm), Z_FINISH) == Z_STREAM_END
+        comp = dst.raw[:cap - strm.avail_out]
+        assert lib.deflateEnd(C.byref(strm)) == Z_OK
+        # system zlib decodes it with the same dictionary, and the dictionary was actually used
+        d = zlib.decompressobj(wbits, zdict=zdict)
+        assert d.decompress(comp) + d.flush() == data
+        plain = deflate_stream(lib, data, level=6, wbits=wbits)
+        assert len(comp) < len(plain), (len(comp), len(plain))
+        # our inflate: Z_NEED_DICT for the wrapped stream, then the data; a wrong dictionary is refused
+        ref = zlib.compressobj(6, zlib.DEFLATED, wbits, zdict=zdict)
+        for stream in (comp, ref.compress(data) + ref.flush()):
+            strm = ZStream()
+            assert lib.inflateInit2_(C.byref(strm), wbits, lib.zlibVersion(), C.sizeof(ZStream)) == Z_OK
+            csrc = C.create_string_buffer(stream, len(stream))
+            out = C.create_string_buffer(len(data) + 16)
+            strm.next_in, strm.avail_in = C.addressof(csrc), len(stream)
+            strm.next_out, strm.avail_out = C.addressof(out), len(data) + 16
+            if wbits > 0:
+                assert lib.inflateSetDictionary(C.byref(strm), zdict, len(zdict)) == Z_STREAM_ERROR   # not asked for yet
+                assert lib.inflate(C.byref(strm), Z_NO_FLUSH) == Z_NEED_DICT
+                assert strm.adler == zlib.adler32(zdict)
+                assert lib.inflateSetDictionary(C.byref(strm), b"wrong" + zdict, len(zdict) + 5) == Z_DATA_ERROR
+            assert lib.inflateSetDictionary(C.byref(strm), zdict, len(zdict)) == Z_OK
+            rc = lib.inflate(C.byref(strm), Z_FINISH)
+            assert rc == Z_STREAM_END, rc
+            assert out.raw[:len(data) + 16 - strm.avail_out] == data
+            assert lib.inflateEnd(C.byref(strm)) == Z_OK
+    # gzip streams take no dictionary (deflate.rs:507-509)
+    strm = ZStream()
+    assert lib.deflateInit2_(C.byref(strm), 6, 8, 31, 8, 0, lib.zlibVersion(), C.sizeof(ZStream)) == Z_OK
+    assert lib.deflateSetDictionary(C.byref(strm), zdict, len(zdict)) == Z_STREAM_ERROR
+    assert lib.deflateEnd(C.byref(strm)) == Z_OK

@@ -349,7 +349,8 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                                                          const uint32_t* __restrict__ out_cap,
                                                          uint32_t* __restrict__ out_len, uint32_t* __restrict__ in_used,
                                                          uint32_t* __restrict__ check, int32_t* __restrict__ status,
-                                                         uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ bm_off) {
+                                                         uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ bm_off,
+                                                         const uint32_t* __restrict__ out_hist) {
     __shared__ InfShared Sh;
     InfShared* S = &Sh;
     const uint32_t lane = zmi_lane();
@@ -366,6 +367,9 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
     const uint32_t cap = out_cap[s];
     uint32_t opos = 0;
     int32_t st = ZMI_OK;
+    // preset dictionary (inflateSetDictionary, zlib-rs/src/inflate.rs:2492-2536): `hist` bytes in front of the output
+    // region are history the stream may refer to
+    const uint32_t hist = out_hist ? out_hist[s] : 0u;
     const uint64_t bmo = bm_off[s];
     uint32_t* bm32 = (uint32_t*)(bitmap + (bmo == ~0ull ? 0ull : bmo));   // bit p set: a back-reference starts at output byte p
     if (bmo == ~0ull) {
@@ -382,8 +386,12 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
         else {
             uint32_t cmf = inf_byte(B, 0), flg = inf_byte(B, 1);
             if ((cmf & 0x0Fu) != 8u || (cmf >> 4) > 7u || ((cmf << 8) | flg) % 31u != 0u) st = ZMI_DATA_ERROR;
-            else if (flg & 0x20u) st = 2;  // Z_NEED_DICT: preset dictionaries are not supported in batch mode
             B.ipos = 2;
+            if (st == ZMI_OK && (flg & 0x20u)) {          // FDICT: a DICTID follows (checked by the host against the dictionary)
+                if (hist == 0u) st = 2;                    // Z_NEED_DICT
+                else if (B.n < 6u) st = ZMI_BUF_ERROR;
+                else B.ipos = 6;
+            }
         }
     } else if (kind_found == 2u) {
         if (B.n < 10u) st = ZMI_BUF_ERROR;
@@ -566,8 +574,8 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                 const uint32_t totA = zmi_readlane(inclA, 63u);
                 const uint32_t inclB = zmi_wave_incl_scan(lenB) + totA;
                 const uint32_t exclA = inclA - lenA, exclB = inclB - lenB;
-                const bool farA = onA && TA.kind == 1u && TA.dist > opos + exclA;   // "invalid distance too far back"
-                const bool farB = onB && TB.kind == 1u && TB.dist > opos + exclB;
+                const bool farA = onA && TA.kind == 1u && TA.dist > opos + exclA + hist;   // "invalid distance too far back"
+                const bool farB = onB && TB.kind == 1u && TB.dist > opos + exclB + hist;
                 const bool fullA = onA && lenA != 0u && opos + inclA > cap;
                 const bool fullB = onB && lenB != 0u && opos + inclB > cap;
                 const uint64_t cutA = __ballot(farA || fullA), cutB = __ballot(farB || fullB);
@@ -701,15 +709,16 @@ static __device__ __forceinline__ uint32_t res_inc(uint32_t i, uint32_t d) {
     i += d;
     return i >= RES_RING ? i - RES_RING : i;
 }
-static __device__ __forceinline__ uint4 res_fetch(const uint8_t* dst, uint32_t n_out, uint32_t at, bool aligned16) {
+// bytes [lo, n_out) of dst exist (lo > 0 only with a preset dictionary shorter than its 1 KiB-aligned slot)
+static __device__ __forceinline__ uint4 res_fetch(const uint8_t* dst, uint32_t n_out, uint32_t at, bool aligned16, uint32_t lo) {
     const uint32_t so = at + 16u * zmi_lane();
     uint4 q;
     q.x = q.y = q.z = q.w = 0u;
-    if (aligned16 && so + 16u <= n_out) q = *(const uint4*)(dst + so);
-    else if (so < n_out) {
+    if (aligned16 && so >= lo && so + 16u <= n_out) q = *(const uint4*)(dst + so);
+    else if (so < n_out && so + 16u > lo) {
         uint32_t w[4] = {0u, 0u, 0u, 0u};
         for (uint32_t j = 0; j < 16u; ++j)
-            if (so + j < n_out) w[j >> 2] |= (uint32_t)dst[so + j] << (8u * (j & 3u));
+            if (so + j >= lo && so + j < n_out) w[j >> 2] |= (uint32_t)dst[so + j] << (8u * (j & 3u));
         q.x = w[0]; q.y = w[1]; q.z = w[2]; q.w = w[3];
     }
     return q;
@@ -717,7 +726,7 @@ static __device__ __forceinline__ uint4 res_fetch(const uint8_t* dst, uint32_t n
 // `pre` holds block [loaded, loaded + RES_BLK) when `have` is set: the load of the next block is always in
 // flight while the holes of the current one are filled
 static __device__ __forceinline__ void res_stage(uint8_t* ring, const uint8_t* dst, uint32_t n_out, uint32_t& loaded, uint32_t upto,
-                                                 bool aligned16, uint4& pre, bool& have, uint32_t& rb) {
+                                                 bool aligned16, uint4& pre, bool& have, uint32_t& rb, uint32_t lo) {
     const uint32_t lane = zmi_lane();
     zmi_wave_order();   // ring reads issued so far (write-back of final lines) stay in front of the stores below
     if (upto > loaded + RES_RING - 2048u) {   // a long stretch without holes: only the window matters
@@ -725,11 +734,11 @@ static __device__ __forceinline__ void res_stage(uint8_t* ring, const uint8_t* d
         have = false;
     }
     while (loaded < upto) {
-        if (!have) pre = res_fetch(dst, n_out, loaded, aligned16);
+        if (!have) pre = res_fetch(dst, n_out, loaded, aligned16, lo);
         rb = (loaded / RES_RING) * RES_RING;
         *(uint4*)(ring + (loaded - rb) + 16u * lane) = pre;   // RES_RING is a multiple of RES_BLK: a block never wraps
         loaded += RES_BLK;
-        pre = res_fetch(dst, n_out, loaded, aligned16);
+        pre = res_fetch(dst, n_out, loaded, aligned16, lo);
         have = true;
     }
     rb = (loaded / RES_RING) * RES_RING;
@@ -764,18 +773,25 @@ struct ResChunk {
 __global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, const uint64_t* __restrict__ out_off,
                                                                  const uint32_t* __restrict__ out_len,
                                                                  const uint64_t* __restrict__ bitmap,
-                                                                 const uint64_t* __restrict__ bm_off) {
+                                                                 const uint64_t* __restrict__ bm_off,
+                                                                 const uint32_t* __restrict__ out_hist) {
     ZMI_DYN_SMEM(smem);
     uint8_t* ring = smem;
     ResChunk* C = (ResChunk*)(smem + RES_RING);
     const uint32_t lane = zmi_lane();
     const uint32_t s = zmi_xcd_spread(blockIdx.x, gridDim.x);
     const uint64_t bmo = bm_off[s];
-    const uint32_t n_out = out_len[s];
-    if (bmo == ~0ull || n_out == 0u) return;
+    const uint32_t n_real = out_len[s];
+    if (bmo == ~0ull || n_real == 0u) return;
     const uint64_t* bm = bitmap + bmo;
-    const uint32_t nwords = (n_out + 63u) >> 6;
-    uint8_t* dst = out + out_off[s];
+    const uint32_t nwords = (n_real + 63u) >> 6;
+    // With a preset dictionary of `hist` bytes in front of the output, every position in this kernel is shifted by
+    // `shift` (hist rounded up to the staging block, so that lines stay aligned): the dictionary occupies
+    // [lo, shift), the output [shift, n_out); nothing below `shift` is ever written back.
+    const uint32_t hist = out_hist ? out_hist[s] : 0u;
+    const uint32_t shift = (hist + RES_BLK - 1u) & ~(RES_BLK - 1u), lo = shift - hist;
+    const uint32_t n_out = n_real + shift;
+    uint8_t* dst = out + out_off[s] - shift;
     const bool aligned16 = ((uintptr_t)dst & 15u) == 0u, aligned4 = ((uintptr_t)dst & 3u) == 0u;
 
     uint32_t loaded = 0, wb = 0, rb = 0;
@@ -789,7 +805,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, c
         const uint32_t incl = zmi_wave_incl_scan(pc);
         const uint32_t total = zmi_readlane(incl, 63u);
         if (total == 0u) continue;
-        const uint32_t chunk0 = cbase << 6;
+        const uint32_t chunk0 = (cbase << 6) + shift;
         zmi_wave_order();
         C->cw[lane] = v;
         C->cex[lane] = incl - pc;
@@ -822,7 +838,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, c
                 if (upto > wb) res_writeback(ring, dst, n_out, wb, upto, aligned4, rb);
                 if (fin > wb) wb = fin;
             }
-            if (p_last + 3u > loaded) res_stage(ring, dst, n_out, loaded, p_last + 3u, aligned16, pre, have, rb);
+            if (p_last + 3u > loaded) res_stage(ring, dst, n_out, loaded, p_last + 3u, aligned16, pre, have, rb, lo);
             uint32_t rec = 0;
             if (active) {
                 const uint32_t a = res_ri(p, rb);
@@ -831,7 +847,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, c
             }
             const uint32_t mlen = (rec >> 15) + 3u, md = (rec & 0x7FFFu) + 1u;
             const uint32_t last_end = p_last + zmi_readlane(mlen, nb - 1u);
-            if (last_end > loaded) res_stage(ring, dst, n_out, loaded, last_end, aligned16, pre, have, rb);
+            if (last_end > loaded) res_stage(ring, dst, n_out, loaded, last_end, aligned16, pre, have, rb, lo);
             const uint32_t s0 = p - md;
             const uint32_t e = s0 + (mlen < md ? mlen : md);   // end of the bytes this hole reads
             uint32_t need = 0;                                  // holes of this batch that must be finished first
@@ -950,17 +966,19 @@ __global__ void __launch_bounds__(256) zmi_inflate_verify_kernel(const uint8_t* 
 extern "C" int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n_streams,
                                   uint32_t wrap, uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                                   uint32_t* d_out_len, uint32_t* d_in_used, uint32_t* d_check, int32_t* d_status,
-                                  uint64_t* d_bitmap, uint64_t bitmap_words, uint64_t* d_bm_off, hipStream_t stream) {
+                                  uint64_t* d_bitmap, uint64_t bitmap_words, uint64_t* d_bm_off, const uint32_t* d_out_hist,
+                                  hipStream_t stream) {
     if (n_streams == 0) return 0;
     ZMI_LAUNCH(zmi_inflate_plan_kernel, dim3(1), dim3(1024), 0, stream, d_out_cap, n_streams, bitmap_words, d_bm_off);
     ZMI_LAUNCH(zmi_inflate_clear_kernel, dim3(n_streams), dim3(256), 0, stream, d_out_cap, (const uint64_t*)d_bm_off, d_bitmap);
     ZMI_LAUNCH(zmi_inflate_kernel, dim3(n_streams), dim3(64), 0, stream, d_in, d_in_off, d_in_len, wrap, d_out, d_out_off,
-               d_out_cap, d_out_len, d_in_used, d_check, d_status, d_bitmap, (const uint64_t*)d_bm_off);
+               d_out_cap, d_out_len, d_in_used, d_check, d_status, d_bitmap, (const uint64_t*)d_bm_off, d_out_hist);
     return 0;
 }
 
 extern "C" int zmi_launch_inflate_resolve(uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_len, uint32_t n_streams,
-                                          const uint64_t* d_bitmap, const uint64_t* d_bm_off, hipStream_t stream) {
+                                          const uint64_t* d_bitmap, const uint64_t* d_bm_off, const uint32_t* d_out_hist,
+                                          hipStream_t stream) {
     if (n_streams == 0) return 0;
 #ifndef ZMI_EMU
     static bool attr_set = false;
@@ -970,7 +988,7 @@ extern "C" int zmi_launch_inflate_resolve(uint8_t* d_out, const uint64_t* d_out_
         attr_set = true;
     }
 #endif
-    ZMI_LAUNCH(zmi_inflate_resolve_kernel, dim3(n_streams), dim3(64), RES_RING + sizeof(ResChunk), stream, d_out, d_out_off, d_out_len, d_bitmap, d_bm_off);
+    ZMI_LAUNCH(zmi_inflate_resolve_kernel, dim3(n_streams), dim3(64), RES_RING + sizeof(ResChunk), stream, d_out, d_out_off, d_out_len, d_bitmap, d_bm_off, d_out_hist);
     return 0;
 }
 

@@ -188,10 +188,10 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
     // positions at the start of the shard; they are hashed (producer) but not searched, so every position index
     // in this kernel is "virtual" = hist + position in the segment, and results are stored at index - hist
     uint32_t hist = 0;
-    if (prm.carry && s > 0u) {
-        const uint64_t before = off[s] - off[0];
+    if (prm.carry) {
+        const uint64_t before = off[s] - off[0] + prm.dict_len;   // history bytes of this stream in front of the segment
         const uint32_t reach = prm.max_dist & ~(LZ_T - 1u);
-        hist = before < reach ? (uint32_t)before & ~(LZ_T - 1u) : reach;
+        hist = before < reach ? (uint32_t)before & ~15u : reach;  // multiples of 16 keep the 16-byte load path
     }
     const uint8_t* src = data + off[s] - hist;
     const uint32_t n = len[s] + hist;

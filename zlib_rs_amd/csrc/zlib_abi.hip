@@ -21,7 +21,14 @@
 extern "C" int zmi_deflate_chain_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                      uint32_t n, uint32_t max_len, int level, int strategy, int finish, void* d_out,
                                      uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_);
+extern "C" int zmi_deflate_chain_dict_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                          uint32_t n, uint32_t max_len, int level, int strategy, int finish, uint32_t dict_len,
+                                          void* d_out, uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream);
 extern "C" int zmi_ctx_set_inflate_out_limit(zmi_ctx* c, uint64_t bytes);
+extern "C" int zmi_inflate_batch_dict_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                          uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off,
+                                          const uint32_t* d_out_cap, const uint32_t* d_out_hist, uint32_t* d_out_len,
+                                          int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail, void* stream);
 extern "C" int zmi_inflate_batch_dev_ex(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                         uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                                         uint32_t* d_out_len, int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail,
@@ -119,9 +126,11 @@ size_t segment_bytes() {  // 1 MiB segments; ZMI_ABI_SEGMENT (bytes, multiple of
     return v;
 }
 
-// compress `n` host bytes as consecutive raw-deflate segments; appends the bytes to `out`.
+// compress `n` host bytes as consecutive raw-deflate segments; appends the bytes to `out`.  `hist` (hist_len
+// bytes, may be 0) is what the stream has in front of these bytes: earlier input or a preset dictionary.
 // returns 0 or a negative zlib code
-int gpu_deflate_segments(const uint8_t* in, size_t n, int level, int strategy, bool finish, std::vector<uint8_t>& out) {
+int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_t hist_len, int level, int strategy, bool finish,
+                         std::vector<uint8_t>& out) {
     if (n == 0) {
         if (finish) { out.push_back(0x03); out.push_back(0x00); }  // empty final static block (deflate.rs: 03 00)
         else { const uint8_t m[5] = {0x00, 0x00, 0x00, 0xFF, 0xFF}; out.insert(out.end(), m, m + 5); }
@@ -134,21 +143,25 @@ int gpu_deflate_segments(const uint8_t* in, size_t n, int level, int strategy, b
     const uint32_t nseg = (uint32_t)((n + kSegment - 1) / kSegment);
     std::vector<uint64_t> off(nseg);
     std::vector<uint32_t> len(nseg);
+    const size_t base = (hist_len + 1023u) & ~(size_t)1023u;   // the history sits right in front of the (aligned) input
     for (uint32_t i = 0; i < nseg; ++i) {
-        off[i] = (uint64_t)i * kSegment;
-        len[i] = (uint32_t)((n - off[i] < kSegment) ? n - off[i] : kSegment);
+        const size_t at = (size_t)i * kSegment;
+        off[i] = base + at;
+        len[i] = (uint32_t)((n - at < kSegment) ? n - at : kSegment);
     }
     const uint32_t max_len = len[0];
     const uint64_t stride = zmi_deflate_bound(max_len, ZMI_WRAP_RAW);
     DevBuf d_in, d_off, d_len, d_out, d_olen, d_st;
-    if (!d_in.alloc(n + 16) || !d_off.alloc(nseg * 8) || !d_len.alloc(nseg * 4) || !d_out.alloc((size_t)nseg * stride) ||
+    if (!d_in.alloc(base + n + 16) || !d_off.alloc(nseg * 8) || !d_len.alloc(nseg * 4) || !d_out.alloc((size_t)nseg * stride) ||
         !d_olen.alloc(nseg * 4) || !d_st.alloc(nseg * 4))
         return Z_MEM_ERROR;
-    if (hipMemcpy(d_in.p, in, n, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
+    if (hist_len && hipMemcpy((uint8_t*)d_in.p + base - hist_len, hist, hist_len, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
+    if (hipMemcpy((uint8_t*)d_in.p + base, in, n, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
     if (hipMemcpy(d_off.p, off.data(), nseg * 8, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
     if (hipMemcpy(d_len.p, len.data(), nseg * 4, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
-    if (zmi_deflate_chain_dev(c, d_in.p, (const uint64_t*)d_off.p, (const uint32_t*)d_len.p, nseg, max_len, level, strategy,
-                              finish ? 1 : 0, d_out.p, stride, (uint32_t*)d_olen.p, (int32_t*)d_st.p, nullptr) != 0)
+    if (zmi_deflate_chain_dict_dev(c, d_in.p, (const uint64_t*)d_off.p, (const uint32_t*)d_len.p, nseg, max_len, level, strategy,
+                                   finish ? 1 : 0, (uint32_t)hist_len, d_out.p, stride, (uint32_t*)d_olen.p, (int32_t*)d_st.p,
+                                   nullptr) != 0)
         return Z_MEM_ERROR;
     if (hipDeviceSynchronize() != hipSuccess) return Z_MEM_ERROR;
     std::vector<uint32_t> olen(nseg);
@@ -165,26 +178,32 @@ int gpu_deflate_segments(const uint8_t* in, size_t n, int level, int strategy, b
     return Z_OK;
 }
 
-// one-stream inflate on the GPU.  status: zlib code (0 = complete), detail 1 = need input, 2 = need output
+// one-stream inflate on the GPU.  status: zlib code (0 = complete), detail 1 = need input, 2 = need output.
+// dict / dict_len: preset dictionary (at most its last 32 KiB matter), placed directly in front of the output.
 int gpu_inflate_stream(const uint8_t* in, size_t n, int wrap, std::vector<uint8_t>& out, size_t cap, uint32_t* in_used,
-                       int32_t* status, int32_t* detail) {
+                       int32_t* status, int32_t* detail, const uint8_t* dict = nullptr, size_t dict_len = 0) {
     std::lock_guard<std::mutex> lk(g_mu);
     zmi_ctx* c = abi_ctx();
     if (!c) return Z_MEM_ERROR;
     if (n > 0xFFFFFFF0ull || cap > 0xFFFFFFF0ull) return Z_MEM_ERROR;
+    if (dict_len > 32768u) { dict += dict_len - 32768u; dict_len = 32768u; }
+    const size_t base = (dict_len + 1023u) & ~(size_t)1023u;   // output region stays aligned; the dictionary ends where it starts
     DevBuf d_in, d_out, d_meta;
-    if (!d_in.alloc(n + 16) || !d_out.alloc(cap + 16) || !d_meta.alloc(64)) return Z_MEM_ERROR;
+    if (!d_in.alloc(n + 16) || !d_out.alloc(base + cap + 16) || !d_meta.alloc(64)) return Z_MEM_ERROR;
     if (n && hipMemcpy(d_in.p, in, n, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
-    // meta layout: in_off u64 | out_off u64 | in_len u32 | out_cap u32 | out_len u32 | status i32 | in_used u32 | detail i32
-    uint64_t offs[2] = {0, 0};
+    if (dict_len && hipMemcpy((uint8_t*)d_out.p + base - dict_len, dict, dict_len, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
+    // meta layout: in_off u64 | out_off u64 | in_len u32 | out_cap u32 | out_len u32 | status i32 | in_used u32 | detail i32 | hist u32
+    uint64_t offs[2] = {0, (uint64_t)base};
     uint32_t lens[2] = {(uint32_t)n, (uint32_t)cap};
+    uint32_t hist = (uint32_t)dict_len;
     uint8_t* m = (uint8_t*)d_meta.p;
     if (hipMemcpy(m, offs, 16, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
     if (hipMemcpy(m + 16, lens, 8, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
+    if (hipMemcpy(m + 40, &hist, 4, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
     (void)zmi_ctx_set_inflate_out_limit(c, (uint64_t)cap + 4096u);
-    if (zmi_inflate_batch_dev_ex(c, d_in.p, (const uint64_t*)m, (const uint32_t*)(m + 16), 1, wrap, d_out.p,
-                                 (const uint64_t*)(m + 8), (const uint32_t*)(m + 20), (uint32_t*)(m + 24), (int32_t*)(m + 28),
-                                 (uint32_t*)(m + 32), (int32_t*)(m + 36), nullptr) != 0)
+    if (zmi_inflate_batch_dict_dev(c, d_in.p, (const uint64_t*)m, (const uint32_t*)(m + 16), 1, wrap, d_out.p,
+                                   (const uint64_t*)(m + 8), (const uint32_t*)(m + 20), (const uint32_t*)(m + 40),
+                                   (uint32_t*)(m + 24), (int32_t*)(m + 28), (uint32_t*)(m + 32), (int32_t*)(m + 36), nullptr) != 0)
         return Z_MEM_ERROR;
     if (hipDeviceSynchronize() != hipSuccess) return Z_MEM_ERROR;
     uint32_t res[4];
@@ -195,7 +214,7 @@ int gpu_inflate_stream(const uint8_t* in, size_t n, int wrap, std::vector<uint8_
     *detail = (int32_t)res[3];
     if (olen > cap) olen = (uint32_t)cap;
     out.resize(olen);
-    if (olen && hipMemcpy(out.data(), d_out.p, olen, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR;
+    if (olen && hipMemcpy(out.data(), (const uint8_t*)d_out.p + base, olen, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR;
     return Z_OK;
 }
 
@@ -211,6 +230,9 @@ struct DeflateState {
     uint32_t adler = 1, crc = 0;
     uint64_t total_len = 0;
     int last_flush = -2;
+    std::vector<uint8_t> hist;     // the up to 32 KiB the stream has in front of `in`: earlier input or the preset dictionary
+    bool dict_set = false;         // zlib wrapper: header announces the dictionary (FDICT + DICTID)
+    uint32_t dictid = 0;
 };
 struct InflateState {
     int kind = KIND_INFLATE;
@@ -222,6 +244,10 @@ struct InflateState {
     bool done = false;    // stream decoded completely (out holds everything)
     int error = 0;
     const char* errmsg = nullptr;
+    std::vector<uint8_t> dict;   // preset dictionary (inflateSetDictionary)
+    bool have_dict = false;
+    bool want_dict = false;      // a zlib header with FDICT was seen: inflate() returned Z_NEED_DICT
+    uint32_t dictid = 0;
 };
 
 const char* const kErrMsg[10] = {"need dictionary", "stream end", "", "file error", "stream error", "data error",
@@ -257,17 +283,20 @@ InflateState* istate(z_streamp strm) {
 void put_header(DeflateState* s) {
     if (s->wrap == 1) {  // deflate.rs:1572-1601
         unsigned lf = (s->strategy >= 2 || s->level < 2) ? 0 : (s->level < 6 ? 1 : (s->level == 6 ? 2 : 3));
-        unsigned h = ((8u + ((unsigned)(s->wbits - 8) << 4)) << 8) | (lf << 6);
+        unsigned h = ((8u + ((unsigned)(s->wbits - 8) << 4)) << 8) | (lf << 6) | (s->dict_set ? 0x20u : 0u);
         h += 31 - (h % 31);
         s->pending.push_back((uint8_t)(h >> 8));
         s->pending.push_back((uint8_t)h);
+        if (s->dict_set)   // DICTID: Adler-32 of the dictionary, big-endian (deflate.rs:1596-1600)
+            for (int i = 3; i >= 0; --i) s->pending.push_back((uint8_t)(s->dictid >> (8 * i)));
     } else if (s->wrap == 2) {  // deflate.rs:2574-2627
         const uint8_t g[10] = {0x1F, 0x8B, 8, 0, 0, 0, 0, 0, (uint8_t)(s->level == 9 ? 2 : ((s->strategy >= 2 || s->level < 2) ? 4 : 0)), 3};
         s->pending.insert(s->pending.end(), g, g + 10);
     }
     s->header_done = true;
 }
-int compress_buffered(DeflateState* s, bool finish) {
+// full_flush: the caller asked for Z_FULL_FLUSH -- the data after it must not refer to anything before it
+int compress_buffered(DeflateState* s, bool finish, bool full_flush = false) {
     if (!s->header_done) put_header(s);
     if (s->wrap == 1) s->adler = host_adler_combine(s->adler, host_adler32(1, s->in.data(), s->in.size()), s->in.size());
     if (s->wrap == 2) {
@@ -275,7 +304,14 @@ int compress_buffered(DeflateState* s, bool finish) {
         s->crc = gf2_mul(gf2_xpow8(s->in.size()), s->crc) ^ c2;
     }
     s->total_len += s->in.size();
-    int rc = gpu_deflate_segments(s->in.data(), s->in.size(), s->level, s->strategy, finish, s->pending);
+    int rc = gpu_deflate_segments(s->in.data(), s->in.size(), s->hist.data(), s->hist.size(), s->level, s->strategy, finish, s->pending);
+    // window carry-over to the next call: the last 32 KiB of what the stream has seen (deflate.rs:2739-2752: only
+    // Z_FULL_FLUSH forgets it)
+    if (full_flush || finish) s->hist.clear();
+    else {
+        s->hist.insert(s->hist.end(), s->in.begin(), s->in.end());
+        if (s->hist.size() > 32768u) s->hist.erase(s->hist.begin(), s->hist.end() - 32768);
+    }
     s->in.clear();
     if (rc != Z_OK) return rc;
     if (finish) {
@@ -364,7 +400,7 @@ int deflate(z_streamp strm, int flush) {
     int rc = Z_OK;
     if (!s->finished) {
         if (flush == Z_FINISH) rc = compress_buffered(s, true);
-        else if (flush != Z_NO_FLUSH) { if (!s->in.empty() || s->last_flush != flush || in0) rc = compress_buffered(s, false); }
+        else if (flush != Z_NO_FLUSH) { if (!s->in.empty() || s->last_flush != flush || in0) rc = compress_buffered(s, false, flush == Z_FULL_FLUSH); }
         else if (s->in.size() >= (64u << 20)) rc = compress_buffered(s, false);
         if (rc != Z_OK) { strm->msg = zError(rc); return rc; }
     }
@@ -429,7 +465,23 @@ int deflatePending(z_streamp strm, unsigned* pending, int* bits) {
     if (bits) *bits = 0;
     return Z_OK;
 }
-int deflateSetDictionary(z_streamp, const Bytef*, uInt) { return Z_STREAM_ERROR; }
+int deflateSetDictionary(z_streamp strm, const Bytef* dictionary, uInt dictLength) {
+    // deflate.rs:499-564: not for gzip streams, for zlib streams only before the first deflate() call, never with
+    // input pending; the last 32 KiB of the dictionary become the window in front of the data
+    ZMI_ABI_TRY
+    DeflateState* s = dstate(strm);
+    if (!s || !dictionary) return Z_STREAM_ERROR;
+    if (s->wrap == 2 || (s->wrap == 1 && s->header_done) || !s->in.empty() || s->finished) return Z_STREAM_ERROR;
+    if (s->wrap == 1) {
+        s->dictid = host_adler32(1, dictionary, dictLength);
+        s->dict_set = true;
+        strm->adler = s->dictid;
+    }
+    const uInt keep = dictLength > 32768u ? 32768u : dictLength;
+    s->hist.assign(dictionary + (dictLength - keep), dictionary + dictLength);
+    return Z_OK;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
+}
 int deflatePrime(z_streamp, int, int) { return Z_STREAM_ERROR; }
 
 z_size_t compressBound_z(z_size_t n) { return n + (n == 0) + (n < 9) + ((n + 7) >> 3) + 3 + 6; }
@@ -499,12 +551,26 @@ int inflate(z_streamp strm, int flush) {
         // decode attempts: when new input arrived and the buffer grew by >= 25 % (or the caller finishes)
         bool attempt = in0 != 0 && (flush == Z_FINISH || s->tried_at == 0 || s->in.size() >= s->tried_at + s->tried_at / 4 + 64);
         if (in0 == 0 && flush == Z_FINISH && s->tried_at != s->in.size()) attempt = true;
+        if (s->have_dict && s->tried_at == 0 && !s->in.empty()) attempt = true;   // first call after inflateSetDictionary
         int32_t st = ZMI_E_OK, detail = 1;
         uint32_t used = 0;
+        // a zlib header that announces a preset dictionary: report Z_NEED_DICT with the DICTID in strm->adler and
+        // wait for inflateSetDictionary (inflate.rs:1036-1062)
+        if (!s->have_dict && s->in.size() >= 2 && (s->wrap == ZMI_WRAP_ZLIB || (s->wrap == ZMI_WRAP_AUTO && s->in[0] != 0x1F)) &&
+            (s->in[0] & 0x0F) == 8 && ((s->in[0] << 8 | s->in[1]) % 31) == 0 && (s->in[1] & 0x20)) {
+            strm->next_in += in0; strm->total_in += in0; strm->avail_in = 0;
+            if (s->in.size() < 6) { if (in0 == 0 || flush == Z_FINISH) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; } return Z_OK; }
+            s->dictid = ((uint32_t)s->in[2] << 24) | ((uint32_t)s->in[3] << 16) | ((uint32_t)s->in[4] << 8) | s->in[5];
+            s->want_dict = true;
+            strm->adler = s->dictid;
+            strm->msg = kErrMsg[0];
+            return Z_NEED_DICT;
+        }
         if (attempt && !s->in.empty()) {
             size_t cap = s->in.size() * 4 + 65536;
             for (;;) {
-                int rc = gpu_inflate_stream(s->in.data(), s->in.size(), s->wrap, s->out, cap, &used, &st, &detail);
+                int rc = gpu_inflate_stream(s->in.data(), s->in.size(), s->wrap, s->out, cap, &used, &st, &detail,
+                                            s->have_dict ? s->dict.data() : nullptr, s->have_dict ? s->dict.size() : 0);
                 if (rc != Z_OK) { strm->msg = zError(rc); return rc; }
                 if (st == Z_BUF_ERROR && detail == 2) { cap *= 4; if (cap > 0xF0000000ull) return Z_MEM_ERROR; continue; }
                 break;
@@ -570,7 +636,23 @@ int inflateReset2(z_streamp strm, int windowBits) {
     s->wrap = wrap; s->wbits = wb;
     return inflateReset(strm);
 }
-int inflateSetDictionary(z_streamp, const Bytef*, uInt) { return Z_STREAM_ERROR; }
+int inflateSetDictionary(z_streamp strm, const Bytef* dictionary, uInt dictLength) {
+    // inflate.rs:2492-2536: for a wrapped stream only after inflate() returned Z_NEED_DICT, and the dictionary must
+    // have the announced Adler-32; for a raw stream before any output
+    ZMI_ABI_TRY
+    InflateState* s = istate(strm);
+    if (!s || !dictionary) return Z_STREAM_ERROR;
+    if (s->wrap != ZMI_WRAP_RAW && !s->want_dict) return Z_STREAM_ERROR;
+    if (s->done || s->out_pos != 0) return Z_STREAM_ERROR;
+    if (s->want_dict && host_adler32(1, dictionary, dictLength) != s->dictid) return Z_DATA_ERROR;
+    const uInt keep = dictLength > 32768u ? 32768u : dictLength;
+    s->dict.assign(dictionary + (dictLength - keep), dictionary + dictLength);
+    s->have_dict = true;
+    s->want_dict = false;
+    s->tried_at = 0;   // decode again with what is buffered
+    return Z_OK;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
+}
 int inflateSync(z_streamp) { return Z_STREAM_ERROR; }
 
 int uncompress2_z(Bytef* dest, z_size_t* destLen, const Bytef* source, z_size_t* sourceLen) {

@@ -202,14 +202,14 @@ extern "C" int zmi_gen_shards_dev(zmi_ctx* c, void* d_out, uint64_t seed, uint32
 }
 
 static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
-                            uint32_t max_len, int level, int strategy, int wrap, uint32_t chain_mode, void* d_out,
-                            uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_);
+                            uint32_t max_len, int level, int strategy, int wrap, uint32_t chain_mode, uint32_t dict_len,
+                            void* d_out, uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_);
 
 extern "C" int zmi_deflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                      uint32_t n, uint32_t max_len, int level, int strategy, int wrap, void* d_out,
                                      uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_) {
-    return zmi_deflate_impl(c, d_in, d_in_off, d_in_len, n, max_len, level, strategy, wrap, 0u, d_out, out_stride, d_out_len,
-                            d_status, stream_);
+    return zmi_deflate_impl(c, d_in, d_in_off, d_in_len, n, max_len, level, strategy, wrap, 0u, 0u, d_out, out_stride,
+                            d_out_len, d_status, stream_);
 }
 
 // The shards are consecutive segments of ONE raw deflate stream, contiguous in d_in (d_in_off[i+1] = d_in_off[i] +
@@ -219,13 +219,24 @@ extern "C" int zmi_deflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_
 extern "C" int zmi_deflate_chain_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                      uint32_t n, uint32_t max_len, int level, int strategy, int finish, void* d_out,
                                      uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_) {
-    return zmi_deflate_impl(c, d_in, d_in_off, d_in_len, n, max_len, level, strategy, ZMI_WRAP_RAW, finish ? 1u : 2u, d_out,
-                            out_stride, d_out_len, d_status, stream_);
+    return zmi_deflate_impl(c, d_in, d_in_off, d_in_len, n, max_len, level, strategy, ZMI_WRAP_RAW, finish ? 1u : 2u, 0u,
+                            d_out, out_stride, d_out_len, d_status, stream_);
+}
+
+// As zmi_deflate_chain_dev; additionally the dict_len bytes in front of the first segment (d_in + d_in_off[0] -
+// dict_len ...) are history the stream may match into: a preset dictionary (deflateSetDictionary,
+// zlib-rs/src/deflate.rs:499-564) or the tail of the input compressed by an earlier call on the same stream.
+extern "C" int zmi_deflate_chain_dict_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                          uint32_t n, uint32_t max_len, int level, int strategy, int finish, uint32_t dict_len,
+                                          void* d_out, uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status,
+                                          void* stream_) {
+    return zmi_deflate_impl(c, d_in, d_in_off, d_in_len, n, max_len, level, strategy, ZMI_WRAP_RAW, finish ? 1u : 2u, dict_len,
+                            d_out, out_stride, d_out_len, d_status, stream_);
 }
 
 static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
-                            uint32_t max_len, int level, int strategy, int wrap, uint32_t chain_mode, void* d_out,
-                            uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_) {
+                            uint32_t max_len, int level, int strategy, int wrap, uint32_t chain_mode, uint32_t dict_len,
+                            void* d_out, uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_) {
     if (!c) return zmi_fail(ZMI_E_ARG, "null context");
     if (level == -1) level = 6;
     if (level < 0 || level > 9) return zmi_fail(ZMI_E_ARG, "level must be -1..9");
@@ -283,6 +294,7 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     const char* lazy_env = getenv("ZMI_LAZY");
     if (lazy_env && atoi(lazy_env) >= 0) ep.max_lazy = (uint32_t)atoi(lazy_env);
     lp.carry = chain_mode != 0u ? 1u : 0u;   // segments of one stream: a segment sees the window in front of it
+    lp.dict_len = chain_mode != 0u ? dict_len : 0u;
     if (const char* cv = getenv("ZMI_CARRY")) lp.carry = (chain_mode != 0u && atoi(cv)) ? 1u : 0u;
     lp.far4 = 1024u;
     lp.far5 = 8192u;
@@ -334,10 +346,24 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
 }
 
 // extended form used by the zlib stream ABI: also returns consumed input bytes and why a stream stopped
+extern "C" int zmi_inflate_batch_dict_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                          uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off,
+                                          const uint32_t* d_out_cap, const uint32_t* d_out_hist, uint32_t* d_out_len,
+                                          int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail, void* stream_);
 extern "C" int zmi_inflate_batch_dev_ex(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                         uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                                         uint32_t* d_out_len, int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail,
                                         void* stream_) {
+    return zmi_inflate_batch_dict_dev(c, d_in, d_in_off, d_in_len, n, wrap, d_out, d_out_off, d_out_cap, nullptr, d_out_len,
+                                      d_status, d_in_used, d_detail, stream_);
+}
+
+// d_out_hist (may be null): per stream, the number of bytes directly in front of its output region that hold a
+// preset dictionary (inflateSetDictionary, zlib-rs/src/inflate.rs:2492-2536; at most 32768 are ever referenced)
+extern "C" int zmi_inflate_batch_dict_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                          uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off,
+                                          const uint32_t* d_out_cap, const uint32_t* d_out_hist, uint32_t* d_out_len,
+                                          int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail, void* stream_) {
     if (!c) return zmi_fail(ZMI_E_ARG, "null context");
     if (wrap < ZMI_WRAP_RAW || wrap > ZMI_WRAP_AUTO) return zmi_fail(ZMI_E_ARG, "wrap must be raw/zlib/gzip/auto");
     if (n == 0) return ZMI_E_OK;
@@ -360,12 +386,12 @@ extern "C" int zmi_inflate_batch_dev_ex(zmi_ctx* c, const void* d_in, const uint
     {
         zmi_scope_timer tm(c, ZMI_K_INFLATE, stream);
         int lrc = zmi_launch_inflate((const uint8_t*)d_in, d_in_off, d_in_len, n, (uint32_t)wrap, (uint8_t*)d_out, d_out_off, d_out_cap,
-                                     d_out_len, d_used, d_check, d_status, (uint64_t*)c->inf_bm.p, bm_words, d_bm_off, stream);
+                                     d_out_len, d_used, d_check, d_status, (uint64_t*)c->inf_bm.p, bm_words, d_bm_off, d_out_hist, stream);
         if (lrc) return zmi_fail(ZMI_E_HIP, "inflate launch setup", (hipError_t)lrc);
     }
     {
         zmi_scope_timer tm(c, ZMI_K_RESOLVE, stream);
-        int lrc = zmi_launch_inflate_resolve((uint8_t*)d_out, d_out_off, d_out_len, n, (const uint64_t*)c->inf_bm.p, d_bm_off, stream);
+        int lrc = zmi_launch_inflate_resolve((uint8_t*)d_out, d_out_off, d_out_len, n, (const uint64_t*)c->inf_bm.p, d_bm_off, d_out_hist, stream);
         if (lrc) return zmi_fail(ZMI_E_HIP, "inflate resolve launch setup", (hipError_t)lrc);
     }
     if (wrap != ZMI_WRAP_RAW) {

@@ -19,6 +19,7 @@ struct zmi_lz_params {
     uint32_t hash6;      // 1: chain keyed by a 6-byte hash + one most-recent 4-byte probe; 0: 4-byte hash chain
     uint32_t carry;      // 1: the shards are consecutive segments of one stream; a segment may match into the up to 28 KiB
                          // in front of it (window carry-over, what a preset dictionary is in deflate.rs:499-564)
+    uint32_t dict_len;   // carry only: bytes in front of shard 0 that are history too (preset dictionary / earlier input)
     uint32_t far4, far5; // a 4- (5-) byte match further back than this costs more bits than its literals: dropped
                          // (classic zlib's TOO_FAR idea; the reference itself only drops matches <= 5 under
                          // Z_FILTERED, zlib-rs/src/deflate/algorithm/slow.rs:69-74)
@@ -56,7 +57,9 @@ int zmi_launch_encode(const uint8_t* d_data, const uint64_t* d_off, const uint32
 int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n_streams,
                        uint32_t wrap, uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                        uint32_t* d_out_len, uint32_t* d_in_used, uint32_t* d_check, int32_t* d_status,
-                       uint64_t* d_bitmap, uint64_t bitmap_words, uint64_t* d_bm_off, hipStream_t stream);
+                       uint64_t* d_bitmap, uint64_t bitmap_words, uint64_t* d_bm_off, const uint32_t* d_out_hist,
+                       hipStream_t stream);
 int zmi_launch_inflate_resolve(uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_len, uint32_t n_streams,
-                               const uint64_t* d_bitmap, const uint64_t* d_bm_off, hipStream_t stream);
+                               const uint64_t* d_bitmap, const uint64_t* d_bm_off, const uint32_t* d_out_hist,
+                               hipStream_t stream);
 }
