@@ -20,8 +20,10 @@
  *              is then handed out across as many calls as the caller's buffers need.
  * Preset dictionaries (deflateSetDictionary / inflateSetDictionary, incl. Z_NEED_DICT and the DICTID check) are
  * supported: the dictionary is the window in front of the first segment.
- * Not implemented (Z_STREAM_ERROR): deflatePrime/inflatePrime, inflateBack*, inflateSync, gzip header get/set,
- * gz* file API ("next").
+ * gzip header fields (deflateSetHeader / inflateGetHeader), deflateCopy / inflateCopy, *ResetKeep and *GetDictionary
+ * work on the host-side stream state.
+ * Not implemented (Z_STREAM_ERROR): deflatePrime/inflatePrime, inflateSync; not exported: inflateBack*, inflateMark,
+ * inflateCodesUsed, inflateValidate, inflateUndermine, gz* file API ("next").
  */
 #ifndef ZMI355_ZLIB_H
 #define ZMI355_ZLIB_H
@@ -65,6 +67,24 @@ typedef struct z_stream_s {
     uLong reserved;
 } z_stream;
 typedef z_stream* z_streamp;
+
+/* gzip header information (zlib-rs/src/c_api.rs:174-203) */
+typedef struct gz_header_s {
+    int text;        /* true if compressed data believed to be text */
+    uLong time;      /* modification time */
+    int xflags;      /* extra flags (not used when writing a gzip file) */
+    int os;          /* operating system */
+    Bytef* extra;    /* pointer to extra field or Z_NULL if none */
+    uInt extra_len;  /* extra field length (valid if extra != Z_NULL) */
+    uInt extra_max;  /* space at extra (only when reading header) */
+    Bytef* name;     /* pointer to zero-terminated file name or Z_NULL */
+    uInt name_max;   /* space at name (only when reading header) */
+    Bytef* comment;  /* pointer to zero-terminated comment or Z_NULL */
+    uInt comm_max;   /* space at comment (only when reading header) */
+    int hcrc;        /* true if there was or will be a header crc */
+    int done;        /* true when done reading gzip header (not used when writing a gzip file) */
+} gz_header;
+typedef gz_header* gz_headerp;
 
 /* zlib-rs/src/c_api.rs:132-166 */
 #define Z_NO_FLUSH 0
@@ -115,6 +135,10 @@ uLong deflateBound(z_streamp strm, uLong sourceLen);                            
 z_size_t deflateBound_z(z_streamp strm, z_size_t sourceLen);                             /* lib.rs:1345 */
 int deflatePending(z_streamp strm, unsigned* pending, int* bits);                        /* lib.rs:1757 */
 int deflateSetDictionary(z_streamp strm, const Bytef* dictionary, uInt dictLength);      /* lib.rs:1689 */
+int deflateGetDictionary(z_streamp strm, Bytef* dictionary, uInt* dictLength);           /* lib.rs:2332 */
+int deflateSetHeader(z_streamp strm, gz_headerp head);                                   /* lib.rs:1319 */
+int deflateCopy(z_streamp dest, z_streamp source);                                       /* lib.rs:1837 */
+int deflateResetKeep(z_streamp strm);                                                    /* lib.rs:1627 */
 int deflatePrime(z_streamp strm, int bits, int value);                                   /* lib.rs:1725, unsupported */
 
 int inflateInit_(z_streamp strm, const char* version, int stream_size);                  /* lib.rs:935 */
@@ -124,6 +148,10 @@ int inflateEnd(z_streamp strm);                                                 
 int inflateReset(z_streamp strm);                                                        /* lib.rs:1055 */
 int inflateReset2(z_streamp strm, int windowBits);                                       /* lib.rs:1082 */
 int inflateSetDictionary(z_streamp strm, const Bytef* dictionary, uInt dictLength);      /* lib.rs:1121 */
+int inflateGetDictionary(z_streamp strm, Bytef* dictionary, uInt* dictLength);           /* lib.rs:2287 */
+int inflateGetHeader(z_streamp strm, gz_headerp head);                                   /* lib.rs:1179 */
+int inflateCopy(z_streamp dest, z_streamp source);                                       /* lib.rs:815 */
+int inflateResetKeep(z_streamp strm);                                                    /* lib.rs:1233 */
 int inflateSync(z_streamp strm);                                                         /* lib.rs:884, unsupported */
 
 int compress(Bytef* dest, uLongf* destLen, const Bytef* source, uLong sourceLen);        /* lib.rs:1447 */

@@ -50,3 +50,10 @@ def test_preset_dictionary_and_history_across_calls(monkeypatch):
     chunked = H.deflate_stream(lib, data, level=6, wbits=15, chunk_in=3000, flush_every=1)
     assert zlib.decompress(chunked) == data
     assert len(chunked) < len(one) * 1.06, (len(chunked), len(one))   # ten flushes: markers + block headers only
+
+
+def test_gzip_header_copy_and_dictionary_queries(monkeypatch):
+    monkeypatch.setenv("ZMI_ABI_SEGMENT", "8192")
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    H.header_copy_checks(lib, oracle_lib.load().gen_shard(2, 40000))

@@ -37,6 +37,12 @@ def test_preset_dictionary_and_window_carry_on_gpu():
     assert len(chunked) < len(one) * 1.01, (len(chunked), len(one))
 
 
+def test_gzip_header_copy_and_dictionary_queries_on_gpu():
+    from zlib_rs_amd import _build
+    lib = H.bind(C.CDLL(_build.ABI_LIB))
+    H.header_copy_checks(lib, oracle_lib.load(rebuild=False).gen_shard(2, 1500000))
+
+
 def test_c_program_links_and_roundtrips(tmp_path):
     from zlib_rs_amd import _build
     exe = str(tmp_path / "abi_smoke")

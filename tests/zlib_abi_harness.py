@@ -202,3 +202,102 @@ def dictionary_checks(lib, data, zdict):
     assert lib.deflateInit2_(C.byref(strm), 6, 8, 31, 8, 0, lib.zlibVersion(), C.sizeof(ZStream)) == Z_OK
     assert lib.deflateSetDictionary(C.byref(strm), zdict, len(zdict)) == Z_STREAM_ERROR
     assert lib.deflateEnd(C.byref(strm)) == Z_OK
+
+
+class GzHeader(C.Structure):
+    """gz_header of include/zmi355_zlib.h (zlib-rs/src/c_api.rs:174-203)"""
+    _fields_ = [("text", C.c_int), ("time", C.c_ulong), ("xflags", C.c_int), ("os", C.c_int), ("extra", C.c_void_p),
+                ("extra_len", C.c_uint), ("extra_max", C.c_uint), ("name", C.c_void_p), ("name_max", C.c_uint),
+                ("comment", C.c_void_p), ("comm_max", C.c_uint), ("hcrc", C.c_int), ("done", C.c_int)]
+
+
+def header_copy_checks(lib, data):
+    """deflateSetHeader / inflateGetHeader (lib.rs:1319, :1179), deflateCopy / inflateCopy (lib.rs:1837, :815),
+    deflateGetDictionary / inflateGetDictionary (lib.rs:2332, :2287) against Python's gzip module"""
+    import gzip
+    import io
+    import zlib
+    for f in ("deflateSetHeader", "inflateGetHeader", "deflateCopy", "inflateCopy", "deflateGetDictionary", "inflateGetDictionary",
+              "deflateResetKeep", "inflateResetKeep"):
+        getattr(lib, f).restype = C.c_int
+    lib.deflateSetHeader.argtypes = [C.POINTER(ZStream), C.POINTER(GzHeader)]
+    lib.inflateGetHeader.argtypes = [C.POINTER(ZStream), C.POINTER(GzHeader)]
+    lib.deflateCopy.argtypes = [C.POINTER(ZStream), C.POINTER(ZStream)]
+    lib.inflateCopy.argtypes = [C.POINTER(ZStream), C.POINTER(ZStream)]
+    lib.deflateGetDictionary.argtypes = [C.POINTER(ZStream), C.c_char_p, C.POINTER(C.c_uint)]
+    lib.inflateGetDictionary.argtypes = [C.POINTER(ZStream), C.c_char_p, C.POINTER(C.c_uint)]
+    ver, zs = lib.zlibVersion(), C.sizeof(ZStream)
+
+    # ---- a gzip stream with name, comment, extra field, mtime and header CRC: Python's gzip module reads it
+    name, comment, extra = C.create_string_buffer(b"shard-0001.bin"), C.create_string_buffer(b"made on an MI355X"), C.create_string_buffer(b"AB\x02\x00xy", 6)
+    h = GzHeader(text=1, time=1234567890, os=3, extra=C.addressof(extra), extra_len=6, name=C.addressof(name),
+                 comment=C.addressof(comment), hcrc=1)
+    strm = ZStream()
+    assert lib.deflateInit2_(C.byref(strm), 6, 8, 15, 8, 0, ver, zs) == Z_OK
+    assert lib.deflateSetHeader(C.byref(strm), C.byref(h)) == Z_STREAM_ERROR      # only gzip streams have a header
+    assert lib.deflateEnd(C.byref(strm)) == Z_OK
+    strm = ZStream()
+    assert lib.deflateInit2_(C.byref(strm), 6, 8, 31, 8, 0, ver, zs) == Z_OK
+    assert lib.deflateSetHeader(C.byref(strm), C.byref(h)) == Z_OK
+    src = C.create_string_buffer(data, len(data))
+    cap = len(data) + 4096
+    dst = C.create_string_buffer(cap)
+    half = len(data) // 2
+    strm.next_in, strm.avail_in = C.addressof(src), half
+    strm.next_out, strm.avail_out = C.addressof(dst), cap
+    assert lib.deflate(C.byref(strm), Z_NO_FLUSH) == Z_OK
+    # deflateCopy in the middle of a stream: both copies finish it identically
+    twin = ZStream()
+    assert lib.deflateCopy(C.byref(twin), C.byref(strm)) == Z_OK
+    dlen = C.c_uint(0)
+    dbuf = C.create_string_buffer(32768)
+    assert lib.deflateGetDictionary(C.byref(strm), dbuf, C.byref(dlen)) == Z_OK
+    assert dbuf.raw[:dlen.value] == data[:half][-32768:]
+    outs = []
+    for st_ in (strm, twin):
+        d2 = C.create_string_buffer(cap)
+        st_.next_in, st_.avail_in = C.addressof(src) + half, len(data) - half
+        st_.next_out, st_.avail_out = C.addressof(d2), cap
+        assert lib.deflate(C.byref(st_), Z_FINISH) == Z_STREAM_END
+        outs.append(d2.raw[:cap - st_.avail_out])
+        assert lib.deflateEnd(C.byref(st_)) == Z_OK
+    assert outs[0] == outs[1]
+    comp = outs[0]
+    assert comp[:4] == b"\x1f\x8b\x08\x1f" and comp[4:8] == (1234567890).to_bytes(4, "little")
+    g = gzip.GzipFile(fileobj=io.BytesIO(comp))
+    assert g.read() == data and g.mtime == 1234567890
+    assert zlib.crc32(comp[:comp.index(b"made on an MI355X\x00") + 18]) & 0xFFFF == int.from_bytes(comp[comp.index(b"made on an MI355X\x00") + 18:][:2], "little")
+
+    # ---- inflateGetHeader: our own stream and one written by Python (name + mtime)
+    bio = io.BytesIO()
+    with gzip.GzipFile(filename="from-python.txt", mode="wb", fileobj=bio, mtime=42) as gz:
+        gz.write(data)
+    for stream, want_name, want_time, want_comment in ((comp, b"shard-0001.bin", 1234567890, b"made on an MI355X"), (bio.getvalue(), b"from-python.txt", 42, None)):
+        nbuf, cbuf, xbuf = C.create_string_buffer(64), C.create_string_buffer(64), C.create_string_buffer(16)
+        hh = GzHeader(extra=C.addressof(xbuf), extra_max=16, name=C.addressof(nbuf), name_max=64, comment=C.addressof(cbuf), comm_max=64)
+        strm = ZStream()
+        assert lib.inflateInit2_(C.byref(strm), 31, ver, zs) == Z_OK
+        assert lib.inflateGetHeader(C.byref(strm), C.byref(hh)) == Z_OK and hh.done == 0
+        csrc = C.create_string_buffer(stream, len(stream))
+        out = C.create_string_buffer(len(data) + 16)
+        strm.next_in, strm.avail_in = C.addressof(csrc), len(stream)
+        strm.next_out, strm.avail_out = C.addressof(out), len(data) + 16
+        assert lib.inflate(C.byref(strm), Z_FINISH) == Z_STREAM_END
+        assert out.raw[:len(data)] == data
+        assert hh.done == 1 and hh.time == want_time and nbuf.value == want_name
+        if want_comment is not None:
+            assert cbuf.value == want_comment and hh.hcrc == 1 and hh.extra_len == 6 and xbuf.raw[:6] == b"AB\x02\x00xy" and hh.text == 1
+        else:
+            assert not hh.comment
+        # inflateCopy of a finished stream and the window it reports
+        twin = ZStream()
+        assert lib.inflateCopy(C.byref(twin), C.byref(strm)) == Z_OK
+        dlen = C.c_uint(0)
+        assert lib.inflateGetDictionary(C.byref(twin), dbuf, C.byref(dlen)) == Z_OK
+        assert dbuf.raw[:dlen.value] == data[-32768:]
+        assert lib.inflateEnd(C.byref(twin)) == Z_OK and lib.inflateEnd(C.byref(strm)) == Z_OK
+    # a zlib stream has no gzip header: Z_STREAM_ERROR (inflate.rs:2676-2678)
+    strm = ZStream()
+    assert lib.inflateInit2_(C.byref(strm), 15, ver, zs) == Z_OK
+    assert lib.inflateGetHeader(C.byref(strm), C.byref(GzHeader())) == Z_STREAM_ERROR
+    assert lib.inflateResetKeep(C.byref(strm)) == Z_OK and lib.inflateEnd(C.byref(strm)) == Z_OK

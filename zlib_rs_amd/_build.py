@@ -31,7 +31,9 @@ def build(force=False, verbose=False):
     subprocess.run(cmd, check=True)
     # the zlib-named symbols (deflate, inflate, crc32 ...) live in their own library so that merely
     # loading the engine never interposes the system libz of the process
-    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", ABI_LIB] + \
+    # -Bsymbolic-functions: calls between the zlib-named entry points (inflateResetKeep -> inflateReset, ...) must stay
+    # inside this library even when the process has the system libz loaded in front of it
+    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic-functions", "-o", ABI_LIB] + \
           [os.path.join(CSRC, s) for s in ABI_SOURCES] + ["-L" + HERE, "-lzmi355", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))

@@ -233,6 +233,7 @@ struct DeflateState {
     std::vector<uint8_t> hist;     // the up to 32 KiB the stream has in front of `in`: earlier input or the preset dictionary
     bool dict_set = false;         // zlib wrapper: header announces the dictionary (FDICT + DICTID)
     uint32_t dictid = 0;
+    gz_headerp gzhead = nullptr;   // deflateSetHeader: read when the header is written, as the reference does
 };
 struct InflateState {
     int kind = KIND_INFLATE;
@@ -248,7 +249,44 @@ struct InflateState {
     bool have_dict = false;
     bool want_dict = false;      // a zlib header with FDICT was seen: inflate() returned Z_NEED_DICT
     uint32_t dictid = 0;
+    gz_headerp gzhead = nullptr; // inflateGetHeader: filled as soon as the buffered input holds the whole gzip header
+    std::vector<uint8_t> window; // the last 32 KiB handed to the caller (inflateGetDictionary)
 };
+
+// fills *h from a gzip header at the start of `in` (inflate.rs:1063-1275); returns false while the header is incomplete
+bool parse_gzip_header(const std::vector<uint8_t>& in, gz_header* h) {
+    if (in.size() < 10) return false;
+    const uint8_t flg = in[3];
+    size_t p = 10;
+    size_t xoff = 0, xlen = 0, noff = 0, coff = 0;
+    if (flg & 4) {
+        if (p + 2 > in.size()) return false;
+        xlen = in[p] | ((size_t)in[p + 1] << 8);
+        xoff = p + 2;
+        p += 2 + xlen;
+        if (p > in.size()) return false;
+    }
+    if (flg & 8) { noff = p; while (p < in.size() && in[p]) ++p; if (p >= in.size()) return false; ++p; }
+    if (flg & 16) { coff = p; while (p < in.size() && in[p]) ++p; if (p >= in.size()) return false; ++p; }
+    if (flg & 2) { if (p + 2 > in.size()) return false; p += 2; }
+    h->text = flg & 1;
+    h->time = (uLong)(in[4] | ((uint32_t)in[5] << 8) | ((uint32_t)in[6] << 16) | ((uint32_t)in[7] << 24));
+    h->xflags = in[8];
+    h->os = in[9];
+    h->hcrc = (flg >> 1) & 1;
+    h->extra_len = (uInt)xlen;
+    if ((flg & 4) && h->extra) memcpy(h->extra, in.data() + xoff, xlen < h->extra_max ? xlen : h->extra_max);
+    auto copy_str = [&](size_t off, Bytef* dst, uInt cap) {
+        if (!dst || cap == 0) return;
+        size_t n = strlen((const char*)in.data() + off) + 1;   // the terminator is stored when it fits (inflate.rs:1176-1222)
+        memcpy(dst, in.data() + off, n < cap ? n : cap);
+    };
+    if (flg & 8) copy_str(noff, h->name, h->name_max); else h->name = nullptr;
+    if (flg & 16) copy_str(coff, h->comment, h->comm_max); else h->comment = nullptr;
+    h->done = 1;
+    return true;
+}
+
 
 const char* const kErrMsg[10] = {"need dictionary", "stream end", "", "file error", "stream error", "data error",
                                  "insufficient memory", "buffer error", "incompatible version", ""};
@@ -289,9 +327,32 @@ void put_header(DeflateState* s) {
         s->pending.push_back((uint8_t)h);
         if (s->dict_set)   // DICTID: Adler-32 of the dictionary, big-endian (deflate.rs:1596-1600)
             for (int i = 3; i >= 0; --i) s->pending.push_back((uint8_t)(s->dictid >> (8 * i)));
-    } else if (s->wrap == 2) {  // deflate.rs:2574-2627
-        const uint8_t g[10] = {0x1F, 0x8B, 8, 0, 0, 0, 0, 0, (uint8_t)(s->level == 9 ? 2 : ((s->strategy >= 2 || s->level < 2) ? 4 : 0)), 3};
-        s->pending.insert(s->pending.end(), g, g + 10);
+    } else if (s->wrap == 2) {  // deflate.rs:2574-2700
+        const uint8_t xfl = (uint8_t)(s->level == 9 ? 2 : ((s->strategy >= 2 || s->level < 2) ? 4 : 0));
+        const size_t at = s->pending.size();
+        if (!s->gzhead) {
+            const uint8_t g[10] = {0x1F, 0x8B, 8, 0, 0, 0, 0, 0, xfl, 3};
+            s->pending.insert(s->pending.end(), g, g + 10);
+        } else {
+            const gz_header& h = *s->gzhead;
+            const uint8_t flg = (uint8_t)((h.text ? 1 : 0) | (h.hcrc ? 2 : 0) | (h.extra ? 4 : 0) | (h.name ? 8 : 0) | (h.comment ? 16 : 0));
+            const uint32_t t = (uint32_t)h.time;
+            const uint8_t g[10] = {0x1F, 0x8B, 8, flg, (uint8_t)t, (uint8_t)(t >> 8), (uint8_t)(t >> 16), (uint8_t)(t >> 24), xfl, (uint8_t)h.os};
+            s->pending.insert(s->pending.end(), g, g + 10);
+            if (h.extra) {
+                const uint32_t xl = h.extra_len & 0xFFFFu;
+                s->pending.push_back((uint8_t)xl);
+                s->pending.push_back((uint8_t)(xl >> 8));
+                s->pending.insert(s->pending.end(), h.extra, h.extra + xl);
+            }
+            if (h.name) s->pending.insert(s->pending.end(), h.name, h.name + strlen((const char*)h.name) + 1);
+            if (h.comment) s->pending.insert(s->pending.end(), h.comment, h.comment + strlen((const char*)h.comment) + 1);
+            if (h.hcrc) {   // CRC-16 = low half of the CRC-32 of the header so far
+                const uint32_t c = host_crc32(0, s->pending.data() + at, s->pending.size() - at);
+                s->pending.push_back((uint8_t)c);
+                s->pending.push_back((uint8_t)(c >> 8));
+            }
+        }
     }
     s->header_done = true;
 }
@@ -483,6 +544,35 @@ int deflateSetDictionary(z_streamp strm, const Bytef* dictionary, uInt dictLengt
     ZMI_ABI_CATCH(Z_MEM_ERROR)
 }
 int deflatePrime(z_streamp, int, int) { return Z_STREAM_ERROR; }
+int deflateGetDictionary(z_streamp strm, Bytef* dictionary, uInt* dictLength) {   // deflate.rs: the current window
+    DeflateState* s = dstate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    std::vector<uint8_t> w(s->hist);
+    w.insert(w.end(), s->in.begin(), s->in.end());
+    if (w.size() > 32768u) w.erase(w.begin(), w.end() - 32768);
+    if (dictionary && !w.empty()) memcpy(dictionary, w.data(), w.size());
+    if (dictLength) *dictLength = (uInt)w.size();
+    return Z_OK;
+}
+int deflateSetHeader(z_streamp strm, gz_headerp head) {   // deflate.rs:3145-3155
+    DeflateState* s = dstate(strm);
+    if (!s || s->wrap != 2) return Z_STREAM_ERROR;
+    s->gzhead = head;
+    return Z_OK;
+}
+int deflateCopy(z_streamp dest, z_streamp source) {   // deflate.rs: a deep copy of the stream state
+    ZMI_ABI_TRY
+    DeflateState* s = dstate(source);
+    if (!s || !dest) return Z_STREAM_ERROR;
+    *dest = *source;
+    DeflateState* d = alloc_state<DeflateState>(dest);
+    if (!d) { dest->state = nullptr; return Z_MEM_ERROR; }
+    *d = *s;
+    dest->state = (internal_state*)d;
+    return Z_OK;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
+}
+int deflateResetKeep(z_streamp strm) { return deflateReset(strm); }   // no window allocation to keep here
 
 z_size_t compressBound_z(z_size_t n) { return n + (n == 0) + (n < 9) + ((n + 7) >> 3) + 3 + 6; }
 uLong compressBound(uLong n) { return (uLong)compressBound_z(n); }
@@ -552,6 +642,10 @@ int inflate(z_streamp strm, int flush) {
         bool attempt = in0 != 0 && (flush == Z_FINISH || s->tried_at == 0 || s->in.size() >= s->tried_at + s->tried_at / 4 + 64);
         if (in0 == 0 && flush == Z_FINISH && s->tried_at != s->in.size()) attempt = true;
         if (s->have_dict && s->tried_at == 0 && !s->in.empty()) attempt = true;   // first call after inflateSetDictionary
+        if (s->gzhead && s->gzhead->done == 0 && s->in.size() >= 2) {
+            if (s->in[0] == 0x1F && s->in[1] == 0x8B && (s->wrap == ZMI_WRAP_GZIP || s->wrap == ZMI_WRAP_AUTO)) (void)parse_gzip_header(s->in, s->gzhead);
+            else s->gzhead->done = -1;   // not a gzip stream (inflate.rs:1024-1028)
+        }
         int32_t st = ZMI_E_OK, detail = 1;
         uint32_t used = 0;
         // a zlib header that announces a preset dictionary: report Z_NEED_DICT with the DICTID in strm->adler and
@@ -598,6 +692,12 @@ int inflate(z_streamp strm, int flush) {
             if (in0 == 0 || flush == Z_FINISH) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; }  // inflate.rs:2450-2456
             return Z_OK;
         }
+    }
+    {
+        size_t n = s->out.size() - s->out_pos;
+        if (n > strm->avail_out) n = strm->avail_out;
+        s->window.insert(s->window.end(), s->out.begin() + s->out_pos, s->out.begin() + s->out_pos + n);
+        if (s->window.size() > 32768u) s->window.erase(s->window.begin(), s->window.end() - 32768);
     }
     drain(strm, s->out, s->out_pos);
     if (s->out.empty()) return Z_STREAM_END;
@@ -654,6 +754,37 @@ int inflateSetDictionary(z_streamp strm, const Bytef* dictionary, uInt dictLengt
     ZMI_ABI_CATCH(Z_MEM_ERROR)
 }
 int inflateSync(z_streamp) { return Z_STREAM_ERROR; }
+int inflateGetDictionary(z_streamp strm, Bytef* dictionary, uInt* dictLength) {   // inflate.rs: the sliding window so far
+    InflateState* s = istate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    // what the stream has produced up to the caller's read position, preceded by the preset dictionary
+    std::vector<uint8_t> w(s->dict);
+    w.insert(w.end(), s->window.begin(), s->window.end());
+    if (w.size() > 32768u) w.erase(w.begin(), w.end() - 32768);
+    if (dictionary && !w.empty()) memcpy(dictionary, w.data(), w.size());
+    if (dictLength) *dictLength = (uInt)w.size();
+    return Z_OK;
+}
+int inflateGetHeader(z_streamp strm, gz_headerp head) {   // inflate.rs: only for streams that may be gzip
+    InflateState* s = istate(strm);
+    if (!s || s->wrap == ZMI_WRAP_RAW || s->wrap == ZMI_WRAP_ZLIB) return Z_STREAM_ERROR;
+    s->gzhead = head;
+    if (head) head->done = 0;
+    return Z_OK;
+}
+int inflateCopy(z_streamp dest, z_streamp source) {
+    ZMI_ABI_TRY
+    InflateState* s = istate(source);
+    if (!s || !dest) return Z_STREAM_ERROR;
+    *dest = *source;
+    InflateState* d = alloc_state<InflateState>(dest);
+    if (!d) { dest->state = nullptr; return Z_MEM_ERROR; }
+    *d = *s;
+    dest->state = (internal_state*)d;
+    return Z_OK;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
+}
+int inflateResetKeep(z_streamp strm) { return inflateReset(strm); }
 
 int uncompress2_z(Bytef* dest, z_size_t* destLen, const Bytef* source, z_size_t* sourceLen) {
     ZMI_ABI_TRY
