@@ -16,8 +16,11 @@
  *              28 KiB in front of it, like a preset dictionary (deflate.rs:499-564).  Across
  *              separate flushes by the caller the history starts empty (Z_FULL_FLUSH semantics,
  *              deflate.rs:2739-2752).
- *   inflate()  buffers input and decodes once the stream is complete (one wave per stream); output
- *              is then handed out across as many calls as the caller's buffers need.
+ *   inflate()  buffers input and decodes what it has whenever the input grew by a quarter (or the
+ *              caller finishes): the bytes decoded so far are final and handed out at once, so output
+ *              arrives while input is still being fed (each attempt decodes from the start of the
+ *              stream on the GPU; geometric growth keeps the total work linear).  The bytes in front
+ *              of a corrupt spot are delivered before Z_DATA_ERROR, as the reference does.
  * Preset dictionaries (deflateSetDictionary / inflateSetDictionary, incl. Z_NEED_DICT and the DICTID check) are
  * supported: the dictionary is the window in front of the first segment.
  * gzip header fields (deflateSetHeader / inflateGetHeader), deflateCopy / inflateCopy, *ResetKeep and *GetDictionary

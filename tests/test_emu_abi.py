@@ -57,3 +57,9 @@ def test_gzip_header_copy_and_dictionary_queries(monkeypatch):
     zmi_ctypes.load_emu()
     lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
     H.header_copy_checks(lib, oracle_lib.load().gen_shard(2, 40000))
+
+
+def test_inflate_hands_out_output_progressively():
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    H.progressive_inflate_checks(lib, oracle_lib.load().gen_shard(0, 60000))

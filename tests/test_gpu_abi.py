@@ -43,6 +43,12 @@ def test_gzip_header_copy_and_dictionary_queries_on_gpu():
     H.header_copy_checks(lib, oracle_lib.load(rebuild=False).gen_shard(2, 1500000))
 
 
+def test_inflate_hands_out_output_progressively_on_gpu():
+    from zlib_rs_amd import _build
+    lib = H.bind(C.CDLL(_build.ABI_LIB))
+    H.progressive_inflate_checks(lib, oracle_lib.load(rebuild=False).gen_shard(0, 2 << 20))
+
+
 def test_c_program_links_and_roundtrips(tmp_path):
     from zlib_rs_amd import _build
     exe = str(tmp_path / "abi_smoke")

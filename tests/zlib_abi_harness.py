@@ -301,3 +301,47 @@ def header_copy_checks(lib, data):
     assert lib.inflateInit2_(C.byref(strm), 15, ver, zs) == Z_OK
     assert lib.inflateGetHeader(C.byref(strm), C.byref(GzHeader())) == Z_STREAM_ERROR
     assert lib.inflateResetKeep(C.byref(strm)) == Z_OK and lib.inflateEnd(C.byref(strm)) == Z_OK
+
+
+def progressive_inflate_checks(lib, data):
+    """output is handed out as the input arrives (not only once the stream is complete), and the bytes in front of a
+    corrupt spot are delivered before Z_DATA_ERROR, as the reference's streaming state machine does"""
+    import zlib
+    comp = zlib.compress(data, 6)
+    ver, zs = lib.zlibVersion(), C.sizeof(ZStream)
+    strm = ZStream()
+    assert lib.inflateInit2_(C.byref(strm), 15, ver, zs) == Z_OK
+    csrc = C.create_string_buffer(comp, len(comp))
+    out = C.create_string_buffer(len(data) + 16)
+    half = len(comp) // 2
+    strm.next_in, strm.avail_in = C.addressof(csrc), half
+    strm.next_out, strm.avail_out = C.addressof(out), len(data) + 16
+    assert lib.inflate(C.byref(strm), Z_NO_FLUSH) == Z_OK
+    got = strm.total_out
+    assert 0 < got < len(data) and out.raw[:got] == data[:got]          # roughly half of the output is there already
+    assert got > len(data) // 4
+    strm.next_in, strm.avail_in = C.addressof(csrc) + half, len(comp) - half
+    assert lib.inflate(C.byref(strm), Z_FINISH) == Z_STREAM_END
+    assert strm.total_out == len(data) and out.raw[:len(data)] == data
+    assert lib.inflateEnd(C.byref(strm)) == Z_OK
+    # corrupt the second half: the first part still comes out, then the error
+    bad = bytearray(comp)
+    bad[(len(comp) * 3) // 4] ^= 0xFF
+    bad = bytes(bad)
+    strm = ZStream()
+    assert lib.inflateInit2_(C.byref(strm), 15, ver, zs) == Z_OK
+    bsrc = C.create_string_buffer(bad, len(bad))
+    strm.next_in, strm.avail_in = C.addressof(bsrc), len(bad)
+    small = C.create_string_buffer(4096)
+    collected = bytearray()
+    rc = Z_OK
+    for _ in range(len(data) // 4096 + 8):
+        strm.next_out, strm.avail_out = C.addressof(small), 4096
+        rc = lib.inflate(C.byref(strm), Z_NO_FLUSH)
+        collected += small.raw[:4096 - strm.avail_out]
+        if rc != Z_OK:
+            break
+    assert rc == Z_DATA_ERROR, rc
+    # everything decodable came out first; the part in front of the flipped byte is the original data
+    assert len(collected) > len(data) // 2 and bytes(collected[:len(data) // 2]) == data[:len(data) // 2]
+    assert lib.inflateEnd(C.byref(strm)) == Z_OK

@@ -633,9 +633,9 @@ int inflate(z_streamp strm, int flush) {
     ZMI_ABI_TRY
     InflateState* s = istate(strm);
     if (!s || !strm->next_out || (strm->avail_in != 0 && !strm->next_in)) return Z_STREAM_ERROR;
-    if (s->error) { strm->msg = s->errmsg; return s->error; }
+    if (s->error && s->out_pos >= s->out.size()) { strm->msg = s->errmsg; return s->error; }
     const uInt in0 = strm->avail_in, out0 = strm->avail_out;
-    if (!s->done) {
+    if (!s->done && !s->error) {
         const size_t before = s->in.size();
         if (strm->avail_in) s->in.insert(s->in.end(), strm->next_in, strm->next_in + strm->avail_in);
         // decode attempts: when new input arrived and the buffer grew by >= 25 % (or the caller finishes)
@@ -680,29 +680,34 @@ int inflate(z_streamp strm, int flush) {
                 strm->total_in += in0 - unused;
                 strm->avail_in = (uInt)unused;
             } else if (st == Z_DATA_ERROR || st == Z_NEED_DICT) {
+                // the bytes decoded in front of the error are valid output: they are handed out first, as the
+                // reference does, and the error is reported once they are gone
                 s->error = st;
                 s->errmsg = st == Z_DATA_ERROR ? "invalid or corrupt deflate stream" : kErrMsg[0];
-                strm->msg = s->errmsg;
                 strm->next_in += in0; strm->total_in += in0; strm->avail_in = 0;
-                return st;
             }
+            // st == Z_BUF_ERROR, more input needed: s->out holds the prefix decoded so far.  It is final (a later
+            // attempt with more input reproduces it and appends), so it can be handed out now.
         }
-        if (!s->done) {
-            strm->next_in += in0; strm->total_in += in0; strm->avail_in = 0;
-            if (in0 == 0 || flush == Z_FINISH) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; }  // inflate.rs:2450-2456
-            return Z_OK;
-        }
+        if (!s->done && !s->error) { strm->next_in += in0; strm->total_in += in0; strm->avail_in = 0; }
     }
-    {
-        size_t n = s->out.size() - s->out_pos;
-        if (n > strm->avail_out) n = strm->avail_out;
+    size_t n = s->out.size() > s->out_pos ? s->out.size() - s->out_pos : 0;
+    if (n > strm->avail_out) n = strm->avail_out;
+    if (n) {
+        memcpy(strm->next_out, s->out.data() + s->out_pos, n);
         s->window.insert(s->window.end(), s->out.begin() + s->out_pos, s->out.begin() + s->out_pos + n);
         if (s->window.size() > 32768u) s->window.erase(s->window.begin(), s->window.end() - 32768);
+        s->out_pos += n;
+        strm->next_out += n;
+        strm->avail_out -= (uInt)n;
+        strm->total_out += n;
     }
-    drain(strm, s->out, s->out_pos);
-    if (s->out.empty()) return Z_STREAM_END;
+    const bool drained = s->out_pos >= s->out.size();
+    if (s->done && drained) return Z_STREAM_END;
+    if (s->error && drained) { strm->msg = s->errmsg; return s->error; }
     if (in0 == strm->avail_in && out0 == strm->avail_out) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; }
-    return flush == Z_FINISH ? Z_BUF_ERROR : Z_OK;
+    if (flush == Z_FINISH && (s->done || (!s->done && drained))) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; }  // inflate.rs:2450-2456
+    return Z_OK;
     ZMI_ABI_CATCH(Z_MEM_ERROR)
 }
 int inflateEnd(z_streamp strm) {
