@@ -51,8 +51,10 @@
 struct LzCtl {
     uint32_t ready;  // positions < ready are searchable (chain built, look-ahead bytes loaded)
     uint32_t next;   // next unclaimed position
-    uint32_t pad[2];
+    uint32_t atok;   // two producers: the tile whose hash-head atomics may be issued next (keeps them in position order)
+    uint32_t pad;
     uint32_t wmin[LZ_NW];  // per wave: lower bound of its oldest in-flight position
+    uint32_t stored[2];    // per producer wave: input bytes [.., stored) of its last chunk are in the ring
 };
 
 #ifdef ZMI_EMU
@@ -103,7 +105,8 @@ static __device__ __forceinline__ void lz_store_chunk(uint8_t* win, uint32_t pos
 //             hash; its answer for position p is parked in a small ring (c4) until p is searched.
 template <bool H6>
 static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_t* prev, uint32_t* head, uint32_t* head4,
-                                                     uint16_t* c4, uint32_t tile, uint32_t n, uint32_t max_dist) {
+                                                     uint16_t* c4, uint32_t tile, uint32_t n, uint32_t max_dist, LzCtl* ctl,
+                                                     uint32_t producers) {
     const uint32_t lane = zmi_lane();
     uint32_t hv[LZ_SUB], h4[LZ_SUB];
 #pragma unroll
@@ -124,6 +127,10 @@ static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_
             hv[s] = (v * 2654435761u) >> (32 - LZ_HBITS);  // multiplier as hash_calc.rs:30-33
             h4[s] = 0;
         }
+    }
+    // two producers hash alternate tiles concurrently; the inserts themselves must happen in position order
+    if (producers > 1u) {
+        while (lz_ld_acq(&ctl->atok) != tile) lz_pause();
     }
     if ((tile + 1u) * LZ_T + 6u <= n) {
         // every position of the tile has its 6 bytes: no per-lane bounds checks (all tiles but the last)
@@ -146,6 +153,8 @@ static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_
             zmi_wave_sync();
         }
     }
+    // the LDS executes a wave's operations in order: once this store is visible the atomics above have been applied
+    if (producers > 1u && lane == 0) lz_st_rel(&ctl->atok, tile + 1u);
 #pragma unroll
     for (uint32_t s = 0; s < LZ_SUB; ++s) {
         uint32_t p = tile * LZ_T + s * 64u + lane;
@@ -202,30 +211,30 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
 
     for (uint32_t i = t; i < LZ_HSIZE; i += 1024u) head[i] = 0u;
     for (uint32_t i = t; i < LZ_H4SIZE; i += 1024u) head4[i] = 0u;
-    if (t == 0) { ctl->ready = 0u; ctl->next = hist; }
+    if (t == 0) { ctl->ready = 0u; ctl->next = hist; ctl->atok = 0u; ctl->stored[0] = 0u; ctl->stored[1] = 0u; }
     if (t < LZ_NW) ctl->wmin[t] = 0xFFFFFFFFu;
     __syncthreads();
 
-    if (wave == 0) {
-        // ---------------- producer ----------------
-        // The whole workgroup waits on this one wave and it shares its SIMD with three searcher waves:
-        // raise its issue priority so the arbiter serves it first.
-#ifndef ZMI_EMU
-        __builtin_amdgcn_s_setprio(3);
-#endif
-        // The HBM load of the chunk needed NEXT round is issued at the top of the round and consumed
-        // at the top of the following one, so its latency hides behind the throttle wait and the
-        // hash inserts of the current tile.
-        for (uint32_t c = lane * 16u; c < LZ_T + 16u; c += 1024u) {
-            zmi_b16 v0 = zmi_ld16(src + c, c < n ? n - c : 0u, aligned);
-            lz_store_chunk(win, c, v0);
+    const uint32_t P = prm.producers > 1u ? 2u : 1u;
+    if (wave < P) {
+        // ---------------- producer(s) ----------------
+        // Tile k is built by producer wave k mod P.  With P = 2 (the low levels, where the searchers outrun a single
+        // producer) the two waves overlap their loads, hashing and link stores; only the hash-head atomics are
+        // serialised in position order (ctl->atok) and the ready frontier is published in tile order.
+        // The HBM load of the chunk a wave needs for its NEXT tile is issued at the top of the round and consumed at
+        // the top of the following one, so its latency hides behind the throttle wait and the hash inserts.
+        if (wave == 0) {
+            for (uint32_t c = lane * 16u; c < LZ_T + 16u; c += 1024u) {
+                zmi_b16 v0 = zmi_ld16(src + c, c < n ? n - c : 0u, aligned);
+                lz_store_chunk(win, c, v0);
+            }
         }
-        uint32_t cpos = LZ_T + 16u + lane * 16u;   // chunk that round 0 must make resident
+        uint32_t cpos = (wave + 1u) * LZ_T + 16u + lane * 16u;   // chunk that this wave's first round must make resident
         zmi_b16 cur = zmi_ld16(src + cpos, cpos < n ? n - cpos : 0u, aligned);
         uint32_t cached_min = 0u;
-        for (uint32_t k = 0; k < ntiles; ++k) {
-            const uint32_t npos = cpos + LZ_T;
-            zmi_b16 nxt = zmi_ld16(src + npos, npos < n ? n - npos : 0u, aligned);  // for round k+1
+        for (uint32_t k = wave; k < ntiles; k += P) {
+            const uint32_t npos = cpos + P * LZ_T;
+            zmi_b16 nxt = zmi_ld16(src + npos, npos < n ? n - npos : 0u, aligned);  // for this wave's next tile
             const uint32_t E = (k + 2u) * LZ_T + 16u;  // bytes [0, E) must be resident after this round
             // ring throttle: byte E-1 lands on the slot of byte E-1-32768, which the oldest in-flight
             // search (position q) may still read while q - max_dist <= E-1-32768
@@ -245,10 +254,19 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
             }
             lz_store_chunk(win, cpos, cur);
             zmi_wave_sync();
-            lz_build_tile<H6>(win, prev, head, head4, c4, k, n, prm.max_dist);
+            if (P > 1u) {
+                if (lane == 0) lz_st_rel(&ctl->stored[wave], E);
+                // hashing tile k reads bytes up to (k+1)*T + 7: the chunk the other wave stored in its round k-1
+                if (k > 0u) while (lz_ld_acq(&ctl->stored[wave ^ 1u]) < (k + 1u) * LZ_T + 16u) lz_pause();
+            }
+            lz_build_tile<H6>(win, prev, head, head4, c4, k, n, prm.max_dist, ctl, P);
             zmi_wave_sync();
             uint32_t r = (k + 1u) * LZ_T;
             if (r > n) r = n;
+            if (P > 1u) {   // publish in tile order
+                const uint32_t before = k * LZ_T < n ? k * LZ_T : n;
+                while (lz_ld_acq(&ctl->ready) < before) lz_pause();
+            }
             if (lane == 0) lz_st_rel(&ctl->ready, r);
             cur = nxt;
             cpos = npos;

@@ -296,6 +296,8 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     lp.carry = chain_mode != 0u ? 1u : 0u;   // segments of one stream: a segment sees the window in front of it
     lp.dict_len = chain_mode != 0u ? dict_len : 0u;
     if (const char* cv = getenv("ZMI_CARRY")) lp.carry = (chain_mode != 0u && atoi(cv)) ? 1u : 0u;
+    lp.producers = L.chain <= 4u ? 2u : 1u;   // short chains: 14 searcher waves outrun one producer wave
+    if (const char* pv = getenv("ZMI_PRODUCERS")) lp.producers = atoi(pv) > 1 ? 2u : 1u;
     lp.far4 = 1024u;
     lp.far5 = 8192u;
     if (const char* f4 = getenv("ZMI_FAR4")) lp.far4 = (uint32_t)atoi(f4);
