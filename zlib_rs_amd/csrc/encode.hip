@@ -525,11 +525,15 @@ __global__ void __launch_bounds__(64, 5) zmi_encode_kernel(const uint8_t* __rest
     uint32_t ntok = 0;     // tokens of the open block
     uint32_t tok0 = pstart;  // scratch index of the open block's first token (its first segment's position)
     uint32_t bstart = pstart;  // first input byte covered by the open block
+    // the match words are fetched two segments ahead: the word of the NEXT segment is needed right away (its first
+    // position decides the lazy rule of this segment's last one), so a load issued in the same iteration would put
+    // one HBM round trip on every segment
     uint32_t m_cur = (pstart + lane < pend) ? tokbuf[pstart + lane] : 0u;
+    uint32_t m_next = (pstart + 64u + lane < pend) ? tokbuf[pstart + 64u + lane] : 0u;
     for (uint32_t seg = seg0; seg < nseg; ++seg) {
         const uint32_t pos = seg * 64u + lane;
-        uint32_t npos = pos + 64u;
-        uint32_t m_next = (npos < pend) ? tokbuf[npos] : 0u;
+        const uint32_t npos2 = pos + 128u;
+        const uint32_t m_next2 = (npos2 < pend) ? tokbuf[npos2] : 0u;
         uint32_t first_next = (uint32_t)__shfl((int)m_next, 0);
         uint32_t m1 = __shfl_down(m_cur, 1u);
         if (lane == 63u) m1 = first_next;
@@ -585,6 +589,7 @@ __global__ void __launch_bounds__(64, 5) zmi_encode_kernel(const uint8_t* __rest
             e -= 64u;
         }
         m_cur = m_next;
+        m_next = m_next2;
         const uint32_t done = (seg + 1u) * 64u;
         if (done - tok0 >= prm.block_span || seg + 1u == nseg) {
             uint32_t bend = done + e;
