@@ -24,6 +24,8 @@ extern "C" int zmi_deflate_chain_dev(zmi_ctx* c, const void* d_in, const uint64_
 extern "C" int zmi_deflate_chain_dict_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                           uint32_t n, uint32_t max_len, int level, int strategy, int finish, uint32_t dict_len,
                                           void* d_out, uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream);
+extern "C" int zmi_checksum_batch_dev(zmi_ctx* c, const void* d_data, const uint64_t* d_off, const uint32_t* d_len, uint32_t n,
+                                      int kind, uint32_t* d_adler, uint32_t* d_crc, void* stream);
 extern "C" int zmi_ctx_set_inflate_out_limit(zmi_ctx* c, uint64_t bytes);
 extern "C" int zmi_inflate_batch_dict_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                           uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off,
@@ -129,8 +131,11 @@ size_t segment_bytes() {  // 1 MiB segments; ZMI_ABI_SEGMENT (bytes, multiple of
 // compress `n` host bytes as consecutive raw-deflate segments; appends the bytes to `out`.  `hist` (hist_len
 // bytes, may be 0) is what the stream has in front of these bytes: earlier input or a preset dictionary.
 // returns 0 or a negative zlib code
+// wrap 1 / 2: *check receives the Adler-32 / CRC-32 of the n bytes (per segment on the GPU, where the data is;
+// stitched with the combine algebra, crc32/combine.rs, adler32 combine lib.rs:372)
 int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_t hist_len, int level, int strategy, bool finish,
-                         std::vector<uint8_t>& out) {
+                         std::vector<uint8_t>& out, int wrap = 0, uint32_t* check = nullptr) {
+    if (check) *check = wrap == 1 ? 1u : 0u;
     if (n == 0) {
         if (finish) { out.push_back(0x03); out.push_back(0x00); }  // empty final static block (deflate.rs: 03 00)
         else { const uint8_t m[5] = {0x00, 0x00, 0x00, 0xFF, 0xFF}; out.insert(out.end(), m, m + 5); }
@@ -163,7 +168,24 @@ int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_
                                    finish ? 1 : 0, (uint32_t)hist_len, d_out.p, stride, (uint32_t*)d_olen.p, (int32_t*)d_st.p,
                                    nullptr) != 0)
         return Z_MEM_ERROR;
+    DevBuf d_sum;
+    if (check && wrap != 0) {
+        if (!d_sum.alloc((size_t)nseg * 8)) return Z_MEM_ERROR;
+        if (zmi_checksum_batch_dev(c, d_in.p, (const uint64_t*)d_off.p, (const uint32_t*)d_len.p, nseg, wrap == 1 ? 1 : 2,
+                                   (uint32_t*)d_sum.p, (uint32_t*)d_sum.p + nseg, nullptr) != 0)
+            return Z_MEM_ERROR;
+    }
     if (hipDeviceSynchronize() != hipSuccess) return Z_MEM_ERROR;
+    if (check && wrap != 0) {
+        std::vector<uint32_t> sums((size_t)nseg * 2);
+        if (hipMemcpy(sums.data(), d_sum.p, (size_t)nseg * 8, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR;
+        uint32_t acc = wrap == 1 ? 1u : 0u;
+        for (uint32_t i = 0; i < nseg; ++i) {
+            if (wrap == 1) acc = host_adler_combine(acc, sums[i], len[i]);
+            else acc = gf2_mul(gf2_xpow8(len[i]), acc) ^ sums[nseg + i];
+        }
+        *check = acc;
+    }
     std::vector<uint32_t> olen(nseg);
     std::vector<int32_t> st(nseg);
     if (hipMemcpy(olen.data(), d_olen.p, nseg * 4, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR;
@@ -359,13 +381,12 @@ void put_header(DeflateState* s) {
 // full_flush: the caller asked for Z_FULL_FLUSH -- the data after it must not refer to anything before it
 int compress_buffered(DeflateState* s, bool finish, bool full_flush = false) {
     if (!s->header_done) put_header(s);
-    if (s->wrap == 1) s->adler = host_adler_combine(s->adler, host_adler32(1, s->in.data(), s->in.size()), s->in.size());
-    if (s->wrap == 2) {
-        uint32_t c2 = host_crc32(0, s->in.data(), s->in.size());
-        s->crc = gf2_mul(gf2_xpow8(s->in.size()), s->crc) ^ c2;
-    }
     s->total_len += s->in.size();
-    int rc = gpu_deflate_segments(s->in.data(), s->in.size(), s->hist.data(), s->hist.size(), s->level, s->strategy, finish, s->pending);
+    uint32_t part = 0;   // checksum of this call's input, computed on the GPU next to the compression
+    int rc = gpu_deflate_segments(s->in.data(), s->in.size(), s->hist.data(), s->hist.size(), s->level, s->strategy, finish, s->pending,
+                                  s->wrap, &part);
+    if (rc == Z_OK && s->wrap == 1) s->adler = host_adler_combine(s->adler, part, s->in.size());
+    if (rc == Z_OK && s->wrap == 2) s->crc = gf2_mul(gf2_xpow8(s->in.size()), s->crc) ^ part;
     // window carry-over to the next call: the last 32 KiB of what the stream has seen (deflate.rs:2739-2752: only
     // Z_FULL_FLUSH forgets it)
     if (full_flush || finish) s->hist.clear();
