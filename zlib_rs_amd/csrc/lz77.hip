@@ -6,31 +6,32 @@
 // compare256.rs), driven by the lazy parse loop of deflate/algorithm/medium.rs:12-178.
 //
 // MI355X design (not a translation):
-//   * one 1024-thread workgroup per shard, the whole search state in LDS (131 KiB, 1 workgroup/CU):
-//       win  32 KiB ring of input bytes (+16 mirrored bytes so an unaligned 8-byte read may
-//            straddle the wrap)
-//       prev 32 Ki x u16 ring: DISTANCE to the previous position with the same hash (0 = end of
-//            chain) -- deltas instead of positions remove the reference's slide_hash pass
-//            (deflate/slide_hash.rs) entirely
-//       head 8 Ki x u32: last position+1 per hash bucket
-//   * NO workgroup barrier in the steady state.  Wave 0 is the PRODUCER: it streams the shard from
-//     HBM (one coalesced 16 B/lane load per 1 KiB), inserts 64 positions per step into head/prev
-//     (LDS atomic-max; the returned old value is the chain predecessor) and publishes a `ready`
-//     frontier.  It is throttled only by the ring: it may not overwrite bytes that the oldest
-//     in-flight search can still reference.
-//   * Waves 1..15 are SEARCHERS.  A searcher claims 64 consecutive positions (one per lane) from a
-//     shared LDS counter and walks the hash chains as a tight per-lane loop.  Every chain step
-//     issues ONE round of LDS reads (prev link of the candidate + its first 8 window bytes + the 4
-//     bytes ending at the current best length) so it costs one LDS latency; matches that survive
-//     the 8-byte compare are extended 16 bytes per round.  A claim is a bounded amount of work
-//     (<= max_chain steps), so a slow wave delays the ring by far less than its slack; claims are
-//     dynamic, so no wave waits for another (the first version had a barrier per 1 KiB tile and
-//     spent 61 % of its wave-cycles waiting).
+//   * one 1024-thread workgroup per shard, the whole search state in LDS (152 KiB, 1 workgroup/CU):
+//       win   32 KiB ring of input bytes (+32 mirrored bytes so an unaligned 16-byte read may straddle the wrap)
+//       prev  32 Ki x u16 ring: DISTANCE to the previous position with the same hash (0 = end of chain) --
+//             deltas instead of positions remove the reference's slide_hash pass (deflate/slide_hash.rs)
+//       head  8 Ki x u32: last position+1 per bucket of the 6-byte hash (the chain)
+//       head4 4 Ki x u32: last position+1 per bucket of the 4-byte hash (chain-less: one probe per position),
+//       c4    ring with the answer of that probe for the positions not searched yet
+//   * NO workgroup barrier in the steady state.  Wave 0 (levels 1-4: waves 0 and 1, alternating tiles) is the
+//     PRODUCER: it streams the shard from HBM (one coalesced 16 B/lane load per 1 KiB, issued a tile ahead),
+//     inserts 64 positions per step into the heads (LDS atomic-max; the returned old value is the chain
+//     predecessor) and publishes a `ready` frontier.  It is throttled only by the ring: it may not overwrite
+//     bytes that the oldest in-flight search can still reference.
+//   * The other waves are SEARCHERS.  A searcher claims 64 consecutive positions (one per lane) from a shared
+//     LDS counter and walks the chains as a tight per-lane loop.  Every chain step issues ONE round of LDS reads
+//     (prev link of the candidate + its first 16 window bytes as five aligned dwords), so it costs one LDS
+//     latency; only a candidate equal in all 16 bytes enters the divergent extension loop (16 bytes per round).
+//     A claim is a bounded amount of work (<= max_chain steps), so a slow wave delays the ring by far less than
+//     its slack; claims are dynamic, so no wave waits for another (the first version had a barrier per 1 KiB
+//     tile and spent 61 % of its wave-cycles waiting).
+//   * window carry-over (prm.carry): the bytes in front of a segment of a longer stream are hashed but not
+//     searched, so the segment matches into them -- also how a preset dictionary works.
 //   * output: one u32 per position  lit | len<<8 | (dist-1)<<17  (len = 0: no match >= 4).
 //     The parse (greedy/lazy selection) happens in encode.hip, which sees the best match of every
 //     position, not just the visited ones.
-// Bound: LDS latency / VALU issue (random window reads), not HBM: algorithmic HBM traffic is
-// 1 B read + 4 B scratch written per input byte.
+// Bound: VALU issue (8.1 instructions per input byte, pipes ~92 % busy at level 6), not HBM: algorithmic HBM
+// traffic is 1 B read + 4 B scratch written per input byte (measured: exactly that, profiles/r01_traffic.json).
 #include "zmi_device.h"
 #include "zmi_kernels.h"
 
