@@ -227,6 +227,36 @@ def test_inflate_unaligned_layout_and_patterns(engine):
         assert bytes(h[off_ + c:off_ + c + 3]) == b"\xee\xee\xee"   # nothing written past the capacity
 
 
+def test_fuzz_roundtrip_mixed(engine):
+    """ragged random batches both ways against system zlib: random sizes (0 .. 300 KiB), data classes, levels,
+    strategies, wrappers and window sizes"""
+    rng = np.random.default_rng(20260924)
+    pool = b"".join(_gen(engine, 8, 1 << 18))
+    for round_ in range(6):
+        n = int(rng.integers(20, 60))
+        shards = []
+        for _ in range(n):
+            ln = int(rng.choice([0, 1, 2, 3, 5, 63, 64, 65, 1000, 4096, 65535, 65536, 65537, int(rng.integers(0, 300000))]))
+            at = int(rng.integers(0, len(pool) - ln + 1))
+            shards.append(pool[at:at + ln])
+        level, wrap, strategy = int(rng.integers(0, 10)), int(rng.integers(0, 3)), int(rng.choice([0, 0, 0, 1, 2, 3, 4]))
+        outs, st = _deflate(engine, shards, level=level, wrap=wrap, strategy=strategy)
+        assert (st == 0).all(), (level, wrap, strategy)
+        for s_, o in zip(shards, outs):
+            assert _dec(o, wrap) == s_, (level, wrap, strategy, len(s_))
+        back, st2 = _inflate(engine, outs, [len(s_) for s_ in shards], wrap=wrap)
+        assert (st2 == 0).all() and back == shards
+        # streams made by system zlib with random parameters, inflated on the GPU
+        wbits = int(rng.integers(9, 16))
+        zs = []
+        for s_ in shards:
+            co = zlib.compressobj(int(rng.integers(0, 10)), zlib.DEFLATED, {0: -wbits, 1: wbits, 2: 16 + wbits}[wrap], 8,
+                                  int(rng.choice([0, 1, 2, 3, 4])))
+            zs.append(co.compress(s_) + co.flush())
+        back, st3 = _inflate(engine, zs, [len(s_) for s_ in shards], wrap=wrap)
+        assert (st3 == 0).all() and back == shards, (wrap, wbits)
+
+
 def test_checksums(engine):
     import torch
     blobs = [b"", b"a", b"abc", bytes(range(256)) * 300] + _gen(engine, 4, 1 << 16) + _gen(engine, 2)
