@@ -440,7 +440,7 @@ static __device__ void enc_flush_block(EncShared* S, EncWriter& W, const uint32_
     }
 }
 
-__global__ void __launch_bounds__(64, 5) zmi_encode_kernel(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off,
+__global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off,
                                                         const uint32_t* __restrict__ len, uint32_t first_shard,
                                                         uint32_t* match, uint64_t match_stride,
                                                         const uint32_t* __restrict__ adler, const uint32_t* __restrict__ crc,
