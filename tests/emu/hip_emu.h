@@ -17,6 +17,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 #include <vector>
 #include <functional>
 
@@ -213,6 +214,7 @@ inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh)
     return (unsigned)(v >> (sh & 31));
 }
 inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+inline float __log2f(float x) { return log2f(x); }
 inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }
 inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline int __ffsll(uint64_t v) { return __builtin_ffsll((long long)v); }

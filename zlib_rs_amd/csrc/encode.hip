@@ -36,8 +36,10 @@
 #define ENC_STG 128u
 
 struct EncShared {
-    uint32_t lfreq[ENC_NL];
+    uint32_t lfreq[ENC_NL];   // symbol counts of the open block
     uint32_t dfreq[ENC_ND];
+    uint32_t lfreq2[ENC_NL];  // ... and of the sub-block being tokenised (joins the block or starts the next one)
+    uint32_t dfreq2[ENC_ND];
     uint32_t lcode[ENC_NL];  // bit-reversed code | len << 16
     uint32_t dcode[ENC_ND];
     uint32_t stg[ENC_STG];
@@ -60,6 +62,11 @@ struct EncShared {
 #define M_NNZ 0
 #define M_REL 1
 #define M_CHOICE 2
+#define M_HC 3
+#define M_HLIT 4
+#define M_HDIST 5
+#define M_HCLEN 6
+#define M_DYNHDR 7
 
 // ---- symbol mapping (RFC 1951 3.2.5), computed instead of table-driven ----
 // length 3..258 -> (code index 0..28, extra bit count, extra value)
@@ -255,10 +262,153 @@ static __device__ void enc_gen_codes(EncShared* S, const uint8_t* lens, uint32_t
     }
 }
 
-// ---- lane 0: decide the block type, write its header into the staging window ----
-// returns (in misc) choice: 0 stored, 1 static, 2 dynamic; updates rel for choices 1/2
-static __device__ void enc_block_header(EncShared* S, uint32_t rel, uint32_t is_final, uint32_t stored_bits, uint32_t strategy) {
-    // code-length sequence
+// ---- all lanes: optimal code lengths (<= maxbits) for the symbols listed in S->order[0..nnz), wave-cooperative ----
+// The two-queue merge itself is serial, but it runs on wave-uniform (scalar) state with the heads of both queues
+// held in registers, so a merge costs one LDS round trip, not six; everything around it (sorted weights, node
+// depths, depth histogram, length assignment) is lane-parallel.  S->lcode is free while lengths are built and
+// serves as the array of sorted leaf weights.
+static __device__ void enc_huff_lengths_w(EncShared* S, const uint32_t* freq, uint32_t nsym, uint32_t nnz, uint32_t maxbits,
+                                          uint8_t* lens) {
+    const uint32_t lane = zmi_lane();
+    for (uint32_t i = lane; i < nsym; i += 64u) lens[i] = 0;
+    zmi_wave_sync();
+    if (nnz <= 1u) {
+        if (lane == 0) {
+            if (nnz == 0u) { lens[0] = 1; lens[1] = 1; }
+            else {
+                uint32_t s = S->order[0];
+                lens[s] = 1;
+                lens[s == 0u ? 1u : 0u] = 1;  // a second, unused code keeps the set complete (cf. deflate.rs:1957-1977)
+            }
+        }
+        zmi_wave_sync();
+        return;
+    }
+    uint32_t* sw = S->lcode;
+    for (uint32_t k = lane; k < nnz; k += 64u) sw[k] = freq[S->order[k]];
+    zmi_wave_sync();
+    // two-queue merge: leaves ascending in sw[], internal nodes are created in ascending weight
+    {
+        uint32_t li = 0, ii = 0;
+        uint32_t lw = zmi_uniform(sw[0]);   // head of the leaf queue (all ones: exhausted)
+        uint32_t nw = 0xFFFFFFFFu;          // head of the node queue (all ones: nothing made yet)
+        for (uint32_t ni = 0; ni + 1u < nnz; ++ni) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int pick = 0; pick < 2; ++pick) {
+                if (lw <= nw) {
+                    w += lw;
+                    S->lpar[li] = (uint16_t)ni;
+                    ++li;
+                    lw = li < nnz ? zmi_uniform(sw[li]) : 0xFFFFFFFFu;
+                } else {
+                    w += nw;
+                    S->ipar[ii] = (uint16_t)ni;
+                    ++ii;
+                    nw = ii < ni ? zmi_uniform(S->nfreq[ii]) : 0xFFFFFFFFu;
+                }
+            }
+            S->nfreq[ni] = w;
+            if (ii == ni) nw = w;   // the node just made is the head of its queue
+        }
+    }
+    zmi_wave_sync();
+    // node depths: a parent always has a larger index; relax until nothing changes (tree height rounds)
+    const uint32_t root = nnz - 2u;
+    for (uint32_t k = lane; k <= root; k += 64u) S->idep[k] = k == root ? (uint16_t)0 : (uint16_t)0xFFFFu;
+    zmi_wave_sync();
+    for (;;) {
+        bool changed = false;
+        for (uint32_t k = lane; k < root; k += 64u) {
+            if (S->idep[k] == 0xFFFFu) {
+                const uint32_t dp = S->idep[S->ipar[k]];
+                if (dp != 0xFFFFu) { S->idep[k] = (uint16_t)(dp + 1u); changed = true; }
+            }
+        }
+        zmi_wave_sync();
+        if (!__ballot(changed)) break;
+    }
+    // histogram of leaf depths, capped at maxbits
+    if (lane <= maxbits) S->cnt[lane] = 0;
+    zmi_wave_sync();
+    bool capped = false;
+    for (uint32_t k = lane; k < nnz; k += 64u) {
+        uint32_t d = (uint32_t)S->idep[S->lpar[k]] + 1u;
+        if (d > maxbits) { d = maxbits; capped = true; }
+        atomicAdd(&S->cnt[d], 1u);
+    }
+    const bool over = __ballot(capped) != 0ull;
+    zmi_wave_sync();
+    if (over && lane == 0) {
+        // Kraft sum in units of 2^-maxbits; every step below lowers it by exactly one unit:
+        // a leaf at the deepest non-full level d becomes an internal node whose children are that
+        // leaf and one leaf lifted from level maxbits.
+        uint32_t K = 0;
+        for (uint32_t d = 1; d <= maxbits; ++d) K += S->cnt[d] << (maxbits - d);
+        const uint32_t full = 1u << maxbits;
+        while (K > full) {
+            uint32_t d = maxbits - 1u;
+            while (S->cnt[d] == 0u) --d;
+            S->cnt[d]--;
+            S->cnt[d + 1u] += 2u;
+            S->cnt[maxbits]--;
+            --K;
+        }
+    }
+    zmi_wave_sync();
+    // rarest symbols get the longest codes: sorted symbol k takes the depth whose slice of the order it falls in
+    for (uint32_t k = lane; k < nnz; k += 64u) {
+        uint32_t acc = 0, dk = 1;
+        for (uint32_t d = maxbits; d >= 1u; --d) {
+            const uint32_t c = S->cnt[d];
+            if (k >= acc && k < acc + c) dk = d;
+            acc += c;
+        }
+        lens[S->order[k]] = (uint8_t)dk;
+    }
+    zmi_wave_sync();
+}
+
+// ---- all lanes: canonical codes (bit-reversed for LSB-first emission), as gen_codes ----
+// A symbol's code is next[len] + its rank among the lower-indexed symbols of the same length: ballot + mbcnt per
+// length and chunk of 64 symbols (LDS atomics would not do: a wave's same-address atomics are not applied in lane order).
+static __device__ void enc_gen_codes_w(EncShared* S, const uint8_t* lens, uint32_t nsym, uint32_t maxbits, uint32_t* table) {
+    const uint32_t lane = zmi_lane();
+    if (lane < 16u) S->cnt[lane] = 0;
+    zmi_wave_sync();
+    for (uint32_t i = lane; i < nsym; i += 64u) atomicAdd(&S->cnt[lens[i]], 1u);
+    zmi_wave_sync();
+    if (lane == 0) {
+        S->cnt[0] = 0;
+        uint32_t code = 0;
+        for (uint32_t d = 1; d <= maxbits; ++d) {
+            code = (code + S->cnt[d - 1u]) << 1;
+            S->next[d] = code;
+        }
+    }
+    zmi_wave_sync();
+    for (uint32_t base = 0; base < nsym; base += 64u) {
+        const uint32_t i = base + lane;
+        const uint32_t l = i < nsym ? lens[i] : 0u;
+        uint32_t code = 0;
+        for (uint32_t d = 1; d <= maxbits; ++d) {
+            const uint64_t m = __ballot(l == d);
+            if (m) {   // uniform
+                const uint32_t nx = zmi_uniform(S->next[d]);
+                if (l == d) code = nx + zmi_mbcnt(m);
+                zmi_wave_sync();
+                if (lane == 0) S->next[d] = nx + (uint32_t)__popcll(m);
+                zmi_wave_sync();
+            }
+        }
+        if (i < nsym) table[i] = l ? ((__brev(code) >> (32u - l)) | (l << 16)) : 0u;
+    }
+    zmi_wave_sync();
+}
+
+// ---- lane 0: plan the dynamic header -- run-length code the code lengths, build the code-length code ----
+// leaves the symbol list in hsym/hext (count in misc[M_HC]), HLIT/HDIST/HCLEN and the header's size in bits in misc
+static __device__ void enc_header_plan(EncShared* S) {
     uint32_t hlit = 286u;
     while (hlit > 257u && S->llen[hlit - 1u] == 0) --hlit;
     uint32_t hdist = 30u;
@@ -286,7 +436,7 @@ static __device__ void enc_block_header(EncShared* S, uint32_t rel, uint32_t is_
             while (run > 0u) { S->hsym[hc] = (uint8_t)v; S->hext[hc++] = 0; S->blfreq[v]++; --run; }
         }
     }
-    // code-length code: insertion sort of <= 19 symbols, then the same length builder (limit 7)
+    // code-length code: insertion sort of <= 19 symbols, then the serial length builder (limit 7)
     uint32_t nnz = 0;
     for (uint32_t s = 0; s < ENC_NBL; ++s) {
         uint32_t f = S->blfreq[s];
@@ -300,79 +450,106 @@ static __device__ void enc_block_header(EncShared* S, uint32_t rel, uint32_t is_
     const uint8_t blorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     uint32_t hclen = 19u;
     while (hclen > 4u && S->bllen[blorder[hclen - 1u]] == 0) --hclen;
-
-    // costs in bits
-    uint32_t dyn = 3u + 14u + 3u * hclen;
-    for (uint32_t s = 0; s < ENC_NBL; ++s) dyn += S->blfreq[s] * S->bllen[s];
-    dyn += S->blfreq[16] * 2u + S->blfreq[17] * 3u + S->blfreq[18] * 7u;
-    uint32_t stat = 3u;
-    for (uint32_t s = 0; s < 286u; ++s) {
-        uint32_t f = S->lfreq[s];
-        if (!f) continue;
-        uint32_t eb = s > 256u ? enc_lext(s - 257u) : 0u;
-        dyn += f * (S->llen[s] + eb);
-        stat += f * (enc_static_llen(s) + eb);
-    }
-    for (uint32_t d = 0; d < 30u; ++d) {
-        uint32_t f = S->dfreq[d];
-        if (!f) continue;
-        uint32_t eb = enc_dext(d);
-        dyn += f * (S->dlen[d] + eb);
-        stat += f * (5u + eb);
-    }
-    uint32_t choice;
-    if (strategy == 100u) choice = 0u;  // level 0: stored blocks only
-    else if (strategy == 4u) choice = (stored_bits < stat) ? 0u : 1u;
-    else if (stored_bits <= dyn && stored_bits <= stat) choice = 0u;
-    else choice = (stat <= dyn) ? 1u : 2u;
-    S->misc[M_CHOICE] = choice;
-    if (choice == 2u) {
-        enc_put0(S, rel, is_final | (2u << 1), 3u);
-        enc_put0(S, rel, hlit - 257u, 5u);
-        enc_put0(S, rel, hdist - 1u, 5u);
-        enc_put0(S, rel, hclen - 4u, 4u);
-        for (uint32_t k = 0; k < hclen; ++k) enc_put0(S, rel, S->bllen[blorder[k]], 3u);
-        for (uint32_t k = 0; k < hc; ++k) {
-            uint32_t s = S->hsym[k];
-            uint32_t c = S->blcode[s];
-            enc_put0(S, rel, c & 0xFFFFu, c >> 16);
-            if (s == 16u) enc_put0(S, rel, S->hext[k], 2u);
-            else if (s == 17u) enc_put0(S, rel, S->hext[k], 3u);
-            else if (s == 18u) enc_put0(S, rel, S->hext[k], 7u);
-        }
-        enc_gen_codes(S, S->llen, 286u, 15u, S->lcode);
-        enc_gen_codes(S, S->dlen, 30u, 15u, S->dcode);
-    } else if (choice == 1u) {
-        enc_put0(S, rel, is_final | (1u << 1), 3u);
-        for (uint32_t s = 0; s < ENC_NL; ++s) S->llen[s] = (uint8_t)enc_static_llen(s);
-        for (uint32_t d = 0; d < ENC_ND; ++d) S->dlen[d] = 5;
-        enc_gen_codes(S, S->llen, ENC_NL, 15u, S->lcode);
-        enc_gen_codes(S, S->dlen, 30u, 15u, S->dcode);
-    }
-    S->misc[M_REL] = rel;
+    uint32_t bits = 3u + 14u + 3u * hclen;
+    for (uint32_t s = 0; s < ENC_NBL; ++s) bits += S->blfreq[s] * S->bllen[s];
+    bits += S->blfreq[16] * 2u + S->blfreq[17] * 3u + S->blfreq[18] * 7u;
+    S->misc[M_HC] = hc;
+    S->misc[M_HLIT] = hlit;
+    S->misc[M_HDIST] = hdist;
+    S->misc[M_HCLEN] = hclen;
+    S->misc[M_DYNHDR] = bits;
 }
 
 // all lanes: emit one deflate block for tokens [tok, tok+ntok) / raw bytes [bstart, bend)
-static __device__ void enc_flush_block(EncShared* S, EncWriter& W, const uint32_t* tok, uint32_t ntok, const uint8_t* src,
-                                       uint32_t bstart, uint32_t bend, uint32_t is_final, const zmi_enc_params& prm) {
+// (out of line: called from two places; the writer state and the parameters travel by value so that they stay in
+// registers on both sides of the call)
+static __device__ __noinline__ EncWriter enc_flush_block(EncShared* S, EncWriter W, const uint32_t* tok, uint32_t ntok,
+                                                         const uint8_t* src, uint32_t bstart, uint32_t bend, uint32_t is_final,
+                                                         uint32_t strategy) {
     const uint32_t lane = zmi_lane();
     if (lane == 0) S->lfreq[256] += 1u;  // end-of-block
     zmi_wave_sync();
     enc_rank_sort(S, S->lfreq, 286u);
-    if (lane == 0) enc_huff_lengths(S, S->lfreq, ENC_NL, S->misc[M_NNZ], 15u, S->llen);
-    zmi_wave_sync();
+    enc_huff_lengths_w(S, S->lfreq, ENC_NL, zmi_uniform(S->misc[M_NNZ]), 15u, S->llen);
     enc_rank_sort(S, S->dfreq, 30u);
+    enc_huff_lengths_w(S, S->dfreq, ENC_ND, zmi_uniform(S->misc[M_NNZ]), 15u, S->dlen);
     const uint32_t blen = bend - bstart;
     const uint32_t nsub = blen ? (blen + 32767u) / 32768u : 1u;
-    if (lane == 0) {
-        enc_huff_lengths(S, S->dfreq, ENC_ND, S->misc[M_NNZ], 15u, S->dlen);
-        enc_block_header(S, W.rel, is_final, 8u * blen + 42u * nsub, prm.strategy);
-    }
+    const uint32_t stored_bits = 8u * blen + 42u * nsub;
+    if (lane == 0) enc_header_plan(S);
     zmi_wave_sync();
-    const uint32_t choice = S->misc[M_CHOICE];
-    if (choice != 0u) {
-        W.rel = S->misc[M_REL];
+    // cost of the block with the dynamic and with the static code (lane-parallel over the symbols)
+    uint32_t dpart = 0, spart = 0;
+    for (uint32_t i = lane; i < 286u + 30u; i += 64u) {
+        if (i < 286u) {
+            const uint32_t f = S->lfreq[i];
+            const uint32_t eb = i > 256u ? enc_lext(i - 257u) : 0u;
+            dpart += f * (S->llen[i] + eb);
+            spart += f * (enc_static_llen(i) + eb);
+        } else {
+            const uint32_t d = i - 286u;
+            const uint32_t f = S->dfreq[d];
+            const uint32_t eb = enc_dext(d);
+            dpart += f * (S->dlen[d] + eb);
+            spart += f * (5u + eb);
+        }
+    }
+    const uint32_t dyn = zmi_uniform(S->misc[M_DYNHDR]) + zmi_wave_sum(dpart);
+    const uint32_t stat = 3u + zmi_wave_sum(spart);
+    uint32_t choice;   // 0 stored, 1 static, 2 dynamic
+    if (strategy == 100u) choice = 0u;  // level 0: stored blocks only
+    else if (strategy == 4u) choice = (stored_bits < stat) ? 0u : 1u;
+    else if (stored_bits <= dyn && stored_bits <= stat) choice = 0u;
+    else choice = (stat <= dyn) ? 1u : 2u;
+    if (choice == 2u) {
+        const uint32_t hc = zmi_uniform(S->misc[M_HC]);
+        if (lane == 0) {
+            const uint8_t blorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+            const uint32_t hclen = S->misc[M_HCLEN];
+            uint32_t rel = W.rel;
+            enc_put0(S, rel, is_final | (2u << 1), 3u);
+            enc_put0(S, rel, S->misc[M_HLIT] - 257u, 5u);
+            enc_put0(S, rel, S->misc[M_HDIST] - 1u, 5u);
+            enc_put0(S, rel, hclen - 4u, 4u);
+            for (uint32_t k = 0; k < hclen; ++k) enc_put0(S, rel, S->bllen[blorder[k]], 3u);
+            S->misc[M_REL] = rel;
+        }
+        zmi_wave_sync();
+        W.rel = zmi_uniform(S->misc[M_REL]);
         enc_flush(S, W);
+        // the run-length coded code lengths, 64 symbols per step through the wave bit packer
+        for (uint32_t base = 0; base < hc; base += 64u) {
+            const uint32_t k = base + lane;
+            uint64_t bits = 0;
+            uint32_t nb = 0;
+            if (k < hc) {
+                const uint32_t hs = S->hsym[k];
+                const uint32_t c = S->blcode[hs];
+                bits = c & 0xFFFFu;
+                nb = c >> 16;
+                const uint32_t xb = hs == 16u ? 2u : (hs == 17u ? 3u : (hs == 18u ? 7u : 0u));
+                bits |= (uint64_t)S->hext[k] << nb;
+                nb += xb;
+            }
+            enc_emit_group(S, W, bits, nb);
+        }
+        enc_gen_codes_w(S, S->llen, 286u, 15u, S->lcode);
+        enc_gen_codes_w(S, S->dlen, 30u, 15u, S->dcode);
+    } else if (choice == 1u) {
+        if (lane == 0) {
+            uint32_t rel = W.rel;
+            enc_put0(S, rel, is_final | (1u << 1), 3u);
+            S->misc[M_REL] = rel;
+        }
+        for (uint32_t i = lane; i < ENC_NL; i += 64u) S->llen[i] = (uint8_t)enc_static_llen(i);
+        if (lane < ENC_ND) S->dlen[lane] = 5;
+        zmi_wave_sync();
+        W.rel = zmi_uniform(S->misc[M_REL]);
+        enc_flush(S, W);
+        enc_gen_codes_w(S, S->llen, ENC_NL, 15u, S->lcode);
+        enc_gen_codes_w(S, S->dlen, 30u, 15u, S->dcode);
+    }
+    if (choice != 0u) {
         // tokens + the end-of-block symbol as virtual token index ntok; the next group's tokens are
         // fetched while the current group is encoded (the HBM/L2 latency is the longest stall here)
         uint32_t tk_next = lane < ntok ? tok[lane] : 0u;
@@ -438,6 +615,35 @@ static __device__ void enc_flush_block(EncShared* S, EncWriter& W, const uint32_
             p += l;
         }
     }
+    return W;
+}
+
+// Should the sub-block (lfreq2/dfreq2: nh tokens) start a new deflate block instead of joining the open one
+// (lfreq/dfreq: nH tokens)?  Zeroth-order entropy of the two symbol sets apart and together, lane-parallel over the
+// alphabets; a block of its own must earn the bits of another dynamic header.  This is what makes blocks follow the
+// data: stationary input (text) grows them to the span limit, drifting statistics get short blocks with their own
+// codes.  (The reference cuts blocks by symbol count only, lit_bufsize = 16383 symbols, deflate.rs:321.)
+static __device__ __noinline__ bool enc_split_pays(const EncShared* S, uint32_t nH, uint32_t nh, uint32_t hdr_bits) {
+    const uint32_t lane = zmi_lane();
+    float sH = 0.f, sh = 0.f, sm = 0.f;
+    uint32_t dH = 0, dh = 0;
+    for (uint32_t i = lane; i < ENC_NL + ENC_ND; i += 64u) {
+        const bool isd = i >= ENC_NL;
+        const uint32_t a = isd ? S->dfreq[i - ENC_NL] : S->lfreq[i];
+        const uint32_t b = isd ? S->dfreq2[i - ENC_NL] : S->lfreq2[i];
+        if (isd) { dH += a; dh += b; }
+        if (a) sH += (float)a * __log2f((float)a);
+        if (b) sh += (float)b * __log2f((float)b);
+        if (a + b) sm += (float)(a + b) * __log2f((float)(a + b));
+    }
+    // fixed point (1/16 bit) so that the integer wave reduction can be used
+    const uint32_t qH = zmi_wave_sum((uint32_t)(sH * 16.f)), qh = zmi_wave_sum((uint32_t)(sh * 16.f)), qm = zmi_wave_sum((uint32_t)(sm * 16.f));
+    dH = zmi_wave_sum(dH);
+    dh = zmi_wave_sum(dh);
+    auto nlgn = [](uint32_t n) { return n ? (float)n * __log2f((float)n) : 0.f; };
+    const float apart = nlgn(nH) + nlgn(dH) - (float)qH * (1.f / 16.f) + nlgn(nh) + nlgn(dh) - (float)qh * (1.f / 16.f);
+    const float joined = nlgn(nH + nh) + nlgn(dH + dh) - (float)qm * (1.f / 16.f);
+    return apart + (float)hdr_bits < joined;
 }
 
 __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off,
@@ -481,8 +687,8 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
     W.err = 0;
 
     for (uint32_t i = lane; i < ENC_STG; i += 64u) S->stg[i] = 0;
-    for (uint32_t i = lane; i < ENC_NL; i += 64u) S->lfreq[i] = 0;
-    if (lane < ENC_ND) S->dfreq[lane] = 0;
+    for (uint32_t i = lane; i < ENC_NL; i += 64u) { S->lfreq[i] = 0; S->lfreq2[i] = 0; }
+    if (lane < ENC_ND) { S->dfreq[lane] = 0; S->dfreq2[lane] = 0; }
     zmi_wave_sync();
 
     // stream header (first piece only)
@@ -522,9 +728,11 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
     const uint32_t seg0 = pstart / 64u;
     const uint32_t nseg = (pend + 63u) / 64u;  // one past the last segment of this piece
     uint32_t e = 0;        // entry offset into the current segment (>= 64: segment fully covered by a match)
-    uint32_t ntok = 0;     // tokens of the open block
-    uint32_t tok0 = pstart;  // scratch index of the open block's first token (its first segment's position)
+    uint32_t ntok = 0;     // tokens of the open block + the sub-block behind it
+    uint32_t nH = 0;       // ... of which the open block holds this many (the sub-block: ntok - nH)
+    uint32_t tok0 = pstart;  // scratch index of the open block's first token (<= the position it stands for)
     uint32_t bstart = pstart;  // first input byte covered by the open block
+    uint32_t bendH = pstart;   // end of the open block's input
     // the match words are fetched two segments ahead: the word of the NEXT segment is needed right away (its first
     // position decides the lazy rule of this segment's last one), so a load issued in the same iteration would put
     // one HBM round trip on every segment
@@ -577,10 +785,10 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
                     uint32_t li, leb, lev, di, deb, dev;
                     enc_len_sym(step, li, leb, lev);
                     enc_dist_sym((m_cur >> 17) + 1u, di, deb, dev);
-                    atomicAdd(&S->lfreq[257u + li], 1u);
-                    atomicAdd(&S->dfreq[di], 1u);
+                    atomicAdd(&S->lfreq2[257u + li], 1u);
+                    atomicAdd(&S->dfreq2[di], 1u);
                 } else {
-                    atomicAdd(&S->lfreq[m_cur & 0xFFu], 1u);
+                    atomicAdd(&S->lfreq2[m_cur & 0xFFu], 1u);
                 }
             }
             ntok += (uint32_t)__popcll(mask);
@@ -591,19 +799,43 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
         m_cur = m_next;
         m_next = m_next2;
         const uint32_t done = (seg + 1u) * 64u;
-        if (done - tok0 >= prm.block_span || seg + 1u == nseg) {
-            uint32_t bend = done + e;
-            if (bend > pend) bend = pend;
-            const uint32_t is_final = (seg + 1u == nseg && is_last) ? 1u : 0u;  // is_last implies last piece
-            __threadfence_block();  // token stores of other lanes must be visible to the encode pass
+        const bool last_seg = seg + 1u == nseg;
+        if (ntok - nH >= prm.block_tokens || done - bstart >= prm.block_span || last_seg) {
+            // ---- sub-block boundary: join the open block, or close it and start the next one here ----
+            uint32_t bmid = done + e;
+            if (bmid > pend) bmid = pend;
+            const uint32_t nh = ntok - nH;
             zmi_wave_sync();
-            enc_flush_block(S, W, tokbuf + tok0, ntok, src, bstart, bend, is_final, prm);
-            bstart = bend;
-            tok0 = done;
-            ntok = 0;
-            for (uint32_t i = lane; i < ENC_NL; i += 64u) S->lfreq[i] = 0;
-            if (lane < ENC_ND) S->dfreq[lane] = 0;
+            if (nH != 0u && enc_split_pays(S, nH, nh, prm.split_hdr_bits)) {
+                __threadfence_block();  // token stores of other lanes must be visible to the encode pass
+                zmi_wave_sync();
+                W = enc_flush_block(S, W, tokbuf + tok0, nH, src, bstart, bendH, 0u, prm.strategy);
+                tok0 += nH;             // the sub-block's tokens stay where they are and become the open block
+                ntok -= nH;
+                nH = 0;
+                bstart = bendH;
+                for (uint32_t i = lane; i < ENC_NL; i += 64u) S->lfreq[i] = 0;
+                if (lane < ENC_ND) S->dfreq[lane] = 0;
+                zmi_wave_sync();
+            }
+            for (uint32_t i = lane; i < ENC_NL; i += 64u) { S->lfreq[i] += S->lfreq2[i]; S->lfreq2[i] = 0; }
+            if (lane < ENC_ND) { S->dfreq[lane] += S->dfreq2[lane]; S->dfreq2[lane] = 0; }
+            nH = ntok;
+            bendH = bmid;
             zmi_wave_sync();
+            if (last_seg || bendH - bstart >= prm.block_span) {
+                const uint32_t is_final = (last_seg && is_last) ? 1u : 0u;  // is_last implies last piece
+                __threadfence_block();
+                zmi_wave_sync();
+                W = enc_flush_block(S, W, tokbuf + tok0, nH, src, bstart, bendH, is_final, prm.strategy);
+                bstart = bendH;
+                tok0 = done;
+                ntok = 0;
+                nH = 0;
+                for (uint32_t i = lane; i < ENC_NL; i += 64u) S->lfreq[i] = 0;
+                if (lane < ENC_ND) S->dfreq[lane] = 0;
+                zmi_wave_sync();
+            }
         }
     }
 

@@ -302,6 +302,10 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     lp.far5 = 8192u;
     if (const char* f4 = getenv("ZMI_FAR4")) lp.far4 = (uint32_t)atoi(f4);
     if (const char* f5 = getenv("ZMI_FAR5")) lp.far5 = (uint32_t)atoi(f5);
+    ep.block_tokens = 4096u;
+    ep.split_hdr_bits = 640u;
+    if (const char* hb = getenv("ZMI_SPLIT_HDR")) ep.split_hdr_bits = (uint32_t)atoi(hb);
+    if (const char* bt = getenv("ZMI_BLOCK_TOKENS")) ep.block_tokens = (uint32_t)atoi(bt) >= 64u ? (uint32_t)atoi(bt) : 64u;
     const char* span_env = getenv("ZMI_BLOCK_SPAN");
     if (span_env && atoi(span_env) >= 64) ep.block_span = (uint32_t)atoi(span_env);
 

@@ -30,7 +30,10 @@ struct zmi_enc_params {
     uint32_t max_lazy;    // defer a match shorter than this if the next position has a longer one (0 = greedy)
     uint32_t wrap;        // 0 raw deflate, 1 zlib (RFC 1950), 2 gzip (RFC 1952)
     uint32_t level;       // only used for the header's level hint bits
-    uint32_t block_span;  // input bytes per deflate block (multiple of 64)
+    uint32_t block_span;  // input bytes per deflate block (multiple of 64) ...
+    uint32_t block_tokens; // tokens per sub-block: after each one the encoder decides whether it joins the open block or starts
+                           // a new one (the reference cuts at 16383 symbols, deflate.rs:321)
+    uint32_t split_hdr_bits; // what a block of its own must save: the cost of another dynamic header
     uint32_t strategy;    // 0 default, 4 = Z_FIXED (static trees only)
     uint32_t chain_mode;  // 0: every shard is its own stream; 1: the shards of the batch are consecutive
                           // segments of ONE raw deflate stream, only shard `last_shard` ends it (BFINAL);
