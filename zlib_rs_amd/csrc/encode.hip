@@ -153,6 +153,28 @@ static __device__ __forceinline__ void enc_emit_group(EncShared* S, EncWriter& W
     enc_flush(S, W);
 }
 
+// entry `idx` (wave-uniform, < 320) of a table held as five registers per lane (entry = lane + 64 * register)
+static __device__ __forceinline__ uint32_t enc_rd5(const uint32_t (&r)[5], uint32_t idx) {
+    const uint32_t l = idx & 63u;
+    switch (idx >> 6) {
+        case 0: return zmi_readlane(r[0], l);
+        case 1: return zmi_readlane(r[1], l);
+        case 2: return zmi_readlane(r[2], l);
+        case 3: return zmi_readlane(r[3], l);
+        default: return zmi_readlane(r[4], l);
+    }
+}
+static __device__ __forceinline__ void enc_wr5(uint32_t (&r)[5], uint32_t idx, uint32_t v) {
+    const uint32_t l = idx & 63u;
+    switch (idx >> 6) {
+        case 0: r[0] = zmi_writelane(r[0], v, l); break;
+        case 1: r[1] = zmi_writelane(r[1], v, l); break;
+        case 2: r[2] = zmi_writelane(r[2], v, l); break;
+        case 3: r[3] = zmi_writelane(r[3], v, l); break;
+        default: r[4] = zmi_writelane(r[4], v, l); break;
+    }
+}
+
 // ---- lane-parallel rank sort of the symbols with non-zero frequency (ascending freq, then index) ----
 static __device__ void enc_rank_sort(EncShared* S, const uint32_t* freq, uint32_t nsym) {
     const uint32_t lane = zmi_lane();
@@ -165,13 +187,20 @@ static __device__ void enc_rank_sort(EncShared* S, const uint32_t* freq, uint32_
         rk[k] = 0;
         mine += fi[k] != 0u;
     }
-    for (uint32_t j = 0; j < nsym; ++j) {
-        uint32_t fj = freq[j];
-        if (fj == 0u) continue;  // uniform branch
+    // every symbol with a non-zero count is broadcast once (a scalar lane read, no LDS round trip) and counted against
 #pragma unroll
-        for (uint32_t k = 0; k < 5u; ++k) {
-            uint32_t i = lane + 64u * k;
-            rk[k] += (fj < fi[k]) || (fj == fi[k] && j < i);
+    for (uint32_t c = 0; c < 5u; ++c) {
+        uint64_t nz = __ballot(fi[c] != 0u);
+        while (nz) {
+            const uint32_t jj = (uint32_t)__ffsll((unsigned long long)nz) - 1u;
+            nz &= nz - 1ull;
+            const uint32_t fj = zmi_readlane(fi[c], jj);
+            const uint32_t j = c * 64u + jj;
+#pragma unroll
+            for (uint32_t k = 0; k < 5u; ++k) {
+                uint32_t i = lane + 64u * k;
+                rk[k] += (fj < fi[k]) || (fj == fi[k] && j < i);
+            }
         }
     }
 #pragma unroll
@@ -184,89 +213,10 @@ static __device__ void enc_rank_sort(EncShared* S, const uint32_t* freq, uint32_
     zmi_wave_sync();
 }
 
-// ---- lane 0: optimal code lengths (<= maxbits) for the symbols listed in S->order[0..nnz) ----
-static __device__ void enc_huff_lengths(EncShared* S, const uint32_t* freq, uint32_t nsym, uint32_t nnz, uint32_t maxbits,
-                                        uint8_t* lens) {
-    for (uint32_t i = 0; i < nsym; ++i) lens[i] = 0;
-    if (nnz == 0u) { lens[0] = 1; lens[1] = 1; return; }
-    if (nnz == 1u) {
-        uint32_t s = S->order[0];
-        lens[s] = 1;
-        lens[s == 0u ? 1u : 0u] = 1;  // a second, unused code keeps the set complete (cf. deflate.rs:1957-1977)
-        return;
-    }
-    // two-queue merge: leaves ascending in order[], internal nodes are created in ascending weight
-    uint32_t li = 0, ii = 0;
-    for (uint32_t ni = 0; ni + 1u < nnz; ++ni) {
-        uint32_t w = 0;
-        for (int pick = 0; pick < 2; ++pick) {
-            bool leaf;
-            if (li >= nnz) leaf = false;
-            else if (ii >= ni) leaf = true;
-            else leaf = freq[S->order[li]] <= S->nfreq[ii];
-            if (leaf) { w += freq[S->order[li]]; S->lpar[li] = (uint16_t)ni; ++li; }
-            else { w += S->nfreq[ii]; S->ipar[ii] = (uint16_t)ni; ++ii; }
-        }
-        S->nfreq[ni] = w;
-    }
-    const uint32_t root = nnz - 2u;
-    S->idep[root] = 0;
-    for (uint32_t k = root; k-- > 0u;) S->idep[k] = (uint16_t)(S->idep[S->ipar[k]] + 1u);
-    for (uint32_t d = 0; d <= maxbits; ++d) S->cnt[d] = 0;
-    bool over = false;
-    for (uint32_t k = 0; k < nnz; ++k) {
-        uint32_t d = S->idep[S->lpar[k]] + 1u;
-        if (d > maxbits) { d = maxbits; over = true; }
-        S->cnt[d]++;
-    }
-    if (over) {
-        // Kraft sum in units of 2^-maxbits; every step below lowers it by exactly one unit:
-        // a leaf at the deepest non-full level d becomes an internal node whose children are that
-        // leaf and one leaf lifted from level maxbits.
-        uint32_t K = 0;
-        for (uint32_t d = 1; d <= maxbits; ++d) K += S->cnt[d] << (maxbits - d);
-        const uint32_t full = 1u << maxbits;
-        while (K > full) {
-            uint32_t d = maxbits - 1u;
-            while (S->cnt[d] == 0u) --d;
-            S->cnt[d]--;
-            S->cnt[d + 1u] += 2u;
-            S->cnt[maxbits]--;
-            --K;
-        }
-    }
-    // rarest symbols get the longest codes
-    uint32_t k = 0;
-    for (uint32_t d = maxbits; d >= 1u; --d)
-        for (uint32_t c = S->cnt[d]; c > 0u; --c) lens[S->order[k++]] = (uint8_t)d;
-}
-
-// ---- lane 0: canonical codes (bit-reversed for LSB-first emission), as gen_codes ----
-static __device__ void enc_gen_codes(EncShared* S, const uint8_t* lens, uint32_t nsym, uint32_t maxbits, uint32_t* table) {
-    for (uint32_t d = 0; d <= maxbits; ++d) S->cnt[d] = 0;
-    for (uint32_t i = 0; i < nsym; ++i) S->cnt[lens[i]]++;
-    S->cnt[0] = 0;
-    uint32_t code = 0;
-    for (uint32_t d = 1; d <= maxbits; ++d) {
-        code = (code + S->cnt[d - 1u]) << 1;
-        S->next[d] = code;
-    }
-    for (uint32_t i = 0; i < nsym; ++i) {
-        uint32_t l = lens[i];
-        if (l) {
-            uint32_t c = S->next[l]++;
-            table[i] = (__brev(c) >> (32u - l)) | (l << 16);
-        } else {
-            table[i] = 0;
-        }
-    }
-}
-
 // ---- all lanes: optimal code lengths (<= maxbits) for the symbols listed in S->order[0..nnz), wave-cooperative ----
 // The two-queue merge itself is serial, but it runs on wave-uniform (scalar) state with the heads of both queues
 // held in registers, so a merge costs one LDS round trip, not six; everything around it (sorted weights, node
-// depths, depth histogram, length assignment) is lane-parallel.  S->lcode is free while lengths are built and
-// serves as the array of sorted leaf weights.
+// depths, depth histogram, length assignment) is lane-parallel.
 static __device__ void enc_huff_lengths_w(EncShared* S, const uint32_t* freq, uint32_t nsym, uint32_t nnz, uint32_t maxbits,
                                           uint8_t* lens) {
     const uint32_t lane = zmi_lane();
@@ -284,13 +234,18 @@ static __device__ void enc_huff_lengths_w(EncShared* S, const uint32_t* freq, ui
         zmi_wave_sync();
         return;
     }
-    uint32_t* sw = S->lcode;
-    for (uint32_t k = lane; k < nnz; k += 64u) sw[k] = freq[S->order[k]];
-    zmi_wave_sync();
-    // two-queue merge: leaves ascending in sw[], internal nodes are created in ascending weight
+    // sorted leaf weights and the weights of the nodes made so far live in five registers per lane; the heads of the
+    // two queues are fetched with scalar lane reads, so the serial merge never waits for the LDS
+    uint32_t swr[5], nwr[5];
+#pragma unroll
+    for (uint32_t c = 0; c < 5u; ++c) {
+        const uint32_t k = lane + 64u * c;
+        swr[c] = k < nnz ? freq[S->order[k]] : 0xFFFFFFFFu;
+        nwr[c] = 0xFFFFFFFFu;
+    }
     {
         uint32_t li = 0, ii = 0;
-        uint32_t lw = zmi_uniform(sw[0]);   // head of the leaf queue (all ones: exhausted)
+        uint32_t lw = enc_rd5(swr, 0);      // head of the leaf queue (all ones: exhausted)
         uint32_t nw = 0xFFFFFFFFu;          // head of the node queue (all ones: nothing made yet)
         for (uint32_t ni = 0; ni + 1u < nnz; ++ni) {
             uint32_t w = 0;
@@ -298,17 +253,17 @@ static __device__ void enc_huff_lengths_w(EncShared* S, const uint32_t* freq, ui
             for (int pick = 0; pick < 2; ++pick) {
                 if (lw <= nw) {
                     w += lw;
-                    S->lpar[li] = (uint16_t)ni;
+                    if (lane == 0) S->lpar[li] = (uint16_t)ni;
                     ++li;
-                    lw = li < nnz ? zmi_uniform(sw[li]) : 0xFFFFFFFFu;
+                    lw = li < nnz ? enc_rd5(swr, li) : 0xFFFFFFFFu;
                 } else {
                     w += nw;
-                    S->ipar[ii] = (uint16_t)ni;
+                    if (lane == 0) S->ipar[ii] = (uint16_t)ni;
                     ++ii;
-                    nw = ii < ni ? zmi_uniform(S->nfreq[ii]) : 0xFFFFFFFFu;
+                    nw = ii < ni ? enc_rd5(nwr, ii) : 0xFFFFFFFFu;
                 }
             }
-            S->nfreq[ni] = w;
+            enc_wr5(nwr, ni, w);
             if (ii == ni) nw = w;   // the node just made is the head of its queue
         }
     }
@@ -406,58 +361,73 @@ static __device__ void enc_gen_codes_w(EncShared* S, const uint8_t* lens, uint32
     zmi_wave_sync();
 }
 
-// ---- lane 0: plan the dynamic header -- run-length code the code lengths, build the code-length code ----
-// leaves the symbol list in hsym/hext (count in misc[M_HC]), HLIT/HDIST/HCLEN and the header's size in bits in misc
-static __device__ void enc_header_plan(EncShared* S) {
-    uint32_t hlit = 286u;
-    while (hlit > 257u && S->llen[hlit - 1u] == 0) --hlit;
-    uint32_t hdist = 30u;
-    while (hdist > 1u && S->dlen[hdist - 1u] == 0) --hdist;
+// ---- all lanes: plan the dynamic header -- run-length code the code lengths, build the code-length code ----
+// leaves the symbol list in hsym/hext (count in misc[M_HC]), HLIT/HDIST/HCLEN and the header's size in bits in misc.
+// The run-length scan is serial but reads the lengths from registers with scalar lane reads; the code-length code
+// (19 symbols) goes through the same wave-cooperative builders as the two big codes.
+static __device__ void enc_header_plan_w(EncShared* S) {
+    const uint32_t lane = zmi_lane();
+    // HLIT / HDIST: trailing zero lengths are not transmitted
+    uint32_t hlit = 257u, hdist = 1u;
+    for (uint32_t base = 0; base < 320u; base += 64u) {
+        const uint32_t i = base + lane;
+        const uint64_t ml = __ballot(i < 286u && S->llen[i] != 0);
+        if (ml) { const uint32_t top = base + 64u - (uint32_t)__clzll((unsigned long long)ml); hlit = top > hlit ? top : hlit; }
+    }
+    {
+        const uint64_t md = __ballot(lane < 30u && S->dlen[lane] != 0);
+        if (md) { const uint32_t top = 64u - (uint32_t)__clzll((unsigned long long)md); hdist = top > hdist ? top : hdist; }
+    }
     const uint32_t total = hlit + hdist;
-    for (uint32_t i = 0; i < ENC_NBL; ++i) S->blfreq[i] = 0;
+    uint32_t lr[5];
+#pragma unroll
+    for (uint32_t c = 0; c < 5u; ++c) {
+        const uint32_t i = lane + 64u * c;
+        lr[c] = i < hlit ? S->llen[i] : (i < total ? S->dlen[i - hlit] : 0xFFu);
+    }
     uint32_t hc = 0;
-    uint32_t i = 0;
-    while (i < total) {
-        uint32_t v = i < hlit ? S->llen[i] : S->dlen[i - hlit];
-        uint32_t run = 1;
-        while (i + run < total) {
-            uint32_t u = (i + run) < hlit ? S->llen[i + run] : S->dlen[i + run - hlit];
-            if (u != v) break;
-            ++run;
-        }
-        i += run;
-        if (v == 0u) {
-            while (run >= 11u) { uint32_t r = run > 138u ? 138u : run; S->hsym[hc] = 18; S->hext[hc++] = (uint8_t)(r - 11u); S->blfreq[18]++; run -= r; }
-            if (run >= 3u) { S->hsym[hc] = 17; S->hext[hc++] = (uint8_t)(run - 3u); S->blfreq[17]++; run = 0; }
-            while (run > 0u) { S->hsym[hc] = 0; S->hext[hc++] = 0; S->blfreq[0]++; --run; }
-        } else {
-            S->hsym[hc] = (uint8_t)v; S->hext[hc++] = 0; S->blfreq[v]++; --run;
-            while (run >= 3u) { uint32_t r = run > 6u ? 6u : run; S->hsym[hc] = 16; S->hext[hc++] = (uint8_t)(r - 3u); S->blfreq[16]++; run -= r; }
-            while (run > 0u) { S->hsym[hc] = (uint8_t)v; S->hext[hc++] = 0; S->blfreq[v]++; --run; }
+    {
+        uint32_t v = enc_rd5(lr, 0), run = 1;
+        for (uint32_t i = 1; i <= total; ++i) {
+            const uint32_t u = i < total ? enc_rd5(lr, i) : 0x100u;   // 0x100: no length has this value, closes the last run
+            if (u == v) { ++run; continue; }
+            // emit the run of `run` lengths of value v (stores by lane 0; the scan itself is wave-uniform)
+            if (v == 0u) {
+                while (run >= 11u) { uint32_t r = run > 138u ? 138u : run; if (lane == 0) { S->hsym[hc] = 18; S->hext[hc] = (uint8_t)(r - 11u); } ++hc; run -= r; }
+                if (run >= 3u) { if (lane == 0) { S->hsym[hc] = 17; S->hext[hc] = (uint8_t)(run - 3u); } ++hc; run = 0; }
+                while (run > 0u) { if (lane == 0) { S->hsym[hc] = 0; S->hext[hc] = 0; } ++hc; --run; }
+            } else {
+                if (lane == 0) { S->hsym[hc] = (uint8_t)v; S->hext[hc] = 0; }
+                ++hc; --run;
+                while (run >= 3u) { uint32_t r = run > 6u ? 6u : run; if (lane == 0) { S->hsym[hc] = 16; S->hext[hc] = (uint8_t)(r - 3u); } ++hc; run -= r; }
+                while (run > 0u) { if (lane == 0) { S->hsym[hc] = (uint8_t)v; S->hext[hc] = 0; } ++hc; --run; }
+            }
+            v = u;
+            run = 1;
         }
     }
-    // code-length code: insertion sort of <= 19 symbols, then the serial length builder (limit 7)
-    uint32_t nnz = 0;
-    for (uint32_t s = 0; s < ENC_NBL; ++s) {
-        uint32_t f = S->blfreq[s];
-        if (!f) continue;
-        uint32_t k = nnz++;
-        while (k > 0u && S->blfreq[S->order[k - 1u]] > f) { S->order[k] = S->order[k - 1u]; --k; }
-        S->order[k] = (uint16_t)s;
-    }
-    enc_huff_lengths(S, S->blfreq, ENC_NBL, nnz, 7u, S->bllen);
-    enc_gen_codes(S, S->bllen, ENC_NBL, 7u, S->blcode);
+    if (lane < 32u) S->blfreq[lane] = 0;
+    zmi_wave_sync();
+    for (uint32_t k = lane; k < hc; k += 64u) atomicAdd(&S->blfreq[S->hsym[k]], 1u);
+    zmi_wave_sync();
+    enc_rank_sort(S, S->blfreq, ENC_NBL);
+    enc_huff_lengths_w(S, S->blfreq, ENC_NBL, zmi_uniform(S->misc[M_NNZ]), 7u, S->bllen);
+    enc_gen_codes_w(S, S->bllen, ENC_NBL, 7u, S->blcode);
     const uint8_t blorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-    uint32_t hclen = 19u;
-    while (hclen > 4u && S->bllen[blorder[hclen - 1u]] == 0) --hclen;
-    uint32_t bits = 3u + 14u + 3u * hclen;
-    for (uint32_t s = 0; s < ENC_NBL; ++s) bits += S->blfreq[s] * S->bllen[s];
-    bits += S->blfreq[16] * 2u + S->blfreq[17] * 3u + S->blfreq[18] * 7u;
-    S->misc[M_HC] = hc;
-    S->misc[M_HLIT] = hlit;
-    S->misc[M_HDIST] = hdist;
-    S->misc[M_HCLEN] = hclen;
-    S->misc[M_DYNHDR] = bits;
+    const uint64_t used = __ballot(lane < 19u && S->bllen[blorder[lane < 19u ? lane : 0u]] != 0);
+    uint32_t hclen = used ? 64u - (uint32_t)__clzll((unsigned long long)used) : 0u;
+    if (hclen < 4u) hclen = 4u;
+    uint32_t part = 0;
+    if (lane < ENC_NBL) part = S->blfreq[lane] * (S->bllen[lane] + (lane == 16u ? 2u : (lane == 17u ? 3u : (lane == 18u ? 7u : 0u))));
+    const uint32_t bits = 3u + 14u + 3u * hclen + zmi_wave_sum(part);
+    if (lane == 0) {
+        S->misc[M_HC] = hc;
+        S->misc[M_HLIT] = hlit;
+        S->misc[M_HDIST] = hdist;
+        S->misc[M_HCLEN] = hclen;
+        S->misc[M_DYNHDR] = bits;
+    }
+    zmi_wave_sync();
 }
 
 // all lanes: emit one deflate block for tokens [tok, tok+ntok) / raw bytes [bstart, bend)
@@ -476,8 +446,7 @@ static __device__ __noinline__ EncWriter enc_flush_block(EncShared* S, EncWriter
     const uint32_t blen = bend - bstart;
     const uint32_t nsub = blen ? (blen + 32767u) / 32768u : 1u;
     const uint32_t stored_bits = 8u * blen + 42u * nsub;
-    if (lane == 0) enc_header_plan(S);
-    zmi_wave_sync();
+    enc_header_plan_w(S);
     // cost of the block with the dynamic and with the static code (lane-parallel over the symbols)
     uint32_t dpart = 0, spart = 0;
     for (uint32_t i = lane; i < 286u + 30u; i += 64u) {

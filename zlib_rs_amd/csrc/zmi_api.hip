@@ -162,22 +162,23 @@ extern "C" uint64_t zmi_deflate_bound(uint64_t n, int wrap) {
 // (zlib-rs/src/deflate/algorithm/mod.rs:69-82).  Every position is searched in parallel, so the
 // chain budget is what the slowest lane of a wave spends; see DESIGN.md for the measured trade-off.
 struct zmi_level_cfg {
-    uint32_t chain, nice, good, lazy;
+    uint32_t chain, nice, good, lazy, tok;
 };
-// chain = candidates examined per position (the 4-byte probe counts as one).  Level 6 is tuned to the ratio the
-// first version of this table reached with 8 (2.213 on the benchmark shards; the reference's level 6 gives
-// 2.233): dropping far 4/5-byte matches (lp.far4 / far5) pays for two chain steps of ~9 % of the run time each.
+// chain = candidates examined per position (the 4-byte probe counts as one); tok = tokens per sub-block of the
+// encoder's adaptive block splitting.  A chain step costs ~9 % of the level-6 run time and buys ~0.2 % ratio; the
+// block splitting buys 2.2 % for ~10 %, dropping far 4/5-byte matches 0.3 % for nothing -- so the table spends its
+// time there first.  Level 6 (chain 4): ratio 2.247 on the benchmark shards, the reference's level 6 gives 2.233.
 static const zmi_level_cfg kLevels[10] = {
-    {0, 0, 0, 0},         // 0: stored
-    {2, 16, 8, 0},        // 1
-    {3, 32, 8, 0},        // 2
-    {4, 32, 8, 4},        // 3
-    {4, 64, 16, 8},       // 4
-    {5, 64, 16, 16},      // 5
-    {6, 128, 32, 16},     // 6
-    {12, 128, 32, 32},    // 7
-    {48, 258, 64, 128},   // 8
-    {128, 258, 128, 258}, // 9
+    {0, 0, 0, 0, 4096},          // 0: stored
+    {2, 16, 8, 0, 8192},         // 1
+    {3, 32, 8, 0, 8192},         // 2
+    {3, 32, 8, 4, 4096},         // 3
+    {3, 64, 16, 8, 4096},        // 4
+    {3, 128, 32, 16, 4096},      // 5
+    {4, 128, 32, 16, 4096},      // 6
+    {6, 128, 32, 32, 4096},      // 7
+    {16, 258, 64, 128, 4096},    // 8
+    {128, 258, 128, 258, 2048},  // 9
 };
 
 extern "C" int zmi_checksum_batch_dev(zmi_ctx* c, const void* d_data, const uint64_t* d_off, const uint32_t* d_len,
@@ -302,7 +303,7 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     lp.far5 = 8192u;
     if (const char* f4 = getenv("ZMI_FAR4")) lp.far4 = (uint32_t)atoi(f4);
     if (const char* f5 = getenv("ZMI_FAR5")) lp.far5 = (uint32_t)atoi(f5);
-    ep.block_tokens = 4096u;
+    ep.block_tokens = L.tok;
     ep.split_hdr_bits = 640u;
     if (const char* hb = getenv("ZMI_SPLIT_HDR")) ep.split_hdr_bits = (uint32_t)atoi(hb);
     if (const char* bt = getenv("ZMI_BLOCK_TOKENS")) ep.block_tokens = (uint32_t)atoi(bt) >= 64u ? (uint32_t)atoi(bt) : 64u;

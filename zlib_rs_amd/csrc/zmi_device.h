@@ -41,6 +41,20 @@ static inline uint32_t zmi_uniform(uint32_t v) { return v; }
 static __device__ __forceinline__ uint32_t zmi_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 #endif
 
+// `old` with lane `k` (wave-uniform) replaced by the wave-uniform value `v`
+#ifdef ZMI_EMU
+static inline uint32_t zmi_writelane(uint32_t old, uint32_t v, uint32_t k) { return (threadIdx.x & 63u) == k ? v : old; }
+#else
+static __device__ __forceinline__ uint32_t zmi_writelane(uint32_t old, uint32_t v, uint32_t k) {
+    // (no writelane builtin in this compiler) value and lane select must be scalar: both go through readfirstlane
+    const uint32_t sv = zmi_uniform(v), sk = zmi_uniform(k);
+    // two different SGPR operands would exceed the constant-bus limit of a gfx9 VALU instruction: the lane select goes via M0
+    asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(old) : "s"(sv), "s"(sk) : "m0");
+    return old;
+}
+#endif
+
+
 // index of the lowest set bit, 0xFFFFFFFF for 0 (v_ffbl_b32's native result; written as asm because the compiler's
 // own ctz forms either add a compare + select for the zero case or make it undefined)
 #ifdef ZMI_EMU
