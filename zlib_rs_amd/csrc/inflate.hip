@@ -61,6 +61,7 @@ struct InfShared {
     uint8_t stage[320];
     uint32_t cnt[16];
     uint32_t offs[16];
+    uint32_t fcode[16];   // first canonical code of every length
     uint32_t misc[8];
     __attribute__((aligned(16))) uint8_t inbuf[INF_CHUNK + 32];  // staged compressed input (one coalesced load per KiB)
 };
@@ -142,13 +143,30 @@ static const __device__ uint8_t inf_dext[32] = {0, 0, 0,  0,  1,  1,  2,  2,  3,
 // kind: 0 = code-length code (symbols are values), 1 = literal/length, 2 = distance
 // Builds a two-level lookup table from S->lens[0..nsym).  Returns 0 ok, 1 over-subscribed /
 // incomplete, 2 table overflow.  All lanes call; `used` receives the entry count.
+static __device__ __forceinline__ uint32_t inf_entry(uint32_t kind, uint32_t sym, uint32_t l) {
+    if (kind == 0u) return INF_ENTRY(sym, INF_OP_LIT, l);
+    if (kind == 1u) {
+        if (sym < 256u) return INF_ENTRY(sym, INF_OP_LIT, l);
+        if (sym == 256u) return INF_ENTRY(0, INF_OP_EOB, l);
+        if (sym - 257u < 29u) return INF_ENTRY(inf_lbase[sym - 257u], INF_OP_BASE | inf_lext[sym - 257u], l);
+        return INF_ENTRY(0, INF_OP_BAD, l);
+    }
+    if (sym < 30u) return INF_ENTRY(inf_dbase[sym], INF_OP_BASE | inf_dext[sym], l);
+    return INF_ENTRY(0, INF_OP_BAD, l);
+}
+
+// Lane-parallel where the work is: the length histogram (LDS atomics), every symbol's canonical code (first code of
+// its length + its rank among the lower-indexed symbols of that length: ballot + mbcnt, running counts in scalar
+// registers) and the root-table entries of the codes that fit the root.  Only the codes longer than the root (few)
+// are walked serially, because the sub-tables are sized by looking ahead in canonical order.
 static __device__ __noinline__ uint32_t inf_build(InfShared* S, uint32_t kind, uint32_t nsym, uint32_t* tab, uint32_t root,
                                      uint32_t cap) {
     const uint32_t lane = zmi_lane();
-    // lane 0: histogram, validity, counting sort of the symbols by (length, index)
+    if (lane < 16u) S->cnt[lane] = 0;
+    zmi_wave_sync();
+    for (uint32_t i = lane; i < nsym; i += 64u) atomicAdd(&S->cnt[S->lens[i]], 1u);
+    zmi_wave_sync();
     if (lane == 0) {
-        for (uint32_t l = 0; l < 16u; ++l) S->cnt[l] = 0;
-        for (uint32_t i = 0; i < nsym; ++i) S->cnt[S->lens[i]]++;
         uint32_t maxl = 15u;
         while (maxl > 0u && S->cnt[maxl] == 0u) --maxl;
         int32_t left = 1;
@@ -159,14 +177,14 @@ static __device__ __noinline__ uint32_t inf_build(InfShared* S, uint32_t kind, u
             if (left < 0) { bad = 1; break; }
         }
         if (!bad && left > 0 && maxl != 0u && (kind == 0u || maxl != 1u)) bad = 1;
-        uint32_t o = 0;
-        for (uint32_t l = 1; l <= 15u; ++l) { S->offs[l] = o; o += S->cnt[l]; }
+        uint32_t o = 0, code = 0;
         S->offs[0] = 0;
-        uint32_t tmp[16];
-        for (uint32_t l = 0; l < 16u; ++l) tmp[l] = S->offs[l];
-        for (uint32_t i = 0; i < nsym; ++i) {
-            uint32_t l = S->lens[i];
-            if (l) S->sorted[tmp[l]++] = (uint16_t)i;
+        S->fcode[0] = 0;
+        for (uint32_t l = 1; l <= 15u; ++l) {
+            S->offs[l] = o;
+            S->fcode[l] = code;
+            o += S->cnt[l];
+            code = (code + S->cnt[l]) << 1;
         }
         S->misc[0] = bad;
         S->misc[1] = maxl;
@@ -181,76 +199,78 @@ static __device__ __noinline__ uint32_t inf_build(InfShared* S, uint32_t kind, u
     zmi_wave_sync();
     if (maxl == 0u) return 0u;  // no codes at all: every lookup reports an invalid code
 
-    uint32_t code = 0;       // canonical code of the current symbol (MSB-first)
-    uint32_t curlen = 0;
+    // every symbol: its place in the (length, index) order and its code; short codes fill their root entries
+    uint32_t run[16];
+#pragma unroll
+    for (uint32_t d = 0; d < 16u; ++d) run[d] = 0;
+    for (uint32_t base = 0; base < nsym; base += 64u) {
+        const uint32_t i = base + lane;
+        const uint32_t l = i < nsym ? S->lens[i] : 0u;
+        uint32_t r = 0;
+#pragma unroll
+        for (uint32_t d = 1; d < 16u; ++d) {
+            const uint64_t m = __ballot(l == d);
+            r = l == d ? run[d] + zmi_mbcnt(m) : r;
+            run[d] += (uint32_t)__popcll(m);
+        }
+        if (l != 0u) {
+            S->sorted[S->offs[l] + r] = (uint16_t)i;
+            if (l <= root) {
+                const uint32_t code = S->fcode[l] + r;
+                const uint32_t rev = __brev(code) >> (32u - l);   // LSB-first bit pattern
+                const uint32_t ent = inf_entry(kind, i, l);
+                for (uint32_t j = 0; j < (1u << (root - l)); ++j) tab[rev + (j << l)] = ent;
+            }
+        }
+    }
+    zmi_wave_sync();
+    if (maxl <= root) return 0u;
+
+    // codes longer than the root, in canonical order: second-level tables
+    uint32_t k = zmi_uniform(S->offs[root + 1u]);
+    uint32_t curlen = root + 1u;
+    uint32_t code = zmi_uniform(S->fcode[root + 1u]);   // canonical code of the current symbol (MSB-first)
     uint32_t used = rsize;   // next free sub-table slot
     uint32_t sub_prefix = 0xFFFFFFFFu, sub_off = 0, sub_bits = 0;
-    for (uint32_t k = 0; k < ncoded; ++k) {
+    for (; k < ncoded; ++k) {
         const uint32_t sym = zmi_uniform(S->sorted[k]);
         const uint32_t l = zmi_uniform(S->lens[sym]);
         code <<= (l - curlen);
         curlen = l;
-        // entry payload
-        uint32_t ent;
-        if (kind == 0u) ent = INF_ENTRY(sym, INF_OP_LIT, l);
-        else if (kind == 1u) {
-            if (sym < 256u) ent = INF_ENTRY(sym, INF_OP_LIT, l);
-            else if (sym == 256u) ent = INF_ENTRY(0, INF_OP_EOB, l);
-            else if (sym - 257u < 29u) ent = INF_ENTRY(inf_lbase[sym - 257u], INF_OP_BASE | inf_lext[sym - 257u], l);
-            else ent = INF_ENTRY(0, INF_OP_BAD, l);
-        } else {
-            if (sym < 30u) ent = INF_ENTRY(inf_dbase[sym], INF_OP_BASE | inf_dext[sym], l);
-            else ent = INF_ENTRY(0, INF_OP_BAD, l);
-        }
+        const uint32_t ent = inf_entry(kind, sym, l);
         const uint32_t rev = __brev(code) >> (32u - l);  // LSB-first bit pattern
-        if (l <= root) {
-            const uint32_t nrep = 1u << (root - l);
-            for (uint32_t j = lane; j < nrep; j += 64u) tab[rev + (j << l)] = ent;
-        } else {
-            const uint32_t prefix = rev & (rsize - 1u);
-            if (prefix != sub_prefix) {
-                // new sub-table: the codes sharing this root prefix are contiguous in canonical
-                // order; the longest of them sizes the table
-                uint32_t last = l;
-                // incremental walk (lengths are non-decreasing in sorted order)
-                {
-                    uint32_t c = code, cl = l;
-                    for (uint32_t k2 = k + 1u; k2 < ncoded; ++k2) {
-                        uint32_t l2 = zmi_uniform(S->lens[zmi_uniform(S->sorted[k2])]);
-                        c = (c + 1u) << (l2 - cl);
-                        cl = l2;
-                        if ((c >> (cl - root)) != (code >> (l - root))) break;
-                        last = l2;
-                    }
+        const uint32_t prefix = rev & (rsize - 1u);
+        if (prefix != sub_prefix) {
+            // new sub-table: the codes sharing this root prefix are contiguous in canonical
+            // order; the longest of them sizes the table
+            uint32_t last = l;
+            {
+                uint32_t c = code, cl = l;
+                for (uint32_t k2 = k + 1u; k2 < ncoded; ++k2) {
+                    uint32_t l2 = zmi_uniform(S->lens[zmi_uniform(S->sorted[k2])]);
+                    c = (c + 1u) << (l2 - cl);
+                    cl = l2;
+                    if ((c >> (cl - root)) != (code >> (l - root))) break;
+                    last = l2;
                 }
-                sub_prefix = prefix;
-                sub_bits = last - root;
-                sub_off = used;
-                used += 1u << sub_bits;
-                if (used > cap) return 2u;
-                for (uint32_t j = lane; j < (1u << sub_bits); j += 64u) tab[sub_off + j] = INF_ENTRY(0, INF_OP_BAD, 0);
-                if (lane == 0) tab[prefix] = INF_ENTRY(sub_off, INF_OP_LINK | sub_bits, root);
-                zmi_wave_sync();
             }
-            const uint32_t sl = l - root;            // bits of this code inside the sub-table
-            const uint32_t srev = rev >> root;
-            const uint32_t nrep = 1u << (sub_bits - sl);
-            for (uint32_t j = lane; j < nrep; j += 64u) tab[sub_off + srev + (j << sl)] = ent;
+            sub_prefix = prefix;
+            sub_bits = last - root;
+            sub_off = used;
+            used += 1u << sub_bits;
+            if (used > cap) return 2u;
+            for (uint32_t j = lane; j < (1u << sub_bits); j += 64u) tab[sub_off + j] = INF_ENTRY(0, INF_OP_BAD, 0);
+            if (lane == 0) tab[prefix] = INF_ENTRY(sub_off, INF_OP_LINK | sub_bits, root);
+            zmi_wave_sync();
         }
+        const uint32_t sl = l - root;            // bits of this code inside the sub-table
+        const uint32_t srev = rev >> root;
+        const uint32_t nrep = 1u << (sub_bits - sl);
+        for (uint32_t j = lane; j < nrep; j += 64u) tab[sub_off + srev + (j << sl)] = ent;
         code += 1u;
     }
     zmi_wave_sync();
     return 0u;
-}
-
-static __device__ __forceinline__ uint32_t inf_lookup(const uint32_t* tab, uint32_t root, const InfBits& B) {
-    uint32_t e = zmi_uniform(tab[inf_peek(B, root)]);
-    uint32_t op = (e >> 8) & 0xFFu;
-    if (op & INF_OP_LINK) {
-        uint32_t sb = op & 0x0Fu;
-        e = zmi_uniform(tab[(e >> 16) + ((uint32_t)(B.hold >> root) & ((1u << sb) - 1u))]);
-    }
-    return e;
 }
 
 // One speculative token: the literal / length code at the low end of (hi:lo) and, if it is a length, the
