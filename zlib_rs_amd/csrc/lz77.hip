@@ -30,7 +30,7 @@
 //   * output: one u32 per position  lit | len<<8 | (dist-1)<<17  (len = 0: no match >= 4).
 //     The parse (greedy/lazy selection) happens in encode.hip, which sees the best match of every
 //     position, not just the visited ones.
-// Bound: VALU issue (7.2 instructions per input byte, pipes ~87 % busy at level 6), not HBM: algorithmic HBM
+// Bound: VALU issue (5.5 instructions per input byte, pipes ~83 % busy at level 6), not HBM: algorithmic HBM
 // traffic is 1 B read + 4 B scratch written per input byte (measured: exactly that, profiles/r01_traffic.json).
 #include "zmi_device.h"
 #include "zmi_kernels.h"
