@@ -11,21 +11,25 @@
 //   BitWriter / compress_block  zlib-rs/src/deflate.rs:907-1175
 //   header / trailer            zlib-rs/src/deflate.rs:1572-1601,2574-2627,2772-2789
 //
-// MI355X design: ONE WAVE PER SHARD (64-thread workgroups, ~9 KiB LDS, 16+ shards resident per CU),
-// no workgroup barriers at all.  The batch supplies the parallelism (thousands of shards); inside a
-// shard the wave walks 64 positions per step:
+// MI355X design: ONE WAVE PER 64 KiB PIECE of a shard (64-thread workgroups, ~9 KiB LDS, 16 waves resident per
+// CU), no workgroup barriers at all.  The batch supplies the parallelism (16 pieces x thousands of shards); the
+// pieces of a shard end byte aligned and are concatenated by zmi_compact_kernel.  Inside a piece the wave walks
+// 64 positions per step:
 //   * parse: every lane owns one position and knows its best match (from lz77.hip).  The greedy/lazy
 //     rule gives each position a local "next token" pointer; six rounds of wave-wide pointer doubling
 //     (ds_bpermute) turn the pointers into the 64-bit set of positions reachable from the segment's
 //     entry point -- the serial token walk of the CPU parse becomes log2(64) shuffles.
 //   * tokens are compacted with mbcnt and overwrite the match scratch in place (token index <=
 //     position index), histogrammed with LDS atomics.
-//   * per block (64 KiB of input): lane-parallel rank sort of the symbol frequencies, a two-queue
-//     Huffman merge + length limiting on lane 0, canonical codes, RFC 1951 header.
+//   * blocks follow the data: after every sub-block of 4096 tokens an entropy test decides whether it joins the
+//     open block or starts a new one (enc_split_pays).
+//   * per block: lane-parallel rank sort of the symbol frequencies (scalar lane reads), two-queue Huffman merge on
+//     wave-uniform state with both queues in registers, depths by parallel relaxation, Kraft-exact length limiting,
+//     canonical codes by ballot ranks, RFC 1951 header planned from registers and emitted through the bit packer.
 //   * bit packing: a wave prefix-sum over the code lengths gives every token its output bit
 //     position; codes are OR-ed into an LDS staging window with ds_or and whole dwords are stored
 //     coalesced.  No serial bit writer on the token path.
-// Bound: instruction issue (integer VALU/LDS), not HBM: 4 B/position scratch read + <=4 B written
+// Bound: instruction issue (integer VALU/SALU/LDS), not HBM: 4 B/position scratch read + <=4 B written
 // back + 1/ratio B of output per input byte.
 #include "zmi_device.h"
 #include "zmi_kernels.h"
