@@ -329,7 +329,10 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     while (pieces > 1u) {
         uint64_t region = (out_stride / pieces) & ~15ull;
         uint64_t psize = (((uint64_t)max_len + pieces - 1u) / pieces + 63u) & ~63ull;
-        uint64_t worst = psize + 5u * (psize / 32768u + 2u) + 32u;
+        // worst case: every block stored (5 header bytes + byte alignment); a block holds at least one sub-block of
+        // block_tokens tokens (>= as many input bytes), stored sub-blocks are cut at 32 KiB
+        const uint64_t min_block = ep.block_tokens < 32768u ? ep.block_tokens : 32768u;
+        uint64_t worst = psize + 6u * (psize / min_block + 3u) + 32u;
         if (region >= worst) break;
         --pieces;
     }
