@@ -143,3 +143,22 @@ def test_inflate_unaligned_layout_and_scratch_limit(eng, o):
     assert st[0] == 0 and outs[0] == big[0]
     assert -4 in st and all(x in (0, -4) for x in st)
     assert all(o_ == big[0] for o_, x in zip(outs, st) if x == 0)
+
+
+def test_adaptive_block_splitting(eng, o, monkeypatch):
+    """drifting statistics get blocks of their own (better ratio than one block per 64 KiB), stationary text does not
+    split; the smallest sub-blocks on incompressible data (all stored) still fit the deflate bound"""
+    walk, text = o.gen_shard(5, 1 << 16), o.gen_shard(0, 1 << 16)
+    sizes = {}
+    for tokens in ("1000000", "4096"):
+        monkeypatch.setenv("ZMI_BLOCK_TOKENS", tokens)
+        outs, st = eng.deflate([walk, text], level=6, wrap=1)
+        assert st == [0, 0] and zlib.decompress(outs[0]) == walk and zlib.decompress(outs[1]) == text
+        sizes[tokens] = [len(x) for x in outs]
+    assert sizes["4096"][0] < sizes["1000000"][0] * 0.95          # the random walk: > 5 % smaller
+    assert sizes["4096"][1] <= sizes["1000000"][1]                # text: never worse (a split must pay for its header)
+    monkeypatch.setenv("ZMI_BLOCK_TOKENS", "64")
+    noise = o.prng_bytes(3, 50000, 1)
+    outs, st = eng.deflate([noise, noise[:777]], level=6, wrap=1)
+    assert st == [0, 0] and zlib.decompress(outs[0]) == noise and zlib.decompress(outs[1]) == noise[:777]
+    assert len(outs[0]) <= len(noise) + len(noise) // 8 + 64
