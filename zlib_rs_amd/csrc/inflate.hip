@@ -495,37 +495,82 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             zmi_wave_sync();
             // code-length code table lives at the start of dtab (128 entries, root 7)
             if (zmi_uniform(inf_build(S, 0u, 19u, S->dtab, 7u, INF_DSIZE))) { st = ZMI_DATA_ERROR; break; }  // "invalid code lengths set"
+            // ---- the nlen + ndist code lengths, run-length coded with the code-length code ----
+            // Same scheme as the symbol rounds below: lane i decodes the code-length token (<= 7 + 7 bits) that would
+            // start at bit P + i, the real chain is walked with scalar lane reads, a wave scan places the runs.  Zero
+            // runs (symbols 17 / 18) need no stores at all -- the array is cleared up front -- and a "repeat previous"
+            // (16) fetches its value from the nearest earlier token that is not a 16.
             uint32_t have = 0, prevl = 0;
             const uint32_t total = nlen + ndist;
-            while (have < total) {
-                inf_refill(B);
-                uint32_t e = zmi_uniform(S->dtab[inf_peek(B, 7)]);
-                uint32_t eb = e & 0xFFu;
-                if (((e >> 8) & 0xFFu) != INF_OP_LIT || eb == 0u) { st = ZMI_DATA_ERROR; break; }
-                if (B.nbits < eb) { st = ZMI_BUF_ERROR; break; }
-                uint32_t sym = e >> 16;
-                uint32_t rep, val;
-                if (sym < 16u) {
-                    inf_drop(B, eb);
-                    if (lane == 0) S->stage[have] = (uint8_t)sym;
-                    prevl = sym;
-                    ++have;
-                    continue;
+            for (uint32_t i = lane; i < 320u; i += 64u) S->stage[i] = 0;
+            zmi_wave_sync();
+            {
+                uint64_t P = 8ull * B.ipos - B.nbits;
+                const uint64_t Pend = 8ull * B.n;
+                const uint32_t* iw = (const uint32_t*)B.inbuf;
+                while (have < total && st == ZMI_OK) {
+                    uint32_t ib = (uint32_t)(P >> 3);
+                    uint32_t relbyte = (uint32_t)((int32_t)ib - B.cbase);
+                    if ((int32_t)relbyte < 0 || relbyte + 20u > INF_CHUNK) {
+                        B.cbase = (int32_t)zmi_uniform((uint32_t)inf_load_chunk(B.src, B.n, ib, B.inbuf));
+                        relbyte = (uint32_t)((int32_t)ib - B.cbase);
+                    }
+                    const uint32_t bo = ((relbyte << 3) | ((uint32_t)P & 7u)) + lane;
+                    const uint32_t wi = bo >> 5, sh = bo & 31u;
+                    const uint32_t lo = __builtin_amdgcn_alignbit(iw[wi + 1u], iw[wi], sh);
+                    const uint64_t left = Pend - P;
+                    const int32_t rem = (int32_t)(left > 0x40000000ull ? 0x40000000u : (uint32_t)left) - (int32_t)lane;
+                    const uint32_t e = S->dtab[lo & 127u];
+                    const uint32_t bits = e & 0xFFu, sym = e >> 16;
+                    const bool bad = ((e >> 8) & 0xFFu) != INF_OP_LIT || bits == 0u;
+                    const uint32_t xb = sym == 16u ? 2u : (sym == 17u ? 3u : (sym == 18u ? 7u : 0u));
+                    const uint32_t t = bits + xb;
+                    const uint32_t x = (lo >> bits) & ((1u << xb) - 1u);
+                    const uint32_t tw = bad ? 256u : ((int32_t)t > rem ? 128u : t);   // 128: more input needed, 256: invalid code
+                    uint32_t pos = 0, w = 0;
+                    uint64_t M = 0;
+                    inf_walk(tw, pos, M, w);
+                    int32_t rst = ZMI_OK;
+                    if (pos < 64u) rst = (w & 128u) ? ZMI_BUF_ERROR : ZMI_DATA_ERROR;
+                    bool on = (M >> lane) & 1ull;
+                    const uint32_t rep = on ? (sym < 16u ? 1u : (sym == 18u ? 11u + x : 3u + x)) : 0u;
+                    const uint32_t incl = zmi_wave_incl_scan(rep), excl = incl - rep;
+                    // "invalid bit length repeat": a repeat with nothing in front of it, or a run past the last length
+                    const uint64_t badrep = __ballot(on && ((sym == 16u && have + excl == 0u) || have + incl > total));
+                    const uint64_t ends = __ballot(on && have + incl == total);
+                    const uint32_t kb = badrep ? (uint32_t)__ffsll((unsigned long long)badrep) - 1u : 64u;
+                    const uint32_t ke = ends ? (uint32_t)__ffsll((unsigned long long)ends) - 1u : 64u;
+                    if (kb < 64u && kb <= ke) { st = ZMI_DATA_ERROR; break; }
+                    if (ke < 64u) {   // the token in lane ke completes the header; nothing behind it belongs to it
+                        M &= (2ull << ke) - 1ull;
+                        on = (M >> lane) & 1ull;
+                        pos = ke + zmi_readlane(t, ke);
+                        rst = ZMI_OK;
+                    }
+                    // value of every run: its own symbol, zero, or (16) that of the nearest earlier token that is not a 16
+                    const uint32_t own = sym < 16u ? sym : 0u;
+                    const uint64_t N = __ballot(on && sym != 16u);
+                    const uint64_t below = N & ((1ull << lane) - 1ull);
+                    const uint32_t src_lane = below ? 63u - (uint32_t)__clzll((unsigned long long)below) : lane;
+                    const uint32_t fetched = (uint32_t)__shfl((int)own, (int)src_lane);
+                    const uint32_t val = sym == 16u ? (below ? fetched : prevl) : own;
+                    if (on && val != 0u)
+                        for (uint32_t j = 0; j < rep; ++j) S->stage[have + excl + j] = (uint8_t)val;
+                    if (M) {
+                        const uint32_t kl = 63u - (uint32_t)__clzll((unsigned long long)M);   // last token of this round
+                        prevl = zmi_readlane(val, kl);
+                        have += zmi_readlane(incl, kl);
+                    }
+                    P += pos;
+                    if (rst != ZMI_OK) st = rst;
                 }
-                uint32_t xb = sym == 16u ? 2u : (sym == 17u ? 3u : 7u);
-                if (B.nbits < eb + xb) { st = ZMI_BUF_ERROR; break; }
-                inf_drop(B, eb);
-                uint32_t x = inf_peek(B, xb);
-                inf_drop(B, xb);
-                if (sym == 16u) {
-                    if (have == 0u) { st = ZMI_DATA_ERROR; break; }  // "invalid bit length repeat"
-                    val = prevl; rep = 3u + x;
-                } else if (sym == 17u) { val = 0; rep = 3u + x; }
-                else { val = 0; rep = 11u + x; }
-                if (have + rep > total) { st = ZMI_DATA_ERROR; break; }  // "invalid bit length repeat"
-                if (lane == 0) for (uint32_t j = 0; j < rep; ++j) S->stage[have + j] = (uint8_t)val;
-                have += rep;
-                prevl = val;
+                B.ipos = (uint32_t)(P >> 3);
+                B.hold = 0;
+                B.nbits = 0;
+                if (st == ZMI_OK) {
+                    inf_refill(B);
+                    inf_drop(B, (uint32_t)P & 7u);
+                }
             }
             if (st != ZMI_OK) break;
             zmi_wave_sync();
