@@ -182,36 +182,32 @@ static __device__ __forceinline__ void enc_wr5(uint32_t (&r)[5], uint32_t idx, u
 // ---- lane-parallel rank sort of the symbols with non-zero frequency (ascending freq, then index) ----
 static __device__ void enc_rank_sort(EncShared* S, const uint32_t* freq, uint32_t nsym) {
     const uint32_t lane = zmi_lane();
-    uint32_t fi[5], rk[5];
+    // one comparison per pair: key = count << 9 | symbol (a block has fewer than 2^23 tokens)
+    uint32_t key[5], rk[5];
     uint32_t mine = 0;
 #pragma unroll
     for (uint32_t k = 0; k < 5u; ++k) {
-        uint32_t i = lane + 64u * k;
-        fi[k] = i < nsym ? freq[i] : 0u;
+        const uint32_t i = lane + 64u * k;
+        const uint32_t f = i < nsym ? freq[i] : 0u;
+        key[k] = f ? ((f << 9) | i) : 0u;
         rk[k] = 0;
-        mine += fi[k] != 0u;
+        mine += f != 0u;
     }
     // every symbol with a non-zero count is broadcast once (a scalar lane read, no LDS round trip) and counted against
 #pragma unroll
     for (uint32_t c = 0; c < 5u; ++c) {
-        uint64_t nz = __ballot(fi[c] != 0u);
+        uint64_t nz = __ballot(key[c] != 0u);
         while (nz) {
             const uint32_t jj = (uint32_t)__ffsll((unsigned long long)nz) - 1u;
             nz &= nz - 1ull;
-            const uint32_t fj = zmi_readlane(fi[c], jj);
-            const uint32_t j = c * 64u + jj;
+            const uint32_t kj = zmi_readlane(key[c], jj);
 #pragma unroll
-            for (uint32_t k = 0; k < 5u; ++k) {
-                uint32_t i = lane + 64u * k;
-                rk[k] += (fj < fi[k]) || (fj == fi[k] && j < i);
-            }
+            for (uint32_t k = 0; k < 5u; ++k) rk[k] += kj < key[k] ? 1u : 0u;
         }
     }
 #pragma unroll
-    for (uint32_t k = 0; k < 5u; ++k) {
-        uint32_t i = lane + 64u * k;
-        if (i < nsym && fi[k] != 0u) S->order[rk[k]] = (uint16_t)i;
-    }
+    for (uint32_t k = 0; k < 5u; ++k)
+        if (key[k] != 0u) S->order[rk[k]] = (uint16_t)(key[k] & 0x1FFu);
     uint32_t nnz = zmi_wave_sum(mine);
     if (lane == 0) S->misc[M_NNZ] = nnz;
     zmi_wave_sync();
@@ -249,7 +245,8 @@ static __device__ void enc_huff_lengths_w(EncShared* S, const uint32_t* freq, ui
     }
     {
         uint32_t li = 0, ii = 0;
-        uint32_t lw = enc_rd5(swr, 0);      // head of the leaf queue (all ones: exhausted)
+        uint32_t cur = swr[0];              // the register holding the leaf queue's current 64 entries
+        uint32_t lw = zmi_readlane(cur, 0); // head of the leaf queue (all ones: exhausted)
         uint32_t nw = 0xFFFFFFFFu;          // head of the node queue (all ones: nothing made yet)
         for (uint32_t ni = 0; ni + 1u < nnz; ++ni) {
             uint32_t w = 0;
@@ -259,7 +256,8 @@ static __device__ void enc_huff_lengths_w(EncShared* S, const uint32_t* freq, ui
                     w += lw;
                     if (lane == 0) S->lpar[li] = (uint16_t)ni;
                     ++li;
-                    lw = li < nnz ? enc_rd5(swr, li) : 0xFFFFFFFFu;
+                    if ((li & 63u) == 0u) cur = li == 64u ? swr[1] : (li == 128u ? swr[2] : (li == 192u ? swr[3] : swr[4]));
+                    lw = zmi_readlane(cur, li & 63u);   // entries past nnz hold all ones
                 } else {
                     w += nw;
                     if (lane == 0) S->ipar[ii] = (uint16_t)ni;
