@@ -110,6 +110,18 @@ int zmi_inflate_batch_dict_dev(zmi_ctx* ctx, const void* d_in, const uint64_t* d
                                uint32_t n_streams, int wrap, void* d_out, const uint64_t* d_out_off,
                                const uint32_t* d_out_cap, const uint32_t* d_out_hist, uint32_t* d_out_len,
                                int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail, void* stream);
+/* Resumable decode of raw deflate streams -- the device half of a streaming inflate() that is fed partial input
+ * (the reference keeps Mode / BitReader / Window for this, zlib-rs/src/inflate.rs:288-320; here the state is a
+ * block-boundary checkpoint).  Stream i starts at bit d_in_bit[i] (0..7, array may be NULL) of its first byte, with
+ * d_out_hist[i] bytes of earlier output directly in front of its output region.  d_resume[4i..4i+3] receives
+ * {byte, bit, output bytes, complete}: the start of the block the decode stopped in (status Z_BUF_ERROR, d_detail
+ * 1 = more input / 2 = more room needed), or the first bit behind the final block (complete = 1, status Z_OK).
+ * d_out_len[i] counts everything decoded including the valid part of the unfinished block; a later call that
+ * starts at the checkpoint, with the output in front of it as history, reproduces those bytes and continues. */
+int zmi_inflate_resume_dev(zmi_ctx* ctx, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                           const uint32_t* d_in_bit, uint32_t n_streams, void* d_out, const uint64_t* d_out_off,
+                           const uint32_t* d_out_cap, const uint32_t* d_out_hist, uint32_t* d_out_len,
+                           int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail, uint32_t* d_resume, void* stream);
 
 /* Adler-32 (kind bit 0) and/or CRC-32 (kind bit 1) of every shard (zlib-rs/src/adler32.rs:19, crc32.rs:19) */
 int zmi_checksum_batch_dev(zmi_ctx* ctx, const void* d_data, const uint64_t* d_off, const uint32_t* d_len,
@@ -126,6 +138,12 @@ int zmi_deflate_batch(zmi_ctx* ctx, const uint8_t* in, const uint64_t* in_off, c
 int zmi_inflate_batch(zmi_ctx* ctx, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n_streams,
                       int wrap, uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len,
                       int32_t* status);
+/* One host stream through zmi_inflate_resume_dev (staging buffers are kept in the context): `in` starts at bit in_bit of
+ * its first byte, `hist` is the up to 32 KiB of output in front of it, resume[4] as above; out receives
+ * min(*out_len, out_cap) bytes.  This is what the stream ABI's inflate() / inflateBack() run on. */
+int zmi_inflate_resume(zmi_ctx* ctx, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist,
+                       uint32_t hist_len, uint8_t* out, uint32_t out_cap, uint32_t* out_len, int32_t* status,
+                       int32_t* detail, uint32_t* in_used, uint32_t* resume);
 
 #ifdef __cplusplus
 }

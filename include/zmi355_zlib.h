@@ -13,20 +13,28 @@
  *              finishes (or 64 MiB are pending).  The input is compressed in 1 MiB segments, one
  *              workgroup each, that start byte aligned (the empty stored block of Z_SYNC_FLUSH,
  *              zlib-rs/src/deflate.rs:2733-2738) and keep the window: a segment matches into the
- *              28 KiB in front of it, like a preset dictionary (deflate.rs:499-564).  Across
- *              separate flushes by the caller the history starts empty (Z_FULL_FLUSH semantics,
- *              deflate.rs:2739-2752).
- *   inflate()  buffers input and decodes what it has whenever the input grew by a quarter (or the
- *              caller finishes): the bytes decoded so far are final and handed out at once, so output
- *              arrives while input is still being fed (each attempt decodes from the start of the
- *              stream on the GPU; geometric growth keeps the total work linear).  The bytes in front
- *              of a corrupt spot are delivered before Z_DATA_ERROR, as the reference does.
+ *              28 KiB in front of it, like a preset dictionary (deflate.rs:499-564).  Across separate
+ *              deflate() calls the last 32 KiB of input stay the window; only Z_FULL_FLUSH forgets them
+ *              (deflate.rs:2739-2752).
+ *   inflate()  takes all of avail_in on every call and decodes as far as that input allows, so the output of
+ *              a flushed packet is there when the call returns.  The device decodes from a checkpoint -- the
+ *              last block boundary it reached -- with the 32 KiB of output in front of it as history
+ *              (zmi_inflate_resume, include/zmi355.h; the reference's Mode / BitReader / Window,
+ *              zlib-rs/src/inflate.rs:288-320): a block is decoded again only while it is incomplete, memory
+ *              is bounded by the block size.  Wrapper header / trailer are parsed on the host.  Z_BLOCK and
+ *              Z_TREES do not stop at block ends (they behave like Z_NO_FLUSH).  The bytes in front of a corrupt
+ *              spot are delivered before Z_DATA_ERROR, as the reference does; header and trailer errors carry the
+ *              reference's messages, errors inside the deflate data a generic one.
  * Preset dictionaries (deflateSetDictionary / inflateSetDictionary, incl. Z_NEED_DICT and the DICTID check) are
  * supported: the dictionary is the window in front of the first segment.
  * gzip header fields (deflateSetHeader / inflateGetHeader), deflateCopy / inflateCopy, *ResetKeep and *GetDictionary
  * work on the host-side stream state.
- * Not implemented (Z_STREAM_ERROR): deflatePrime/inflatePrime, inflateSync; not exported: inflateBack*, inflateMark,
- * inflateCodesUsed, inflateValidate, inflateUndermine, gz* file API ("next").
+ * deflatePrime: the bits go out in front of the next compressed data; since every segment of this engine starts on a
+ * byte boundary, a bit count that is not a multiple of 8 is followed by an empty stored block (3 bits + padding +
+ * 00 00 FF FF), which keeps the stream valid.  inflatePrime is accepted while no undecoded input is buffered (right
+ * after init / reset or at a block boundary: the documented uses).  inflateSync, inflateSyncPoint, inflateMark,
+ * inflateValidate, inflateUndermine, inflateBack* follow the reference; inflateCodesUsed reports 0 (the decode tables
+ * live on the device).  Not exported: the gz* file API ("next").
  */
 #ifndef ZMI355_ZLIB_H
 #define ZMI355_ZLIB_H
@@ -142,7 +150,8 @@ int deflateGetDictionary(z_streamp strm, Bytef* dictionary, uInt* dictLength);  
 int deflateSetHeader(z_streamp strm, gz_headerp head);                                   /* lib.rs:1319 */
 int deflateCopy(z_streamp dest, z_streamp source);                                       /* lib.rs:1837 */
 int deflateResetKeep(z_streamp strm);                                                    /* lib.rs:1627 */
-int deflatePrime(z_streamp strm, int bits, int value);                                   /* lib.rs:1725, unsupported */
+int deflatePrime(z_streamp strm, int bits, int value);                                   /* lib.rs:1725 */
+int deflateUsed(z_streamp strm, int* bits);                                              /* lib.rs:1800 */
 
 int inflateInit_(z_streamp strm, const char* version, int stream_size);                  /* lib.rs:935 */
 int inflateInit2_(z_streamp strm, int windowBits, const char* version, int stream_size); /* lib.rs:967 */
@@ -155,7 +164,19 @@ int inflateGetDictionary(z_streamp strm, Bytef* dictionary, uInt* dictLength);  
 int inflateGetHeader(z_streamp strm, gz_headerp head);                                   /* lib.rs:1179 */
 int inflateCopy(z_streamp dest, z_streamp source);                                       /* lib.rs:815 */
 int inflateResetKeep(z_streamp strm);                                                    /* lib.rs:1233 */
-int inflateSync(z_streamp strm);                                                         /* lib.rs:884, unsupported */
+int inflateSync(z_streamp strm);                                                         /* lib.rs:884 */
+int inflateSyncPoint(z_streamp strm);                                                    /* lib.rs:901 */
+int inflatePrime(z_streamp strm, int bits, int value);                                   /* lib.rs:1029 */
+long inflateMark(z_streamp strm);                                                        /* lib.rs:850 */
+int inflateValidate(z_streamp strm, int check);                                          /* lib.rs:1216 */
+int inflateUndermine(z_streamp strm, int subvert);                                       /* lib.rs:1199 */
+unsigned long inflateCodesUsed(z_streamp strm);                                          /* lib.rs:1252 */
+/* raw deflate through callbacks (zlib-rs/src/inflate/infback.rs) */
+typedef unsigned (*in_func)(void* desc, unsigned char** buf);                            /* zlib-rs/src/c_api.rs:12 */
+typedef int (*out_func)(void* desc, unsigned char* buf, unsigned len);                   /* zlib-rs/src/c_api.rs:13 */
+int inflateBackInit_(z_streamp strm, int windowBits, unsigned char* window, const char* version, int stream_size); /* lib.rs:697 */
+int inflateBack(z_streamp strm, in_func in, void* in_desc, out_func out, void* out_desc); /* lib.rs:741 */
+int inflateBackEnd(z_streamp strm);                                                      /* lib.rs:780 */
 
 int compress(Bytef* dest, uLongf* destLen, const Bytef* source, uLong sourceLen);        /* lib.rs:1447 */
 int compress2(Bytef* dest, uLongf* destLen, const Bytef* source, uLong sourceLen, int level); /* lib.rs:1529 */

@@ -63,3 +63,12 @@ def test_inflate_hands_out_output_progressively():
     zmi_ctypes.load_emu()
     lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
     H.progressive_inflate_checks(lib, oracle_lib.load().gen_shard(0, 60000))
+
+
+def test_streaming_entry_points():
+    """packet-wise and byte-wise inflate on the resumable device decode, inflateSync / Prime / Mark / Validate /
+    SyncPoint, inflateBack, deflatePrime / deflateUsed"""
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    o = oracle_lib.load()
+    H.streaming_checks(lib, o.gen_shard(0, 40000) + o.gen_shard(3, 30000), syslib=C.CDLL("libz.so.1"))

@@ -162,3 +162,14 @@ def test_adaptive_block_splitting(eng, o, monkeypatch):
     outs, st = eng.deflate([noise, noise[:777]], level=6, wrap=1)
     assert st == [0, 0] and zlib.decompress(outs[0]) == noise and zlib.decompress(outs[1]) == noise[:777]
     assert len(outs[0]) <= len(noise) + len(noise) // 8 + 64
+
+
+def test_resumable_inflate_from_block_checkpoints():
+    """zmi_inflate_resume (include/zmi355.h): cut streams, restart at the reported block boundary with the output in
+    front of it as history -- the device half of the streaming inflate (zlib-rs/src/inflate.rs:288-320)"""
+    import resume_checks
+    eng = zmi_ctypes.Engine(zmi_ctypes.load_emu())
+    try:
+        resume_checks.resume_chain_checks(eng, oracle_lib.load(), sizes=(60000, 40000, 20000, 20000), trials=2)
+    finally:
+        eng.close()

@@ -58,3 +58,27 @@ def test_c_program_links_and_roundtrips(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "abi_smoke ok" in r.stdout
+
+
+def test_streaming_entry_points_on_gpu():
+    """packet-wise and piece-wise inflate on the resumable device decode, inflateSync / Prime / Mark / Validate /
+    SyncPoint, inflateBack, deflatePrime / deflateUsed; the system's zlib reads the primed stream too"""
+    from zlib_rs_amd import _build
+    lib = H.bind(C.CDLL(_build.ABI_LIB))
+    o = oracle_lib.load(rebuild=False)
+    H.streaming_checks(lib, o.gen_shard(0, 400000) + o.gen_shard(3, 300000), syslib=C.CDLL("libz.so.1"))
+
+
+def test_streaming_inflate_large_in_small_chunks_on_gpu():
+    """24 MiB through inflate() in 64 KiB pieces with a 256 KiB output buffer (the zpipe.c loop): bit-exact, and the
+    host state stays small -- the decode restarts at block checkpoints instead of buffering the stream"""
+    import zlib
+    from zlib_rs_amd import _build
+    lib = H.bind(C.CDLL(_build.ABI_LIB))
+    o = oracle_lib.load(rebuild=False)
+    data = b"".join(o.gen_shard(i, 1 << 20) for i in range(24))
+    for wbits in (15, 31):
+        co = zlib.compressobj(6, zlib.DEFLATED, wbits)
+        comp = co.compress(data) + co.flush()
+        rc, out, unused = H.inflate_stream(lib, comp + b"tail", wbits=wbits, chunk_in=1 << 16, chunk_out=1 << 18)
+        assert rc == H.Z_STREAM_END and out == data and unused == 4

@@ -268,3 +268,14 @@ def test_checksums(engine):
     for i, b in enumerate(blobs):
         assert int(a[i]) == zlib.adler32(b), i
         assert int(c[i]) == zlib.crc32(b), i
+
+
+def test_resumable_inflate_from_block_checkpoints():
+    """zmi_inflate_resume through the C ABI on the MI355X: cut streams restart at the reported block boundary"""
+    import resume_checks
+    import zmi_ctypes
+    eng = zmi_ctypes.Engine(zmi_ctypes.load_product())
+    try:
+        resume_checks.resume_chain_checks(eng, oracle_lib.load(rebuild=False), trials=6)
+    finally:
+        eng.close()

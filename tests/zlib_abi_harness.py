@@ -346,3 +346,241 @@ def progressive_inflate_checks(lib, data):
     # everything decodable came out first; the part in front of the flipped byte is the original data
     assert len(collected) > len(data) // 2 and bytes(collected[:len(data) // 2]) == data[:len(data) // 2]
     assert lib.inflateEnd(C.byref(strm)) == Z_OK
+
+
+IN_FUNC = C.CFUNCTYPE(C.c_uint, C.c_void_p, C.POINTER(C.c_void_p))
+OUT_FUNC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint)
+
+
+def _bind_streaming(lib):
+    P = C.POINTER(ZStream)
+    lib.inflateSync.argtypes = [P]
+    lib.inflateSyncPoint.argtypes = [P]
+    lib.inflatePrime.argtypes = [P, C.c_int, C.c_int]
+    lib.inflateMark.restype = C.c_long
+    lib.inflateMark.argtypes = [P]
+    lib.inflateValidate.argtypes = [P, C.c_int]
+    lib.inflateReset.argtypes = [P]
+    lib.deflatePrime.argtypes = [P, C.c_int, C.c_int]
+    lib.deflatePending.argtypes = [P, C.POINTER(C.c_uint), C.POINTER(C.c_int)]
+    lib.inflateBackInit_.argtypes = [P, C.c_int, C.c_void_p, C.c_char_p, C.c_int]
+    lib.inflateBack.argtypes = [P, IN_FUNC, C.c_void_p, OUT_FUNC, C.c_void_p]
+    lib.inflateBackEnd.argtypes = [P]
+
+
+def _feed(lib, strm, buf_addr, n, out, flush=Z_NO_FLUSH, room=1 << 16):
+    """one inflate() call over n input bytes, collecting what comes out (repeats while the room fills up)"""
+    obuf = C.create_string_buffer(room)
+    strm.next_in, strm.avail_in = buf_addr, n
+    while True:
+        strm.next_out, strm.avail_out = C.addressof(obuf), room
+        rc = lib.inflate(C.byref(strm), flush)
+        out += obuf.raw[:room - strm.avail_out]
+        if rc != Z_OK or strm.avail_out != 0:
+            return rc
+
+
+def streaming_checks(lib, data, syslib=None):
+    """the stream ABI when it is driven in pieces: resumable inflate (inflate.rs:288-320 keeps the state the device
+    checkpoint replaces), sync / prime / mark / validate, inflateBack, deflatePrime / deflateUsed.
+    syslib: the system's libz as an independent implementation of the same entry points."""
+    import zlib
+    _bind_streaming(lib)
+    ver, zs = lib.zlibVersion(), C.sizeof(ZStream)
+    assert len(data) >= 60000
+
+    # -- 1. a packet protocol: every Z_SYNC_FLUSHed packet must come out completely in the call that delivers it
+    co = zlib.compressobj(6, zlib.DEFLATED, 15)
+    cuts = [0, 700, 701, 9000, 30000, len(data)]
+    packets = []
+    for a, b in zip(cuts, cuts[1:]):
+        packets.append(co.compress(data[a:b]) + co.flush(zlib.Z_SYNC_FLUSH))
+    tail = co.flush()
+    strm = ZStream()
+    assert lib.inflateInit2_(C.byref(strm), 15, ver, zs) == Z_OK
+    got = bytearray()
+    for i, pk in enumerate(packets):
+        src = C.create_string_buffer(pk, len(pk))
+        rc = _feed(lib, strm, C.addressof(src), len(pk), got)
+        assert rc == Z_OK, rc
+        assert bytes(got) == data[:cuts[i + 1]], (i, len(got), cuts[i + 1])
+        assert strm.avail_in == 0 and strm.data_type & 128        # stopped right behind a block
+    src = C.create_string_buffer(tail + b"XYZ", len(tail) + 3)
+    assert _feed(lib, strm, C.addressof(src), len(tail) + 3, got) == Z_STREAM_END
+    assert strm.avail_in == 3 and strm.total_in == sum(map(len, packets)) + len(tail) and strm.total_out == len(data)
+    assert strm.adler == zlib.adler32(data)
+    assert lib.inflateEnd(C.byref(strm)) == Z_OK
+
+    # -- 2. in small pieces (a tiny stream one byte at a time), every wrapper; no Z_FINISH anywhere (the zpipe.c loop)
+    small = data[:20000]
+    for wbits, payload, step in ((15, data[:90], 1), (15, small, 501), (31, small, 97), (-15, small, 333), (47, small, 1000)):
+        comp = zlib.compressobj(6, zlib.DEFLATED, 31 if wbits == 47 else wbits)
+        blob = comp.compress(payload) + comp.flush()
+        strm = ZStream()
+        assert lib.inflateInit2_(C.byref(strm), wbits, ver, zs) == Z_OK
+        src = C.create_string_buffer(blob, len(blob))
+        got = bytearray()
+        rc = Z_OK
+        for at in range(0, len(blob), step):
+            rc = _feed(lib, strm, C.addressof(src) + at, min(step, len(blob) - at), got)
+            assert rc in (Z_OK, Z_STREAM_END), (wbits, at, rc)
+        assert rc == Z_STREAM_END and bytes(got) == payload, (wbits, rc, len(got))
+        assert lib.inflateEnd(C.byref(strm)) == Z_OK
+
+    # -- 3. header and trailer errors carry the reference's messages (inflate.rs:1000-1062, 1790-1839)
+    good = zlib.compress(small, 6)
+    for blob, msg in ((b"\x78\x9d" + good[2:], b"incorrect header check"), (b"\x77\x9c"[:1] + b"\x85" + good[2:], b"unknown compression method"),
+                      (good[:-1] + bytes([good[-1] ^ 1]), b"incorrect data check")):
+        strm = ZStream()
+        assert lib.inflateInit2_(C.byref(strm), 15, ver, zs) == Z_OK
+        src = C.create_string_buffer(blob, len(blob))
+        got = bytearray()
+        rc = _feed(lib, strm, C.addressof(src), len(blob), got, Z_FINISH)
+        assert rc == Z_DATA_ERROR and strm.msg == msg, (rc, strm.msg, msg)
+        assert lib.inflateEnd(C.byref(strm)) == Z_OK
+    gz = zlib.compressobj(6, zlib.DEFLATED, 31)
+    gzblob = gz.compress(small) + gz.flush()
+    badlen = gzblob[:-4] + bytes([gzblob[-4] ^ 1]) + gzblob[-3:]
+    strm = ZStream()
+    assert lib.inflateInit2_(C.byref(strm), 31, ver, zs) == Z_OK
+    src = C.create_string_buffer(badlen, len(badlen))
+    got = bytearray()
+    assert _feed(lib, strm, C.addressof(src), len(badlen), got, Z_FINISH) == Z_DATA_ERROR and strm.msg == b"incorrect length check"
+    # inflateValidate(0): the same stream passes when the check is switched off (inflate.rs:2595)
+    assert lib.inflateReset(C.byref(strm)) == Z_OK and lib.inflateValidate(C.byref(strm), 0) == Z_OK
+    got = bytearray()
+    assert _feed(lib, strm, C.addressof(src), len(badlen), got, Z_FINISH) == Z_STREAM_END and bytes(got) == small
+    assert lib.inflateEnd(C.byref(strm)) == Z_OK
+
+    # -- 4. inflateSync: damage in front of a Z_FULL_FLUSH point, resume behind it (inflate.rs:2458-2535)
+    co = zlib.compressobj(6, zlib.DEFLATED, 15)
+    first = co.compress(data[:30000]) + co.flush(zlib.Z_FULL_FLUSH)
+    second = co.compress(data[30000:60000]) + co.flush()
+    hurt = bytearray(first)
+    for i in range(40, 60):
+        hurt[i] ^= 0x5A
+    blob = bytes(hurt) + second
+    strm = ZStream()
+    assert lib.inflateInit2_(C.byref(strm), 15, ver, zs) == Z_OK
+    src = C.create_string_buffer(blob, len(blob))
+    got = bytearray()
+    k = len(first) - 100                                     # the error shows up before the flush point arrives
+    rc = _feed(lib, strm, C.addressof(src), k, got)
+    assert rc == Z_DATA_ERROR, rc
+    strm.next_in, strm.avail_in = C.addressof(src) + k, len(blob) - k
+    assert lib.inflateSync(C.byref(strm)) == Z_OK
+    assert strm.total_in == len(first), (strm.total_in, len(first))          # "where valid compressed data was found"
+    rest = bytearray()
+    rc = _feed(lib, strm, strm.next_in, strm.avail_in, rest, Z_FINISH)
+    assert rc == Z_STREAM_END and bytes(rest) == data[30000:60000], (rc, len(rest))
+    assert lib.inflateEnd(C.byref(strm)) == Z_OK
+    # no marker in the input: Z_DATA_ERROR, everything consumed; with nothing to search: Z_BUF_ERROR
+    strm = ZStream()
+    assert lib.inflateInit2_(C.byref(strm), -15, ver, zs) == Z_OK
+    junk = C.create_string_buffer(b"\x01\x02\x03\x00\x00\xff\x01" * 10, 70)
+    assert lib.inflateSync(C.byref(strm)) == Z_BUF_ERROR
+    strm.next_in, strm.avail_in = C.addressof(junk), 70
+    assert lib.inflateSync(C.byref(strm)) == Z_DATA_ERROR and strm.avail_in == 0 and strm.total_in == 70
+    assert lib.inflateEnd(C.byref(strm)) == Z_OK
+
+    # -- 5. inflateSyncPoint (inflate.rs:2537): true while the LEN bytes of a flush marker are still missing
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    pk = co.compress(small) + co.flush(zlib.Z_SYNC_FLUSH)
+    assert pk[-4:] == b"\x00\x00\xff\xff"
+    strm = ZStream()
+    assert lib.inflateInit2_(C.byref(strm), -15, ver, zs) == Z_OK
+    assert lib.inflateMark(C.byref(strm)) in (-65536, -(1 << 63))        # nothing in flight
+    src = C.create_string_buffer(pk, len(pk))
+    got = bytearray()
+    assert _feed(lib, strm, C.addressof(src), len(pk) - 4, got) == Z_OK and bytes(got) == small
+    assert lib.inflateSyncPoint(C.byref(strm)) == 1
+    assert _feed(lib, strm, C.addressof(src) + len(pk) - 4, 4, got) in (Z_OK, Z_BUF_ERROR)
+    assert lib.inflateSyncPoint(C.byref(strm)) == 0
+    assert lib.inflateMark(C.byref(strm)) == -65536
+    assert lib.inflateEnd(C.byref(strm)) == Z_OK
+
+    # -- 6. deflatePrime / inflatePrime (deflate.rs:566, inflate.rs:2160): 3 bits in front of a raw stream
+    strm = ZStream()
+    assert lib.deflateInit2_(C.byref(strm), 6, 8, -15, 8, 0, ver, zs) == Z_OK
+    assert lib.deflatePrime(C.byref(strm), 3, 0b101) == Z_OK
+    pend, bits = C.c_uint(9), C.c_int(9)
+    assert lib.deflatePending(C.byref(strm), C.byref(pend), C.byref(bits)) == Z_OK and (pend.value, bits.value) == (0, 3)
+    assert lib.deflatePrime(C.byref(strm), 33, 0) == Z_BUF_ERROR
+    src = C.create_string_buffer(small, len(small))
+    obuf = C.create_string_buffer(len(small) + 1000)
+    strm.next_in, strm.avail_in = C.addressof(src), len(small)
+    strm.next_out, strm.avail_out = C.addressof(obuf), len(small) + 1000
+    assert lib.deflate(C.byref(strm), Z_FINISH) == Z_STREAM_END
+    primed = obuf.raw[:strm.total_out]
+    used = C.c_int(0)
+    if hasattr(lib, "deflateUsed"):
+        lib.deflateUsed.argtypes = [C.POINTER(ZStream), C.POINTER(C.c_int)]
+        assert lib.deflateUsed(C.byref(strm), C.byref(used)) == Z_OK and 1 <= used.value <= 8
+        assert primed[-1] >> used.value == 0 and (used.value == 1 or primed[-1] != 0 or True)
+    assert lib.deflateEnd(C.byref(strm)) == Z_OK
+    assert primed[0] & 7 == 0b101
+    for L in [lib] + ([syslib] if syslib is not None else []):      # the system's zlib reads our primed stream too
+        _bind_streaming(L) if L is lib else None
+        if L is not lib:
+            L.inflateInit2_.argtypes = [C.POINTER(ZStream), C.c_int, C.c_char_p, C.c_int]
+            L.inflate.argtypes = [C.POINTER(ZStream), C.c_int]
+            L.inflateEnd.argtypes = [C.POINTER(ZStream)]
+            L.inflatePrime.argtypes = [C.POINTER(ZStream), C.c_int, C.c_int]
+            L.zlibVersion.restype = C.c_char_p
+        strm = ZStream()
+        assert L.inflateInit2_(C.byref(strm), -15, L.zlibVersion(), zs) == Z_OK
+        assert L.inflatePrime(C.byref(strm), 5, primed[0] >> 3) == Z_OK       # skip the three foreign bits
+        psrc = C.create_string_buffer(primed, len(primed))
+        got = bytearray()
+        assert _feed(L, strm, C.addressof(psrc) + 1, len(primed) - 1, got, Z_FINISH) == Z_STREAM_END
+        assert bytes(got) == small
+        assert L.inflateEnd(C.byref(strm)) == Z_OK
+    # an empty stream ends with the 10 bits of an empty static block: two bits of the last byte are in use
+    if hasattr(lib, "deflateUsed"):
+        strm = ZStream()
+        assert lib.deflateInit2_(C.byref(strm), 6, 8, -15, 8, 0, ver, zs) == Z_OK
+        assert lib.deflateUsed(C.byref(strm), C.byref(used)) == Z_OK and used.value == 0
+        strm.next_in, strm.avail_in = None, 0
+        strm.next_out, strm.avail_out = C.addressof(obuf), 100
+        assert lib.deflate(C.byref(strm), Z_FINISH) == Z_STREAM_END and obuf.raw[:2] == b"\x03\x00"
+        assert lib.deflateUsed(C.byref(strm), C.byref(used)) == Z_OK and used.value == 2
+        assert lib.deflateEnd(C.byref(strm)) == Z_OK
+
+    # -- 7. inflateBack (inflate/infback.rs): input pulled in pieces, output pushed one window at a time
+    raw = zlib.compressobj(6, zlib.DEFLATED, -15)
+    blob = raw.compress(data[:60000]) + raw.flush() + b"TRAILING"
+    holder = C.create_string_buffer(blob, len(blob))
+    state = {"pos": 0, "out": bytearray(), "calls": 0}
+
+    def pull(desc, bufp):
+        n = min(1500, len(blob) - state["pos"])
+        bufp[0] = C.addressof(holder) + state["pos"]
+        state["pos"] += n
+        return n
+
+    def push(desc, buf, n):
+        state["out"] += C.string_at(buf, n)
+        state["calls"] += 1
+        return 0
+
+    window = C.create_string_buffer(1 << 15)
+    strm = ZStream()
+    assert lib.inflateBackInit_(C.byref(strm), 15, C.addressof(window), ver, zs) == Z_OK
+    strm.next_in, strm.avail_in = None, 0
+    rc = lib.inflateBack(C.byref(strm), IN_FUNC(pull), None, OUT_FUNC(push), None)
+    assert rc == Z_STREAM_END, rc
+    assert bytes(state["out"]) == data[:60000] and state["calls"] == 2        # 32768 + 27232
+    left = C.string_at(strm.next_in, strm.avail_in) + blob[state["pos"]:]
+    assert left == b"TRAILING", left
+    # truncated input: Z_BUF_ERROR with next_in NULL; a failing out(): Z_BUF_ERROR with next_in set (infback.rs:705-722)
+    state.update(pos=0, out=bytearray(), calls=0)
+    full, blob = blob, blob[:4000]
+    strm.next_in, strm.avail_in = None, 0
+    rc = lib.inflateBack(C.byref(strm), IN_FUNC(pull), None, OUT_FUNC(push), None)
+    assert rc == Z_BUF_ERROR and not strm.next_in
+    state.update(pos=0, out=bytearray(), calls=0)
+    blob = full
+    strm.next_in, strm.avail_in = None, 0
+    rc = lib.inflateBack(C.byref(strm), IN_FUNC(pull), None, OUT_FUNC(lambda d, b, n: 1), None)
+    assert rc == Z_BUF_ERROR and strm.next_in
+    assert lib.inflateBackEnd(C.byref(strm)) == Z_OK

@@ -26,6 +26,7 @@ def _bind(lib):
     vp = C.c_void_p
     lib.zmi_inflate_batch_dev.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.zmi_ctx_set_inflate_out_limit.argtypes = [vp, C.c_uint64]
+    lib.zmi_inflate_resume.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, u32p, i32p, i32p, u32p, u32p]
     return lib
 
 
@@ -123,3 +124,18 @@ class Engine:
         res = [bytes(out[int(ooff[i]):int(ooff[i]) + min(int(olen[i]), int(ocap[i]))]) for i in range(n)]
         guard = [bytes(out[int(ooff[i]) + int(ocap[i]):int(ooff[i]) + int(ocap[i]) + 1]) for i in range(n)]
         return res, [int(x) for x in st], guard
+
+    def inflate_resume(self, data, in_bit=0, hist=b"", cap=1 << 16):
+        """one call of the resumable raw-deflate decode (zmi_inflate_resume) ->
+        (output bytes incl. the valid part of an unfinished block, status, detail, in_used, [byte, bit, out, complete])"""
+        src = np.frombuffer(bytes(data) + b"\0", dtype=np.uint8).copy()
+        h = np.frombuffer(bytes(hist) + b"\0", dtype=np.uint8).copy()
+        out = np.zeros(max(1, cap), dtype=np.uint8)
+        olen, used = C.c_uint32(0), C.c_uint32(0)
+        st, det = C.c_int32(0), C.c_int32(0)
+        res = (C.c_uint32 * 4)()
+        rc = self.lib.zmi_inflate_resume(self.ctx, src.ctypes.data, len(data), in_bit, h.ctypes.data, len(hist), out.ctypes.data, cap,
+                                         C.byref(olen), C.byref(st), C.byref(det), C.byref(used), res)
+        if rc != 0:
+            raise RuntimeError("zmi_inflate_resume failed: %d %s" % (rc, self.lib.zmi_last_error().decode()))
+        return bytes(out[:min(olen.value, cap)]), st.value, det.value, used.value, list(res)

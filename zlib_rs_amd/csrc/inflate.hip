@@ -64,6 +64,7 @@ struct InfShared {
     uint32_t fcode[16];   // first canonical code of every length
     uint32_t misc[8];
     __attribute__((aligned(16))) uint8_t inbuf[INF_CHUNK + 32];  // staged compressed input (one coalesced load per KiB)
+    uint32_t rs[4];       // resumable decode: where the block being decoded starts (byte, bit, output position, complete)
 };
 
 struct InfBits {
@@ -363,6 +364,12 @@ static __device__ __forceinline__ void inf_emit(uint8_t* dst, uint32_t* bm32, bo
 }
 
 // wrap: 0 raw, 1 zlib, 2 gzip, 3 auto (zlib or gzip by magic)
+// RESUME (raw streams only; the streaming ABI's resumable inflate, zlib-rs/src/inflate.rs:288-320 keeps the same
+// facts in its Mode / BitReader / Window): stream s starts at bit in_bit[s] (0..7) of its first byte, and
+// resume[4s..4s+3] receives {byte, bit, output position, complete} of the start of the block the decode stopped
+// in -- or of the end of the final block.  Decoding the same input again from there, with the output in front of
+// that point as history, continues the stream.  A separate instantiation: the batch kernel's registers are full.
+template <bool RESUME>
 __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                          const uint32_t* __restrict__ in_len, uint32_t wrap,
                                                          uint8_t* out, const uint64_t* __restrict__ out_off,
@@ -370,7 +377,8 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                                                          uint32_t* __restrict__ out_len, uint32_t* __restrict__ in_used,
                                                          uint32_t* __restrict__ check, int32_t* __restrict__ status,
                                                          uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ bm_off,
-                                                         const uint32_t* __restrict__ out_hist) {
+                                                         const uint32_t* __restrict__ out_hist,
+                                                         const uint32_t* __restrict__ in_bit, uint32_t* __restrict__ resume) {
     __shared__ InfShared Sh;
     InfShared* S = &Sh;
     const uint32_t lane = zmi_lane();
@@ -393,7 +401,10 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
     const uint64_t bmo = bm_off[s];
     uint32_t* bm32 = (uint32_t*)(bitmap + (bmo == ~0ull ? 0ull : bmo));   // bit p set: a back-reference starts at output byte p
     if (bmo == ~0ull) {
-        if (lane == 0) { out_len[s] = 0; in_used[s] = 0; check[s] = 0; status[s] = ZMI_NO_SCRATCH; }
+        if (lane == 0) {
+            out_len[s] = 0; in_used[s] = 0; check[s] = 0; status[s] = ZMI_NO_SCRATCH;
+            if (RESUME) { resume[4u * s] = 0; resume[4u * s + 1u] = in_bit ? (in_bit[s] & 7u) : 0u; resume[4u * s + 2u] = 0; resume[4u * s + 3u] = 0; }
+        }
         return;
     }
     uint32_t kind_found = wrap;  // resolved wrapper: 0 raw, 1 zlib, 2 gzip
@@ -437,10 +448,24 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
         }
     }
 
+    if (RESUME) {
+        const uint32_t sb = in_bit ? (in_bit[s] & 7u) : 0u;
+        if (lane == 0) { S->rs[0] = 0; S->rs[1] = sb; S->rs[2] = 0; S->rs[3] = 0; }
+        if (sb) {
+            inf_refill(B);
+            if (B.nbits < sb) st = ZMI_BUF_ERROR;
+            else inf_drop(B, sb);
+        }
+    }
+
     // ---- blocks ----
     uint32_t last = 0;
     while (st == ZMI_OK && !last) {
         inf_refill(B);
+        if (RESUME && lane == 0) {
+            const uint64_t at = 8ull * B.ipos - B.nbits;
+            S->rs[0] = (uint32_t)(at >> 3); S->rs[1] = (uint32_t)at & 7u; S->rs[2] = opos;
+        }
         if (B.nbits < 3u) { st = ZMI_BUF_ERROR; break; }
         last = inf_peek(B, 1);
         uint32_t type = (inf_peek(B, 3) >> 1);
@@ -688,6 +713,10 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
     // ---- trailer ----
     uint32_t chk = 0;
     if (st == ZMI_OK) {
+        if (RESUME && lane == 0) {   // complete: the position is that of the first bit behind the final block
+            const uint64_t at = 8ull * B.ipos - B.nbits;
+            S->rs[0] = (uint32_t)(at >> 3); S->rs[1] = (uint32_t)at & 7u; S->rs[2] = opos; S->rs[3] = 1u;
+        }
         // give back whole unread bytes
         B.ipos -= B.nbits >> 3;
         if (kind_found == 1u) {
@@ -720,6 +749,9 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
         in_used[s] = B.ipos;
         check[s] = chk;
         status[s] = st;
+        if (RESUME) {
+            resume[4u * s] = S->rs[0]; resume[4u * s + 1u] = S->rs[1]; resume[4u * s + 2u] = S->rs[2]; resume[4u * s + 3u] = S->rs[3];
+        }
     }
 }
 
@@ -1032,12 +1064,17 @@ extern "C" int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off,
                                   uint32_t wrap, uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                                   uint32_t* d_out_len, uint32_t* d_in_used, uint32_t* d_check, int32_t* d_status,
                                   uint64_t* d_bitmap, uint64_t bitmap_words, uint64_t* d_bm_off, const uint32_t* d_out_hist,
-                                  hipStream_t stream) {
+                                  const uint32_t* d_in_bit, uint32_t* d_resume, hipStream_t stream) {
     if (n_streams == 0) return 0;
     ZMI_LAUNCH(zmi_inflate_plan_kernel, dim3(1), dim3(1024), 0, stream, d_out_cap, n_streams, bitmap_words, d_bm_off);
     ZMI_LAUNCH(zmi_inflate_clear_kernel, dim3(n_streams), dim3(256), 0, stream, d_out_cap, (const uint64_t*)d_bm_off, d_bitmap);
-    ZMI_LAUNCH(zmi_inflate_kernel, dim3(n_streams), dim3(64), 0, stream, d_in, d_in_off, d_in_len, wrap, d_out, d_out_off,
-               d_out_cap, d_out_len, d_in_used, d_check, d_status, d_bitmap, (const uint64_t*)d_bm_off, d_out_hist);
+    if (d_resume)
+        ZMI_LAUNCH(zmi_inflate_kernel<true>, dim3(n_streams), dim3(64), 0, stream, d_in, d_in_off, d_in_len, wrap, d_out, d_out_off,
+                   d_out_cap, d_out_len, d_in_used, d_check, d_status, d_bitmap, (const uint64_t*)d_bm_off, d_out_hist, d_in_bit, d_resume);
+    else
+        ZMI_LAUNCH(zmi_inflate_kernel<false>, dim3(n_streams), dim3(64), 0, stream, d_in, d_in_off, d_in_len, wrap, d_out, d_out_off,
+                   d_out_cap, d_out_len, d_in_used, d_check, d_status, d_bitmap, (const uint64_t*)d_bm_off, d_out_hist,
+                   (const uint32_t*)nullptr, (uint32_t*)nullptr);
     return 0;
 }
 

@@ -15,6 +15,7 @@
 #include <mutex>
 #include <new>
 #include <stdlib.h>
+#include <limits.h>
 #include <string.h>
 #include <vector>
 
@@ -31,6 +32,9 @@ extern "C" int zmi_inflate_batch_dict_dev(zmi_ctx* c, const void* d_in, const ui
                                           uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off,
                                           const uint32_t* d_out_cap, const uint32_t* d_out_hist, uint32_t* d_out_len,
                                           int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail, void* stream);
+extern "C" int zmi_inflate_resume(zmi_ctx* c, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist,
+                                  uint32_t hist_len, uint8_t* out, uint32_t out_cap, uint32_t* out_len, int32_t* status,
+                                  int32_t* detail, uint32_t* in_used, uint32_t* resume);
 extern "C" int zmi_inflate_batch_dev_ex(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                         uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                                         uint32_t* d_out_len, int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail,
@@ -43,14 +47,16 @@ extern "C" int zmi_inflate_batch_dev_ex(zmi_ctx* c, const void* d_in, const uint
 // ------------------------------------------------------------------------------------------------
 namespace {
 const uint32_t kBase = 65521u, kNmax = 5552u, kPoly = 0xEDB88320u;
-uint32_t g_crc_table[256];
+uint32_t g_crc_table[8][256];   // slicing-by-8: table k advances a byte that is followed by k more bytes
 std::once_flag g_crc_once;
 void crc_init() {
     for (uint32_t i = 0; i < 256; ++i) {
         uint32_t c = i;
         for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? kPoly : 0u);
-        g_crc_table[i] = c;
+        g_crc_table[0][i] = c;
     }
+    for (uint32_t i = 0; i < 256; ++i)
+        for (int k = 1; k < 8; ++k) g_crc_table[k][i] = g_crc_table[0][g_crc_table[k - 1][i] & 0xFFu] ^ (g_crc_table[k - 1][i] >> 8);
 }
 uint32_t host_adler32(uint32_t adler, const uint8_t* buf, size_t len) {
     uint32_t a = adler & 0xFFFFu, b = (adler >> 16) & 0xFFFFu;
@@ -65,7 +71,17 @@ uint32_t host_adler32(uint32_t adler, const uint8_t* buf, size_t len) {
 uint32_t host_crc32(uint32_t crc, const uint8_t* buf, size_t len) {
     std::call_once(g_crc_once, crc_init);
     crc = ~crc;
-    while (len--) crc = g_crc_table[(crc ^ *buf++) & 0xFFu] ^ (crc >> 8);
+    while (len >= 8) {
+        uint32_t lo, hi;
+        memcpy(&lo, buf, 4);
+        memcpy(&hi, buf + 4, 4);
+        lo ^= crc;
+        crc = g_crc_table[7][lo & 0xFFu] ^ g_crc_table[6][(lo >> 8) & 0xFFu] ^ g_crc_table[5][(lo >> 16) & 0xFFu] ^ g_crc_table[4][lo >> 24] ^
+              g_crc_table[3][hi & 0xFFu] ^ g_crc_table[2][(hi >> 8) & 0xFFu] ^ g_crc_table[1][(hi >> 16) & 0xFFu] ^ g_crc_table[0][hi >> 24];
+        buf += 8;
+        len -= 8;
+    }
+    while (len--) crc = g_crc_table[0][(crc ^ *buf++) & 0xFFu] ^ (crc >> 8);
     return ~crc;
 }
 uint32_t gf2_mul(uint32_t a, uint32_t b) {
@@ -134,8 +150,9 @@ size_t segment_bytes() {  // 1 MiB segments; ZMI_ABI_SEGMENT (bytes, multiple of
 // wrap 1 / 2: *check receives the Adler-32 / CRC-32 of the n bytes (per segment on the GPU, where the data is;
 // stitched with the combine algebra, crc32/combine.rs, adler32 combine lib.rs:372)
 int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_t hist_len, int level, int strategy, bool finish,
-                         std::vector<uint8_t>& out, int wrap = 0, uint32_t* check = nullptr) {
+                         std::vector<uint8_t>& out, int wrap = 0, uint32_t* check = nullptr, size_t* last_at = nullptr) {
     if (check) *check = wrap == 1 ? 1u : 0u;
+    if (last_at) *last_at = out.size();
     if (n == 0) {
         if (finish) { out.push_back(0x03); out.push_back(0x00); }  // empty final static block (deflate.rs: 03 00)
         else { const uint8_t m[5] = {0x00, 0x00, 0x00, 0xFF, 0xFF}; out.insert(out.end(), m, m + 5); }
@@ -193,6 +210,7 @@ int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_
     for (uint32_t i = 0; i < nseg; ++i) {
         if (st[i] != 0) return Z_BUF_ERROR;
         size_t at = out.size();
+        if (last_at) *last_at = at;
         out.resize(at + olen[i]);
         if (hipMemcpy(out.data() + at, (const uint8_t*)d_out.p + (uint64_t)i * stride, olen[i], hipMemcpyDeviceToHost) != hipSuccess)
             return Z_MEM_ERROR;
@@ -256,57 +274,93 @@ struct DeflateState {
     bool dict_set = false;         // zlib wrapper: header announces the dictionary (FDICT + DICTID)
     uint32_t dictid = 0;
     gz_headerp gzhead = nullptr;   // deflateSetHeader: read when the header is written, as the reference does
+    uint32_t prime_val = 0;        // deflatePrime: bits (< 8) waiting in front of the next compressed data
+    int prime_bits = 0;
+    std::vector<uint8_t> last_seg; // compressed bytes of the most recent segment (deflateUsed decodes them on demand)
+    bool last_seg_final = false;
+    int used_bits = 0;             // deflateUsed: 0 = no flush yet, -1 = not computed for last_seg yet
 };
+// The inflate side is a host state machine around the resumable device decode (zmi_inflate_resume): wrapper
+// header and trailer are parsed here, the deflate data goes to the GPU from the last block boundary the decode
+// reached (the checkpoint), with the 32 KiB of output in front of it as history.  The reference keeps the
+// equivalent facts in Mode / BitReader / Window (zlib-rs/src/inflate.rs:288-320).
+enum { IM_HEAD = 0, IM_DICT, IM_BLOCKS, IM_TRAILER, IM_DONE, IM_BAD };
 struct InflateState {
     int kind = KIND_INFLATE;
     int wrap = 1, wbits = 15;
-    std::vector<uint8_t> in;
-    std::vector<uint8_t> out;
+    int mode = IM_HEAD;
+    int form = -1;                 // wrapper found: 0 raw, 1 zlib, 2 gzip (-1: no header seen yet)
+    std::vector<uint8_t> in;       // input from the checkpoint on; the next block starts at bit `sbit` of in[0]
+    uint32_t sbit = 0;
+    size_t tried = (size_t)-1;     // in.size() at the last decode attempt
+    size_t stop = 0;               // how far into `in` the decoder got (inflateSync searches from there)
+    std::vector<uint8_t> hist;     // the up to 32 KiB of output in front of the checkpoint; starts as the preset dictionary
+    size_t pend = 0;               // decoded bytes behind the checkpoint that are already queued
+    std::vector<uint8_t> out;      // decoded bytes not yet handed to the caller
     size_t out_pos = 0;
-    size_t tried_at = 0;  // input size at the last decode attempt
-    bool done = false;    // stream decoded completely (out holds everything)
+    std::vector<uint8_t> tmp;      // decode target of one attempt
+    uint32_t check = 1;            // Adler-32 / CRC-32 of the bytes handed to the caller
+    uint32_t want_check = 0;       // trailer values, compared when the last byte has been handed out
+    uint32_t want_len = 0;
+    uint64_t total = 0;            // bytes decoded
+    bool verify = true;            // inflateValidate
     int error = 0;
     const char* errmsg = nullptr;
-    std::vector<uint8_t> dict;   // preset dictionary (inflateSetDictionary)
     bool have_dict = false;
-    bool want_dict = false;      // a zlib header with FDICT was seen: inflate() returned Z_NEED_DICT
     uint32_t dictid = 0;
-    gz_headerp gzhead = nullptr; // inflateGetHeader: filled as soon as the buffered input holds the whole gzip header
-    std::vector<uint8_t> window; // the last 32 KiB handed to the caller (inflateGetDictionary)
+    gz_headerp gzhead = nullptr;   // inflateGetHeader
+    std::vector<uint8_t> window;   // the last 32 KiB handed to the caller (inflateGetDictionary)
+    uint64_t bias = 0;             // buffered bytes inflateSync reported as not yet consumed
+    int sync_have = 0;             // inflateSync: marker bytes matched so far
+    bool in_sync = false;
+    int last_block = 0;
+    uint32_t primed = 0;           // bits at the front of `in` that came from inflatePrime
+    std::vector<uint8_t> dict;     // the preset dictionary (inflateGetDictionary shows it in front of the output)
+    uint8_t* back_window = nullptr;   // inflateBack: the caller's window
 };
 
-// fills *h from a gzip header at the start of `in` (inflate.rs:1063-1275); returns false while the header is incomplete
-bool parse_gzip_header(const std::vector<uint8_t>& in, gz_header* h) {
-    if (in.size() < 10) return false;
+// length of the gzip header at the start of `in` (inflate.rs:1063-1275): 0 while it is incomplete, -1 with *err
+// set when it is invalid; fills *h (may be null) once the header is complete
+long gzip_header_len(const std::vector<uint8_t>& in, gz_header* h, bool verify, const char** err) {
+    if (in.size() < 10) return 0;
+    if (in[2] != 8) { *err = "unknown compression method"; return -1; }
     const uint8_t flg = in[3];
+    if (flg & 0xE0) { *err = "unknown header flags set"; return -1; }
     size_t p = 10;
     size_t xoff = 0, xlen = 0, noff = 0, coff = 0;
     if (flg & 4) {
-        if (p + 2 > in.size()) return false;
+        if (p + 2 > in.size()) return 0;
         xlen = in[p] | ((size_t)in[p + 1] << 8);
         xoff = p + 2;
         p += 2 + xlen;
-        if (p > in.size()) return false;
+        if (p > in.size()) return 0;
     }
-    if (flg & 8) { noff = p; while (p < in.size() && in[p]) ++p; if (p >= in.size()) return false; ++p; }
-    if (flg & 16) { coff = p; while (p < in.size() && in[p]) ++p; if (p >= in.size()) return false; ++p; }
-    if (flg & 2) { if (p + 2 > in.size()) return false; p += 2; }
-    h->text = flg & 1;
-    h->time = (uLong)(in[4] | ((uint32_t)in[5] << 8) | ((uint32_t)in[6] << 16) | ((uint32_t)in[7] << 24));
-    h->xflags = in[8];
-    h->os = in[9];
-    h->hcrc = (flg >> 1) & 1;
-    h->extra_len = (uInt)xlen;
-    if ((flg & 4) && h->extra) memcpy(h->extra, in.data() + xoff, xlen < h->extra_max ? xlen : h->extra_max);
-    auto copy_str = [&](size_t off, Bytef* dst, uInt cap) {
-        if (!dst || cap == 0) return;
-        size_t n = strlen((const char*)in.data() + off) + 1;   // the terminator is stored when it fits (inflate.rs:1176-1222)
-        memcpy(dst, in.data() + off, n < cap ? n : cap);
-    };
-    if (flg & 8) copy_str(noff, h->name, h->name_max); else h->name = nullptr;
-    if (flg & 16) copy_str(coff, h->comment, h->comm_max); else h->comment = nullptr;
-    h->done = 1;
-    return true;
+    if (flg & 8) { noff = p; while (p < in.size() && in[p]) ++p; if (p >= in.size()) return 0; ++p; }
+    if (flg & 16) { coff = p; while (p < in.size() && in[p]) ++p; if (p >= in.size()) return 0; ++p; }
+    if (flg & 2) {
+        if (p + 2 > in.size()) return 0;
+        const uint32_t c = host_crc32(0, in.data(), p) & 0xFFFFu;
+        if (verify && c != (uint32_t)(in[p] | (in[p + 1] << 8))) { *err = "header crc mismatch"; return -1; }
+        p += 2;
+    }
+    if (h) {
+        h->text = flg & 1;
+        h->time = (uLong)(in[4] | ((uint32_t)in[5] << 8) | ((uint32_t)in[6] << 16) | ((uint32_t)in[7] << 24));
+        h->xflags = in[8];
+        h->os = in[9];
+        h->hcrc = (flg >> 1) & 1;
+        h->extra_len = (uInt)xlen;
+        if ((flg & 4) && h->extra) memcpy(h->extra, in.data() + xoff, xlen < h->extra_max ? xlen : h->extra_max);
+        auto copy_str = [&](size_t off, Bytef* dst, uInt cap) {
+            if (!dst || cap == 0) return;
+            size_t n = strlen((const char*)in.data() + off) + 1;   // the terminator is stored when it fits (inflate.rs:1176-1222)
+            memcpy(dst, in.data() + off, n < cap ? n : cap);
+        };
+        if (flg & 8) copy_str(noff, h->name, h->name_max); else h->name = nullptr;
+        if (flg & 16) copy_str(coff, h->comment, h->comm_max); else h->comment = nullptr;
+        h->done = 1;
+    }
+    return (long)p;
 }
 
 
@@ -381,10 +435,26 @@ void put_header(DeflateState* s) {
 // full_flush: the caller asked for Z_FULL_FLUSH -- the data after it must not refer to anything before it
 int compress_buffered(DeflateState* s, bool finish, bool full_flush = false) {
     if (!s->header_done) put_header(s);
+    if (s->prime_bits) {
+        // deflatePrime left a partial byte.  Every segment of this engine starts on a byte boundary, so an empty
+        // stored block (3 header bits, padding, 00 00 FF FF) follows the primed bits: valid deflate, byte aligned again
+        s->pending.push_back((uint8_t)s->prime_val);
+        if (s->prime_bits > 5) s->pending.push_back(0);   // the block header does not fit into that byte
+        const uint8_t m[4] = {0x00, 0x00, 0xFF, 0xFF};
+        s->pending.insert(s->pending.end(), m, m + 4);
+        s->prime_bits = 0;
+        s->prime_val = 0;
+    }
     s->total_len += s->in.size();
     uint32_t part = 0;   // checksum of this call's input, computed on the GPU next to the compression
+    size_t last_at = 0;
     int rc = gpu_deflate_segments(s->in.data(), s->in.size(), s->hist.data(), s->hist.size(), s->level, s->strategy, finish, s->pending,
-                                  s->wrap, &part);
+                                  s->wrap, &part, &last_at);
+    if (rc == Z_OK) {
+        s->last_seg.assign(s->pending.begin() + last_at, s->pending.end());
+        s->last_seg_final = finish;
+        s->used_bits = -1;
+    }
     if (rc == Z_OK && s->wrap == 1) s->adler = host_adler_combine(s->adler, part, s->in.size());
     if (rc == Z_OK && s->wrap == 2) s->crc = gf2_mul(gf2_xpow8(s->in.size()), s->crc) ^ part;
     // window carry-over to the next call: the last 32 KiB of what the stream has seen (deflate.rs:2739-2752: only
@@ -418,6 +488,188 @@ size_t drain(z_streamp strm, std::vector<uint8_t>& buf, size_t& pos) {
         pos += n;
     }
     if (pos == buf.size()) { buf.clear(); pos = 0; }
+    return n;
+}
+// ---- inflate machinery ----
+void inf_bad(InflateState* s, const char* msg) {
+    s->mode = IM_BAD;
+    s->error = Z_DATA_ERROR;
+    s->errmsg = msg;
+    s->in.clear();
+    s->sbit = 0;
+}
+void inf_keep_hist(InflateState* s, const uint8_t* p, size_t n) {
+    if (n >= 32768u) s->hist.assign(p + (n - 32768u), p + n);
+    else {
+        s->hist.insert(s->hist.end(), p, p + n);
+        if (s->hist.size() > 32768u) s->hist.erase(s->hist.begin(), s->hist.end() - 32768);
+    }
+}
+const size_t kQueueLimit = (size_t)32 << 20;   // decoded bytes waiting for the caller before decoding pauses
+
+// Decode what is buffered, from the checkpoint.  Queues every new byte, moves the checkpoint to the last block
+// boundary reached, and changes the mode when the final block ended or the data is invalid.
+int inflate_attempt(InflateState* s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    zmi_ctx* c = abi_ctx();
+    if (!c) return Z_MEM_ERROR;
+    size_t take = s->in.size() < ((size_t)256 << 20) ? s->in.size() : ((size_t)256 << 20);
+    size_t cap = take * 4 + 65536;
+    if (cap > ((size_t)64 << 20)) cap = (size_t)64 << 20;
+    for (;;) {
+        if (s->tmp.size() < cap) s->tmp.resize(cap);
+        uint32_t olen = 0, used = 0, res[4] = {0, 0, 0, 0};
+        int32_t st = 0, det = 0;
+        if (zmi_inflate_resume(c, s->in.data(), (uint32_t)take, s->sbit, s->hist.data(), (uint32_t)s->hist.size(), s->tmp.data(),
+                               (uint32_t)cap, &olen, &st, &det, &used, res) != 0)
+            return Z_MEM_ERROR;
+        if (st == Z_MEM_ERROR) return Z_MEM_ERROR;
+        const size_t eff = olen < cap ? olen : cap;
+        if (st == Z_BUF_ERROR && det == 2 && res[2] == 0) {   // one block that is larger than the room: more room
+            if (cap >= 0xE0000000ull) return Z_MEM_ERROR;
+            cap *= 2;
+            continue;
+        }
+        if (eff > s->pend) {
+            s->out.insert(s->out.end(), s->tmp.begin() + s->pend, s->tmp.begin() + eff);
+            s->total += eff - s->pend;
+        }
+        if (st == Z_OK) {   // the final block ended `used` bytes in
+            s->in.erase(s->in.begin(), s->in.begin() + (used < s->in.size() ? used : s->in.size()));
+            s->sbit = 0;
+            s->primed = 0;
+            s->pend = 0;
+            s->stop = 0;
+            s->last_block = 1;
+            inf_keep_hist(s, s->tmp.data(), eff);
+            s->mode = IM_TRAILER;
+            break;
+        }
+        if (st != Z_BUF_ERROR) {
+            // the bytes decoded in front of the error are valid output: they are handed out first, as the reference
+            // does, and the error is reported once they are gone
+            inf_bad(s, "invalid or corrupt deflate stream");
+            break;
+        }
+        // more input or more room needed: everything in front of the checkpoint is settled
+        inf_keep_hist(s, s->tmp.data(), res[2]);
+        s->pend = eff - res[2];
+        s->in.erase(s->in.begin(), s->in.begin() + res[0]);
+        if (res[0] || res[1] != s->sbit) s->primed = 0;
+        s->sbit = res[1];
+        s->stop = used > res[0] ? used - res[0] : 0;
+        if (take > res[0]) take -= res[0]; else take = 0;
+        const bool more_buffered = take < s->in.size();
+        if (det == 2 || more_buffered) {
+            if (s->out.size() - s->out_pos > kQueueLimit) { s->tried = (size_t)-1; return Z_OK; }   // let the caller drain first
+            if (more_buffered) {
+                if (res[0] == 0 && det != 2) {   // no block boundary inside what was given: give more
+                    if (take >= 0xF0000000ull || take == s->in.size()) break;
+                    take = s->in.size() < take * 2 ? s->in.size() : take * 2;
+                } else take = s->in.size() < ((size_t)256 << 20) ? s->in.size() : ((size_t)256 << 20);
+            }
+            continue;
+        }
+        break;
+    }
+    s->tried = s->in.size();
+    return Z_OK;
+}
+
+// header / blocks / trailer.  Returns Z_OK, Z_NEED_DICT or Z_MEM_ERROR.
+int inflate_run(z_streamp strm, InflateState* s) {
+    for (;;) {
+        switch (s->mode) {
+        case IM_HEAD: {
+            if (s->wrap == ZMI_WRAP_RAW) { s->form = 0; s->mode = IM_BLOCKS; break; }
+            if (s->sbit != 0) { inf_bad(s, "incorrect header check"); break; }   // primed bits in front of a wrapper
+            if (s->in.size() < 2) return Z_OK;
+            const bool magic = s->in[0] == 0x1F && s->in[1] == 0x8B;
+            if (s->wrap == ZMI_WRAP_GZIP || (s->wrap == ZMI_WRAP_AUTO && magic)) {   // inflate.rs:1000-1030
+                if (!magic) { inf_bad(s, "incorrect header check"); break; }
+                const char* err = nullptr;
+                const long l = gzip_header_len(s->in, s->gzhead, s->verify, &err);
+                if (l < 0) { inf_bad(s, err); break; }
+                if (l == 0) return Z_OK;
+                s->in.erase(s->in.begin(), s->in.begin() + l);
+                s->form = 2;
+                s->check = 0;
+                strm->adler = 0;
+                s->mode = IM_BLOCKS;
+                break;
+            }
+            if (s->gzhead) s->gzhead->done = -1;   // not a gzip stream (inflate.rs:1024-1028)
+            const unsigned h = ((unsigned)s->in[0] << 8) | s->in[1];
+            if (h % 31u) { inf_bad(s, "incorrect header check"); break; }
+            if ((s->in[0] & 0x0F) != 8) { inf_bad(s, "unknown compression method"); break; }
+            const int len = (s->in[0] >> 4) + 8;
+            if (len > 15 || (s->wbits != 0 && len > s->wbits)) { inf_bad(s, "invalid window size"); break; }
+            s->form = 1;
+            s->check = 1;
+            if (s->in[1] & 0x20) {   // FDICT: the DICTID follows; wait for inflateSetDictionary (inflate.rs:1036-1062)
+                if (s->in.size() < 6) return Z_OK;
+                s->dictid = ((uint32_t)s->in[2] << 24) | ((uint32_t)s->in[3] << 16) | ((uint32_t)s->in[4] << 8) | s->in[5];
+                s->in.erase(s->in.begin(), s->in.begin() + 6);
+                s->mode = IM_DICT;
+                break;
+            }
+            s->in.erase(s->in.begin(), s->in.begin() + 2);
+            strm->adler = 1;
+            s->mode = IM_BLOCKS;
+            break;
+        }
+        case IM_DICT:
+            strm->adler = s->dictid;
+            strm->msg = kErrMsg[0];
+            return Z_NEED_DICT;
+        case IM_BLOCKS: {
+            if (s->in.empty() || s->tried == s->in.size()) return Z_OK;
+            if (s->out.size() - s->out_pos > kQueueLimit) return Z_OK;
+            const int rc = inflate_attempt(s);
+            if (rc != Z_OK) return rc;
+            if (s->mode == IM_BLOCKS) return Z_OK;
+            break;
+        }
+        case IM_TRAILER: {
+            const size_t need = s->form == 1 ? 4 : (s->form == 2 ? 8 : 0);
+            if (s->in.size() < need) return Z_OK;
+            if (s->form == 1) s->want_check = ((uint32_t)s->in[0] << 24) | ((uint32_t)s->in[1] << 16) | ((uint32_t)s->in[2] << 8) | s->in[3];
+            else if (s->form == 2) {
+                s->want_check = s->in[0] | ((uint32_t)s->in[1] << 8) | ((uint32_t)s->in[2] << 16) | ((uint32_t)s->in[3] << 24);
+                s->want_len = s->in[4] | ((uint32_t)s->in[5] << 8) | ((uint32_t)s->in[6] << 16) | ((uint32_t)s->in[7] << 24);
+            }
+            s->in.erase(s->in.begin(), s->in.begin() + need);
+            s->mode = IM_DONE;
+            return Z_OK;
+        }
+        default:
+            return Z_OK;
+        }
+    }
+}
+
+// hands decoded bytes to the caller; the check value follows what has been handed out (inflate/window.rs:95-168)
+size_t inflate_drain(z_streamp strm, InflateState* s) {
+    size_t n = s->out.size() > s->out_pos ? s->out.size() - s->out_pos : 0;
+    if (n > strm->avail_out) n = strm->avail_out;
+    if (n) {
+        const uint8_t* p = s->out.data() + s->out_pos;
+        memcpy(strm->next_out, p, n);
+        if (s->verify && s->form == 1) s->check = host_adler32(s->check, p, n);
+        else if (s->verify && s->form == 2) s->check = host_crc32(s->check, p, n);
+        if (n >= 32768u) s->window.assign(p + (n - 32768u), p + n);
+        else {
+            s->window.insert(s->window.end(), p, p + n);
+            if (s->window.size() > 32768u) s->window.erase(s->window.begin(), s->window.end() - 32768);
+        }
+        s->out_pos += n;
+        strm->next_out += n;
+        strm->avail_out -= (uInt)n;
+        strm->total_out += n;
+        if (s->form > 0) strm->adler = s->check;
+    }
+    if (s->out_pos >= s->out.size()) { s->out.clear(); s->out_pos = 0; }
+    else if (s->out_pos > ((size_t)8 << 20)) { s->out.erase(s->out.begin(), s->out.begin() + s->out_pos); s->out_pos = 0; }
     return n;
 }
 }  // namespace
@@ -544,7 +796,7 @@ int deflatePending(z_streamp strm, unsigned* pending, int* bits) {
     DeflateState* s = dstate(strm);
     if (!s) return Z_STREAM_ERROR;
     if (pending) *pending = (unsigned)(s->pending.size() - s->pending_pos);
-    if (bits) *bits = 0;
+    if (bits) *bits = s->prime_bits;
     return Z_OK;
 }
 int deflateSetDictionary(z_streamp strm, const Bytef* dictionary, uInt dictLength) {
@@ -564,7 +816,61 @@ int deflateSetDictionary(z_streamp strm, const Bytef* dictionary, uInt dictLengt
     return Z_OK;
     ZMI_ABI_CATCH(Z_MEM_ERROR)
 }
-int deflatePrime(z_streamp, int, int) { return Z_STREAM_ERROR; }
+int deflatePrime(z_streamp strm, int bits, int value) {
+    // deflate.rs:566-606: whole bytes go to the pending output at once (in front of a header that is not written yet,
+    // as in the reference); a rest below 8 bits waits for the next compressed data (compress_buffered)
+    ZMI_ABI_TRY
+    DeflateState* s = dstate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    if (bits < 0 || bits > 32) return Z_BUF_ERROR;
+    uint64_t acc = (uint64_t)s->prime_val | (((uint64_t)(uint32_t)value & ((1ull << bits) - 1ull)) << s->prime_bits);
+    int total = s->prime_bits + bits;
+    while (total >= 8) { s->pending.push_back((uint8_t)acc); acc >>= 8; total -= 8; }
+    s->prime_val = (uint32_t)acc;
+    s->prime_bits = total;
+    return Z_OK;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
+}
+int deflateUsed(z_streamp strm, int* bits) {
+    // deflate.rs:129 bits_used: bits of the last byte in use when the output last went to a byte boundary (1..8, 0 before
+    // any flush).  The encoder kernels do not report bit positions; the most recent segment is decoded on the device to
+    // the block that ends it (zmi_inflate_resume's checkpoint), only when somebody asks.
+    ZMI_ABI_TRY
+    DeflateState* s = dstate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    if (s->used_bits < 0) {
+        std::lock_guard<std::mutex> lk(g_mu);
+        zmi_ctx* c = abi_ctx();
+        if (!c) return Z_MEM_ERROR;
+        // a flush ends with the empty stored block 00 00 FF FF: without those four bytes the decode stops at its header
+        size_t n = s->last_seg.size();
+        if (!s->last_seg_final) n = n >= 4 ? n - 4 : 0;
+        const std::vector<uint8_t> zeros(32768, 0);   // any history will do: only positions are wanted
+        std::vector<uint8_t> tmp;
+        size_t base = 0, cap = (size_t)4 << 20;
+        uint32_t bit = 0;
+        for (;;) {
+            tmp.resize(cap);
+            uint32_t olen = 0, used = 0, res[4] = {0, 0, 0, 0};
+            int32_t st = 0, det = 0;
+            if (zmi_inflate_resume(c, s->last_seg.data() + base, (uint32_t)(n - base), bit, zeros.data(), 32768u, tmp.data(), (uint32_t)cap,
+                                   &olen, &st, &det, &used, res) != 0)
+                return Z_MEM_ERROR;
+            if (st == Z_BUF_ERROR && det == 2) {   // out of room: go on from the checkpoint (or with more room)
+                if (res[2] == 0) { if (cap >= 0xE0000000ull) return Z_MEM_ERROR; cap *= 2; }
+                base += res[0]; bit = res[1];
+                continue;
+            }
+            if (st == Z_OK) s->used_bits = res[1] ? (int)res[1] : 8;
+            else if (st == Z_BUF_ERROR) s->used_bits = (int)((res[1] + 2u) & 7u) + 1;
+            else return Z_STREAM_ERROR;
+            break;
+        }
+    }
+    if (bits) *bits = s->used_bits;
+    return Z_OK;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
+}
 int deflateGetDictionary(z_streamp strm, Bytef* dictionary, uInt* dictLength) {   // deflate.rs: the current window
     DeflateState* s = dstate(strm);
     if (!s) return Z_STREAM_ERROR;
@@ -624,17 +930,37 @@ int compress2(Bytef* dest, uLongf* destLen, const Bytef* source, uLong sourceLen
 int compress(Bytef* dest, uLongf* destLen, const Bytef* source, uLong sourceLen) { return compress2(dest, destLen, source, sourceLen, 6); }
 
 // ---------------------------------------------------------------- inflate
+namespace {
+int parse_window_bits(int windowBits, int* wrap, int* wb) {   // inflate.rs:2298-2327
+    int w = windowBits;
+    if (w < 0) { if (w < -15) return Z_STREAM_ERROR; *wrap = ZMI_WRAP_RAW; w = -w; }
+    else if (w >= 32) { *wrap = ZMI_WRAP_AUTO; w -= 32; }
+    else if (w >= 16) { *wrap = ZMI_WRAP_GZIP; w -= 16; }
+    else *wrap = ZMI_WRAP_ZLIB;
+    if (w != 0 && (w < 8 || w > 15)) return Z_STREAM_ERROR;
+    *wb = w;
+    return Z_OK;
+}
+void inflate_reset_state(z_streamp strm, InflateState* s) {
+    const int wrap = s->wrap, wb = s->wbits;
+    uint8_t* bw = s->back_window;
+    s->~InflateState();
+    new (s) InflateState();
+    s->wrap = wrap; s->wbits = wb; s->back_window = bw;
+    strm->total_in = strm->total_out = 0;
+    strm->msg = nullptr;
+    strm->adler = 1;
+    strm->data_type = 0;
+}
+}  // namespace
+
 int inflateInit2_(z_streamp strm, int windowBits, const char* version, int stream_size) {
     ZMI_ABI_TRY
     if (!version_ok(version, stream_size)) return Z_VERSION_ERROR;
     if (!strm) return Z_STREAM_ERROR;
     strm->msg = nullptr;
-    int wrap, wb = windowBits;
-    if (wb < 0) { if (wb < -15) return Z_STREAM_ERROR; wrap = ZMI_WRAP_RAW; wb = -wb; }
-    else if (wb >= 32) { wrap = ZMI_WRAP_AUTO; wb -= 32; }   // inflate.rs:2298-2327
-    else if (wb >= 16) { wrap = ZMI_WRAP_GZIP; wb -= 16; }
-    else wrap = ZMI_WRAP_ZLIB;
-    if (wb != 0 && (wb < 8 || wb > 15)) return Z_STREAM_ERROR;
+    int wrap = 0, wb = 0;
+    if (parse_window_bits(windowBits, &wrap, &wb) != Z_OK) return Z_STREAM_ERROR;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         if (!abi_ctx()) { strm->msg = "no HIP device"; return Z_MEM_ERROR; }
@@ -651,83 +977,44 @@ int inflateInit2_(z_streamp strm, int windowBits, const char* version, int strea
 }
 int inflateInit_(z_streamp strm, const char* version, int stream_size) { return inflateInit2_(strm, MAX_WBITS, version, stream_size); }
 int inflate(z_streamp strm, int flush) {
+    // Every call takes all of avail_in and decodes as far as the buffered input allows ("provides as much output as
+    // possible", lib.rs:637): Z_BLOCK / Z_TREES are accepted and behave like Z_NO_FLUSH (no stop at block ends).
     ZMI_ABI_TRY
     InflateState* s = istate(strm);
-    if (!s || !strm->next_out || (strm->avail_in != 0 && !strm->next_in)) return Z_STREAM_ERROR;
-    if (s->error && s->out_pos >= s->out.size()) { strm->msg = s->errmsg; return s->error; }
+    if (!s || s->back_window || !strm->next_out || (strm->avail_in != 0 && !strm->next_in)) return Z_STREAM_ERROR;
+    if (s->bias) { strm->total_in += (uLong)s->bias; s->bias = 0; }
     const uInt in0 = strm->avail_in, out0 = strm->avail_out;
-    if (!s->done && !s->error) {
-        const size_t before = s->in.size();
-        if (strm->avail_in) s->in.insert(s->in.end(), strm->next_in, strm->next_in + strm->avail_in);
-        // decode attempts: when new input arrived and the buffer grew by >= 25 % (or the caller finishes)
-        bool attempt = in0 != 0 && (flush == Z_FINISH || s->tried_at == 0 || s->in.size() >= s->tried_at + s->tried_at / 4 + 64);
-        if (in0 == 0 && flush == Z_FINISH && s->tried_at != s->in.size()) attempt = true;
-        if (s->have_dict && s->tried_at == 0 && !s->in.empty()) attempt = true;   // first call after inflateSetDictionary
-        if (s->gzhead && s->gzhead->done == 0 && s->in.size() >= 2) {
-            if (s->in[0] == 0x1F && s->in[1] == 0x8B && (s->wrap == ZMI_WRAP_GZIP || s->wrap == ZMI_WRAP_AUTO)) (void)parse_gzip_header(s->in, s->gzhead);
-            else s->gzhead->done = -1;   // not a gzip stream (inflate.rs:1024-1028)
-        }
-        int32_t st = ZMI_E_OK, detail = 1;
-        uint32_t used = 0;
-        // a zlib header that announces a preset dictionary: report Z_NEED_DICT with the DICTID in strm->adler and
-        // wait for inflateSetDictionary (inflate.rs:1036-1062)
-        if (!s->have_dict && s->in.size() >= 2 && (s->wrap == ZMI_WRAP_ZLIB || (s->wrap == ZMI_WRAP_AUTO && s->in[0] != 0x1F)) &&
-            (s->in[0] & 0x0F) == 8 && ((s->in[0] << 8 | s->in[1]) % 31) == 0 && (s->in[1] & 0x20)) {
-            strm->next_in += in0; strm->total_in += in0; strm->avail_in = 0;
-            if (s->in.size() < 6) { if (in0 == 0 || flush == Z_FINISH) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; } return Z_OK; }
-            s->dictid = ((uint32_t)s->in[2] << 24) | ((uint32_t)s->in[3] << 16) | ((uint32_t)s->in[4] << 8) | s->in[5];
-            s->want_dict = true;
-            strm->adler = s->dictid;
-            strm->msg = kErrMsg[0];
-            return Z_NEED_DICT;
-        }
-        if (attempt && !s->in.empty()) {
-            size_t cap = s->in.size() * 4 + 65536;
-            for (;;) {
-                int rc = gpu_inflate_stream(s->in.data(), s->in.size(), s->wrap, s->out, cap, &used, &st, &detail,
-                                            s->have_dict ? s->dict.data() : nullptr, s->have_dict ? s->dict.size() : 0);
-                if (rc != Z_OK) { strm->msg = zError(rc); return rc; }
-                if (st == Z_BUF_ERROR && detail == 2) { cap *= 4; if (cap > 0xF0000000ull) return Z_MEM_ERROR; continue; }
-                break;
-            }
-            s->tried_at = s->in.size();
-            if (st == Z_OK) {
-                s->done = true;
-                // bytes after the end of the stream belong to the caller: hand them back
-                size_t from_this_call = s->in.size() - before;
-                size_t unused = s->in.size() - used;
-                if (unused > from_this_call) unused = from_this_call;
-                strm->next_in += in0 - unused;
-                strm->total_in += in0 - unused;
-                strm->avail_in = (uInt)unused;
-            } else if (st == Z_DATA_ERROR || st == Z_NEED_DICT) {
-                // the bytes decoded in front of the error are valid output: they are handed out first, as the
-                // reference does, and the error is reported once they are gone
-                s->error = st;
-                s->errmsg = st == Z_DATA_ERROR ? "invalid or corrupt deflate stream" : kErrMsg[0];
-                strm->next_in += in0; strm->total_in += in0; strm->avail_in = 0;
-            }
-            // st == Z_BUF_ERROR, more input needed: s->out holds the prefix decoded so far.  It is final (a later
-            // attempt with more input reproduces it and appends), so it can be handed out now.
-        }
-        if (!s->done && !s->error) { strm->next_in += in0; strm->total_in += in0; strm->avail_in = 0; }
+    uInt taken = 0;
+    if (s->mode != IM_DONE && s->mode != IM_BAD && in0) {
+        s->in.insert(s->in.end(), strm->next_in, strm->next_in + in0);
+        strm->next_in += in0; strm->total_in += in0; strm->avail_in = 0;
+        taken = in0;
+        s->in_sync = false;
     }
-    size_t n = s->out.size() > s->out_pos ? s->out.size() - s->out_pos : 0;
-    if (n > strm->avail_out) n = strm->avail_out;
-    if (n) {
-        memcpy(strm->next_out, s->out.data() + s->out_pos, n);
-        s->window.insert(s->window.end(), s->out.begin() + s->out_pos, s->out.begin() + s->out_pos + n);
-        if (s->window.size() > 32768u) s->window.erase(s->window.begin(), s->window.end() - 32768);
-        s->out_pos += n;
-        strm->next_out += n;
-        strm->avail_out -= (uInt)n;
-        strm->total_out += n;
+    const int was = s->mode;
+    const int rc = inflate_run(strm, s);
+    if (rc == Z_NEED_DICT) return Z_NEED_DICT;
+    if (rc != Z_OK) { strm->msg = zError(rc); return rc; }
+    if (s->mode == IM_DONE && was != IM_DONE && !s->in.empty()) {
+        // bytes behind the end of the stream belong to the caller: hand them back (they came with this call)
+        const size_t unused = s->in.size() < taken ? s->in.size() : taken;
+        strm->next_in -= unused; strm->total_in -= unused; strm->avail_in += (uInt)unused;
+        s->in.clear();
     }
+    inflate_drain(strm, s);
     const bool drained = s->out_pos >= s->out.size();
-    if (s->done && drained) return Z_STREAM_END;
-    if (s->error && drained) { strm->msg = s->errmsg; return s->error; }
+    // data_type as the reference reports it (inflate.rs:2440-2448): unused bits of the last byte, +64 in the last
+    // block, +128 right behind a block
+    const bool at_boundary = s->mode == IM_BLOCKS && s->pend == 0 && s->in.size() <= (s->sbit ? 1u : 0u) && s->form >= 0;
+    strm->data_type = (int)((s->sbit && s->mode == IM_BLOCKS ? 8u - s->sbit : 0u) + (s->last_block ? 64 : 0) + (at_boundary ? 128 : 0));
+    if (s->mode == IM_DONE && drained) {
+        if (s->verify && s->form > 0 && s->check != s->want_check) { inf_bad(s, "incorrect data check"); strm->msg = s->errmsg; return Z_DATA_ERROR; }
+        if (s->verify && s->form == 2 && (uint32_t)s->total != s->want_len) { inf_bad(s, "incorrect length check"); strm->msg = s->errmsg; return Z_DATA_ERROR; }
+        return Z_STREAM_END;
+    }
+    if (s->mode == IM_BAD && drained) { strm->msg = s->errmsg; return s->error; }
     if (in0 == strm->avail_in && out0 == strm->avail_out) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; }
-    if (flush == Z_FINISH && (s->done || (!s->done && drained))) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; }  // inflate.rs:2450-2456
+    if (flush == Z_FINISH) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; }   // inflate.rs:2450-2456
     return Z_OK;
     ZMI_ABI_CATCH(Z_MEM_ERROR)
 }
@@ -741,46 +1028,38 @@ int inflateEnd(z_streamp strm) {
 int inflateReset(z_streamp strm) {
     InflateState* s = istate(strm);
     if (!s) return Z_STREAM_ERROR;
-    int wrap = s->wrap, wb = s->wbits;
-    s->~InflateState();
-    new (s) InflateState();
-    s->wrap = wrap; s->wbits = wb;
-    strm->total_in = strm->total_out = 0;
-    strm->msg = nullptr;
-    strm->adler = 1;
+    inflate_reset_state(strm, s);
     return Z_OK;
 }
 int inflateReset2(z_streamp strm, int windowBits) {
     InflateState* s = istate(strm);
     if (!s) return Z_STREAM_ERROR;
-    int wrap, wb = windowBits;
-    if (wb < 0) { if (wb < -15) return Z_STREAM_ERROR; wrap = ZMI_WRAP_RAW; wb = -wb; }
-    else if (wb >= 32) { wrap = ZMI_WRAP_AUTO; wb -= 32; }
-    else if (wb >= 16) { wrap = ZMI_WRAP_GZIP; wb -= 16; }
-    else wrap = ZMI_WRAP_ZLIB;
-    if (wb != 0 && (wb < 8 || wb > 15)) return Z_STREAM_ERROR;
+    int wrap = 0, wb = 0;
+    if (parse_window_bits(windowBits, &wrap, &wb) != Z_OK) return Z_STREAM_ERROR;
     s->wrap = wrap; s->wbits = wb;
     return inflateReset(strm);
 }
+int inflateResetKeep(z_streamp strm) { return inflateReset(strm); }   // no window allocation to keep here
 int inflateSetDictionary(z_streamp strm, const Bytef* dictionary, uInt dictLength) {
     // inflate.rs:2492-2536: for a wrapped stream only after inflate() returned Z_NEED_DICT, and the dictionary must
     // have the announced Adler-32; for a raw stream before any output
     ZMI_ABI_TRY
     InflateState* s = istate(strm);
     if (!s || !dictionary) return Z_STREAM_ERROR;
-    if (s->wrap != ZMI_WRAP_RAW && !s->want_dict) return Z_STREAM_ERROR;
-    if (s->done || s->out_pos != 0) return Z_STREAM_ERROR;
-    if (s->want_dict && host_adler32(1, dictionary, dictLength) != s->dictid) return Z_DATA_ERROR;
+    if (s->wrap != ZMI_WRAP_RAW && s->mode != IM_DICT) return Z_STREAM_ERROR;
+    if (s->wrap == ZMI_WRAP_RAW && (s->total != 0 || s->mode == IM_DONE || s->mode == IM_BAD)) return Z_STREAM_ERROR;
+    if (s->mode == IM_DICT && host_adler32(1, dictionary, dictLength) != s->dictid) return Z_DATA_ERROR;
     const uInt keep = dictLength > 32768u ? 32768u : dictLength;
-    s->dict.assign(dictionary + (dictLength - keep), dictionary + dictLength);
+    s->hist.assign(dictionary + (dictLength - keep), dictionary + dictLength);
+    s->dict = s->hist;
     s->have_dict = true;
-    s->want_dict = false;
-    s->tried_at = 0;   // decode again with what is buffered
+    if (s->mode == IM_DICT) { s->mode = IM_BLOCKS; strm->adler = 1; }
+    s->tried = (size_t)-1;   // decode what is buffered with the dictionary in place
     return Z_OK;
     ZMI_ABI_CATCH(Z_MEM_ERROR)
 }
-int inflateSync(z_streamp) { return Z_STREAM_ERROR; }
 int inflateGetDictionary(z_streamp strm, Bytef* dictionary, uInt* dictLength) {   // inflate.rs: the sliding window so far
+    ZMI_ABI_TRY
     InflateState* s = istate(strm);
     if (!s) return Z_STREAM_ERROR;
     // what the stream has produced up to the caller's read position, preceded by the preset dictionary
@@ -790,6 +1069,7 @@ int inflateGetDictionary(z_streamp strm, Bytef* dictionary, uInt* dictLength) { 
     if (dictionary && !w.empty()) memcpy(dictionary, w.data(), w.size());
     if (dictLength) *dictLength = (uInt)w.size();
     return Z_OK;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
 }
 int inflateGetHeader(z_streamp strm, gz_headerp head) {   // inflate.rs: only for streams that may be gzip
     InflateState* s = istate(strm);
@@ -810,7 +1090,197 @@ int inflateCopy(z_streamp dest, z_streamp source) {
     return Z_OK;
     ZMI_ABI_CATCH(Z_MEM_ERROR)
 }
-int inflateResetKeep(z_streamp strm) { return inflateReset(strm); }
+int inflatePrime(z_streamp strm, int bits, int value) {
+    // inflate.rs:2160-2172: bits go in front of the input still to come.  Here that position exists while nothing but
+    // the rest of a partly used byte (or earlier primed bits) is buffered; with undecoded input buffered the call
+    // is refused (Z_STREAM_ERROR).
+    ZMI_ABI_TRY
+    InflateState* s = istate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    if (bits == 0) return Z_OK;
+    if (bits < 0) {   // forget the bits held in front of the next input byte
+        if (s->primed) { s->in.erase(s->in.begin(), s->in.begin() + (s->sbit + s->primed) / 8u); s->sbit = 0; s->primed = 0; }
+        else if (s->sbit && !s->in.empty()) { s->in.erase(s->in.begin()); s->sbit = 0; }
+        s->tried = (size_t)-1;
+        return Z_OK;
+    }
+    if (s->in.size() > 4 || s->pend != 0 || s->mode == IM_DONE || s->mode == IM_BAD) return Z_STREAM_ERROR;
+    const uint32_t held = (uint32_t)s->in.size() * 8u - (s->in.empty() ? 0u : s->sbit);
+    if (bits > 16 || held + (uint32_t)bits > 32u) return Z_STREAM_ERROR;
+    uint64_t v = 0;
+    for (size_t i = 0; i < s->in.size(); ++i) v |= (uint64_t)s->in[i] << (8u * i);
+    v >>= s->in.empty() ? 0u : s->sbit;
+    v |= ((uint64_t)(uint32_t)value & ((1ull << bits) - 1ull)) << held;
+    const uint32_t total = held + (uint32_t)bits;
+    const uint32_t nbytes = (total + 7u) / 8u;
+    s->sbit = nbytes * 8u - total;   // top-aligned: the input byte that comes next continues the bit sequence
+    v <<= s->sbit;
+    s->in.resize(nbytes);
+    for (uint32_t i = 0; i < nbytes; ++i) s->in[i] = (uint8_t)(v >> (8u * i));
+    s->primed = total;
+    s->tried = (size_t)-1;
+    return Z_OK;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
+}
+int inflateSync(z_streamp strm) {
+    // inflate.rs:2458-2535: skip input up to the 00 00 FF FF of a flush point; decoding restarts behind it with an
+    // empty window (so only a Z_FULL_FLUSH point really works), without check value verification
+    ZMI_ABI_TRY
+    InflateState* s = istate(strm);
+    if (!s || (strm->avail_in != 0 && !strm->next_in)) return Z_STREAM_ERROR;
+    if (s->bias) { strm->total_in += (uLong)s->bias; s->bias = 0; }
+    auto search = [&](const uint8_t* buf, size_t len, size_t* next) {
+        int got = s->sync_have;
+        size_t i = 0;
+        while (i < len && got < 4) {
+            if (buf[i] == (got < 2 ? 0 : 0xFF)) ++got;
+            else if (buf[i] != 0) got = 0;
+            else got = 4 - got;
+            ++i;
+        }
+        s->sync_have = got;
+        *next = i;
+    };
+    size_t from = s->stop;
+    if (s->sbit && from == 0) from = 1;
+    if (from > s->in.size()) from = s->in.size();
+    if (strm->avail_in == 0 && (s->in_sync || s->in.size() == from)) return Z_BUF_ERROR;
+    if (!s->in_sync) { s->in_sync = true; s->sync_have = 0; }
+    bool found = false;
+    if (!s->in.empty()) {   // first what is buffered, from where the decoder stopped
+        size_t next = 0;
+        search(s->in.data() + from, s->in.size() - from, &next);
+        if (s->sync_have == 4) {
+            found = true;
+            s->in.erase(s->in.begin(), s->in.begin() + from + next);
+            s->bias = s->in.size();          // these count as not yet consumed, as they are for the reference
+            strm->total_in -= (uLong)s->bias;
+        } else s->in.clear();
+        s->sbit = 0;
+        s->primed = 0;
+        s->stop = 0;
+    }
+    if (!found) {
+        size_t next = 0;
+        search(strm->next_in, strm->avail_in, &next);
+        strm->next_in += next; strm->avail_in -= (uInt)next; strm->total_in += (uLong)next;
+        if (s->sync_have != 4) return Z_DATA_ERROR;
+    }
+    // restart on a new block
+    if (s->form < 0) { s->wrap = ZMI_WRAP_RAW; s->form = 0; }   // no header yet: treat the rest as raw
+    else s->verify = false;                                      // no point in computing a check value now
+    s->mode = IM_BLOCKS;
+    s->hist.clear();
+    s->pend = 0;
+    s->tried = (size_t)-1;
+    s->error = 0; s->errmsg = nullptr;
+    s->in_sync = false; s->sync_have = 0;
+    s->last_block = 0;
+    return Z_OK;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
+}
+int inflateSyncPoint(z_streamp strm) {   // inflate.rs:2537: waiting for the LEN of a stored block with no bits held
+    InflateState* s = istate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    if (s->mode != IM_BLOCKS || s->in.empty() || s->pend != 0) return 0;
+    const uint32_t avail = (uint32_t)(s->in.size() > 2 ? 16 : s->in.size() * 8) - s->sbit;
+    if (avail < 3u) return 0;
+    const uint32_t v = ((uint32_t)s->in[0] | (s->in.size() > 1 ? (uint32_t)s->in[1] << 8 : 0u)) >> s->sbit;
+    if (((v >> 1) & 3u) != 0u) return 0;
+    return s->in.size() == (s->sbit + 3u + 7u) / 8u;
+}
+long inflateMark(z_streamp strm) {   // inflate.rs:2605-2619: -1 in the upper half while not inside a code
+    InflateState* s = istate(strm);
+    if (!s) return -65536;
+    if (!strm->next_out || (!strm->next_in && strm->avail_in != 0)) return LONG_MIN;
+    return (s->pend == 0 && s->in.size() <= (s->sbit ? 1u : 0u)) ? -65536 : 0;
+}
+int inflateValidate(z_streamp strm, int check) {   // inflate.rs:2595
+    InflateState* s = istate(strm);
+    if (!s) return Z_STREAM_ERROR;
+    s->verify = check != 0;
+    return Z_OK;
+}
+int inflateUndermine(z_streamp strm, int) { return istate(strm) ? Z_OK : Z_STREAM_ERROR; }   // inflate.rs:2588
+unsigned long inflateCodesUsed(z_streamp strm) { return istate(strm) ? 0ul : (unsigned long)-1; }   // decode tables live on the device
+
+// ---- inflateBack: raw deflate, input pulled and output pushed through callbacks (inflate/infback.rs:17-722)
+int inflateBackInit_(z_streamp strm, int windowBits, unsigned char* window, const char* version, int stream_size) {
+    ZMI_ABI_TRY
+    if (!version_ok(version, stream_size)) return Z_VERSION_ERROR;
+    if (!strm || !window || windowBits < 8 || windowBits > 15) return Z_STREAM_ERROR;
+    strm->msg = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (!abi_ctx()) { strm->msg = "no HIP device"; return Z_MEM_ERROR; }
+    }
+    InflateState* s = alloc_state<InflateState>(strm);
+    if (!s) return Z_MEM_ERROR;
+    s->wrap = ZMI_WRAP_RAW; s->wbits = windowBits; s->back_window = window;
+    strm->state = (internal_state*)s;
+    return Z_OK;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
+}
+int inflateBack(z_streamp strm, in_func in, void* in_desc, out_func out, void* out_desc) {
+    ZMI_ABI_TRY
+    InflateState* s = istate(strm);
+    if (!s || !s->back_window || !in || !out) return Z_STREAM_ERROR;
+    const uLong tin = strm->total_in, tout = strm->total_out;
+    inflate_reset_state(strm, s);
+    strm->total_in = tin; strm->total_out = tout;
+    s->mode = IM_BLOCKS; s->form = 0;
+    const size_t wsize = (size_t)1 << s->wbits;
+    const unsigned char* next = strm->next_in;
+    unsigned have = next ? strm->avail_in : 0;
+    size_t wpos = 0;
+    int ret = Z_OK;
+    if (have) { s->in.assign(next, next + have); next += have; }
+    unsigned chunk = have;
+    for (;;) {
+        if (s->in.empty() || s->tried == s->in.size()) {   // everything buffered has been tried: pull
+            have = in(in_desc, (unsigned char**)&next);
+            if (have == 0) { next = nullptr; ret = Z_BUF_ERROR; break; }
+            s->in.insert(s->in.end(), next, next + have);
+            next += have;
+            chunk = have;
+        }
+        const int rc = inflate_attempt(s);
+        if (rc != Z_OK) { ret = rc; break; }
+        bool stop = false;
+        while (s->out_pos < s->out.size()) {   // push through the caller's window, one window at a time
+            size_t n = s->out.size() - s->out_pos;
+            if (n > wsize - wpos) n = wsize - wpos;
+            memcpy(s->back_window + wpos, s->out.data() + s->out_pos, n);
+            s->out_pos += n;
+            wpos += n;
+            if (wpos == wsize) {
+                wpos = 0;
+                if (out(out_desc, s->back_window, (unsigned)wsize) != 0) { ret = Z_BUF_ERROR; stop = true; break; }
+            }
+        }
+        s->out.clear(); s->out_pos = 0;
+        if (stop) break;
+        if (s->mode == IM_TRAILER) { s->mode = IM_DONE; ret = Z_STREAM_END; break; }
+        if (s->mode == IM_BAD) { ret = Z_DATA_ERROR; strm->msg = s->errmsg; break; }
+    }
+    if (wpos != 0 && out(out_desc, s->back_window, (unsigned)wpos) != 0 && ret == Z_STREAM_END) ret = Z_BUF_ERROR;
+    unsigned unused = 0;
+    if (ret == Z_STREAM_END || (ret == Z_BUF_ERROR && next)) {   // what lies behind the end of the stream stays with the caller
+        unused = (unsigned)(s->in.size() < chunk ? s->in.size() : chunk);
+        if (ret != Z_STREAM_END) unused = 0;
+    }
+    strm->next_in = next ? (Bytef*)(next - unused) : nullptr;
+    strm->avail_in = next ? unused : 0;
+    return ret;
+    ZMI_ABI_CATCH(Z_MEM_ERROR)
+}
+int inflateBackEnd(z_streamp strm) {
+    InflateState* s = istate(strm);
+    if (!s || !s->back_window) return Z_STREAM_ERROR;
+    free_state(strm, s);
+    strm->state = nullptr;
+    return Z_OK;
+}
 
 int uncompress2_z(Bytef* dest, z_size_t* destLen, const Bytef* source, z_size_t* sourceLen) {
     ZMI_ABI_TRY
@@ -853,6 +1323,6 @@ uLong crc32_combine_gen(long len2) { return crc32_combine_gen64(len2); }
 uLong crc32_combine_op(uLong crc1, uLong crc2, uLong op) { return gf2_mul((uint32_t)op, (uint32_t)crc1) ^ (uint32_t)crc2; }
 uLong crc32_combine64(uLong crc1, uLong crc2, long long len2) { return crc32_combine_op(crc1, crc2, crc32_combine_gen64(len2)); }
 uLong crc32_combine(uLong crc1, uLong crc2, long len2) { return crc32_combine64(crc1, crc2, len2); }
-const uint32_t* get_crc_table(void) { std::call_once(g_crc_once, crc_init); return g_crc_table; }
+const uint32_t* get_crc_table(void) { std::call_once(g_crc_once, crc_init); return g_crc_table[0]; }
 
 }  // extern "C"

@@ -53,6 +53,7 @@ struct zmi_ctx {
     zmi_buf pieces;   // per shard x piece compressed length
     zmi_buf inf_tmp;  // in_used[n] check[n] adler[n] crc[n] bm_off[n] (u64)
     zmi_buf inf_bm;   // inflate: 1 bit per output byte of the batch (where back-references start)
+    zmi_buf st_in, st_out, st_meta;  // zmi_inflate_resume: staging of one host stream (kept across calls)
     uint64_t inflate_out_limit = 0;  // output bytes one inflate batch may cover; 0 = scratch_limit
 };
 
@@ -91,6 +92,9 @@ extern "C" int zmi_ctx_destroy(zmi_ctx* c) {
     if (c->pieces.p) (void)hipFree(c->pieces.p);
     if (c->inf_tmp.p) (void)hipFree(c->inf_tmp.p);
     if (c->inf_bm.p) (void)hipFree(c->inf_bm.p);
+    if (c->st_in.p) (void)hipFree(c->st_in.p);
+    if (c->st_out.p) (void)hipFree(c->st_out.p);
+    if (c->st_meta.p) (void)hipFree(c->st_meta.p);
     delete c;
     return ZMI_E_OK;
 }
@@ -370,10 +374,11 @@ extern "C" int zmi_inflate_batch_dev_ex(zmi_ctx* c, const void* d_in, const uint
 
 // d_out_hist (may be null): per stream, the number of bytes directly in front of its output region that hold a
 // preset dictionary (inflateSetDictionary, zlib-rs/src/inflate.rs:2492-2536; at most 32768 are ever referenced)
-extern "C" int zmi_inflate_batch_dict_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
-                                          uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off,
-                                          const uint32_t* d_out_cap, const uint32_t* d_out_hist, uint32_t* d_out_len,
-                                          int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail, void* stream_) {
+static int zmi_inflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                            uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off,
+                            const uint32_t* d_out_cap, const uint32_t* d_out_hist, uint32_t* d_out_len,
+                            int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail, const uint32_t* d_in_bit,
+                            uint32_t* d_resume, void* stream_) {
     if (!c) return zmi_fail(ZMI_E_ARG, "null context");
     if (wrap < ZMI_WRAP_RAW || wrap > ZMI_WRAP_AUTO) return zmi_fail(ZMI_E_ARG, "wrap must be raw/zlib/gzip/auto");
     if (n == 0) return ZMI_E_OK;
@@ -396,7 +401,8 @@ extern "C" int zmi_inflate_batch_dict_dev(zmi_ctx* c, const void* d_in, const ui
     {
         zmi_scope_timer tm(c, ZMI_K_INFLATE, stream);
         int lrc = zmi_launch_inflate((const uint8_t*)d_in, d_in_off, d_in_len, n, (uint32_t)wrap, (uint8_t*)d_out, d_out_off, d_out_cap,
-                                     d_out_len, d_used, d_check, d_status, (uint64_t*)c->inf_bm.p, bm_words, d_bm_off, d_out_hist, stream);
+                                     d_out_len, d_used, d_check, d_status, (uint64_t*)c->inf_bm.p, bm_words, d_bm_off, d_out_hist, d_in_bit, d_resume,
+                                     stream);
         if (lrc) return zmi_fail(ZMI_E_HIP, "inflate launch setup", (hipError_t)lrc);
     }
     {
@@ -416,6 +422,31 @@ extern "C" int zmi_inflate_batch_dict_dev(zmi_ctx* c, const void* d_in, const ui
     }
     ZMI_HIP(hipGetLastError());
     return ZMI_E_OK;
+}
+
+extern "C" int zmi_inflate_batch_dict_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                          uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off,
+                                          const uint32_t* d_out_cap, const uint32_t* d_out_hist, uint32_t* d_out_len,
+                                          int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail, void* stream_) {
+    return zmi_inflate_impl(c, d_in, d_in_off, d_in_len, n, wrap, d_out, d_out_off, d_out_cap, d_out_hist, d_out_len, d_status,
+                            d_in_used, d_detail, nullptr, nullptr, stream_);
+}
+
+// Resumable raw-deflate decode (the device half of a streaming inflate; the facts the reference keeps in
+// Mode / BitReader / Window, zlib-rs/src/inflate.rs:288-320, reduced to a block-boundary checkpoint).
+// Stream i starts at bit d_in_bit[i] (0..7; array may be NULL) of its first byte, with d_out_hist[i] bytes of
+// earlier output in front of its output region.  d_resume[4i..4i+3] = {byte, bit, output bytes, complete}: the
+// start of the block the decode stopped in (status Z_BUF_ERROR: more input or more room needed), or the first bit
+// behind the final block (complete = 1).  d_out_len[i] counts everything decoded, also the valid part of the
+// unfinished block; a later call that starts at the checkpoint reproduces those bytes and continues.
+extern "C" int zmi_inflate_resume_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                      const uint32_t* d_in_bit, uint32_t n, void* d_out, const uint64_t* d_out_off,
+                                      const uint32_t* d_out_cap, const uint32_t* d_out_hist, uint32_t* d_out_len,
+                                      int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail, uint32_t* d_resume,
+                                      void* stream_) {
+    if (!d_resume) return zmi_fail(ZMI_E_ARG, "d_resume is required");
+    return zmi_inflate_impl(c, d_in, d_in_off, d_in_len, n, ZMI_WRAP_RAW, d_out, d_out_off, d_out_cap, d_out_hist, d_out_len,
+                            d_status, d_in_used, d_detail, d_in_bit, d_resume, stream_);
 }
 
 extern "C" int zmi_inflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
@@ -521,5 +552,47 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     for (uint32_t i = 0; i < n; ++i)
         if (out_len[i] && out_len[i] <= out_cap[i])
             ZMI_HIP(hipMemcpy(out + out_off[i], d_out + dooff[i], out_len[i], hipMemcpyDeviceToHost));
+    return ZMI_E_OK;
+}
+
+// One host stream through zmi_inflate_resume_dev: `in` (raw deflate, starting at bit in_bit of its first byte),
+// `hist` = the up to 32 KiB of output in front of it.  The staging buffers belong to the context and are reused,
+// a streaming caller pays no allocation per call.  out receives min(*out_len, out_cap) bytes.
+extern "C" int zmi_inflate_resume(zmi_ctx* c, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist,
+                                  uint32_t hist_len, uint8_t* out, uint32_t out_cap, uint32_t* out_len, int32_t* status,
+                                  int32_t* detail, uint32_t* in_used, uint32_t* resume) {
+    if (!c || (!in && in_len) || (!hist && hist_len) || (!out && out_cap) || !out_len || !status || !detail || !in_used || !resume)
+        return zmi_fail(ZMI_E_ARG, "null argument");
+    if (in_len > 0xFFFFFF00u || out_cap > 0xFFFF0000u || in_bit > 7u) return zmi_fail(ZMI_E_ARG, "stream too large for one call");
+    ZMI_HIP(hipSetDevice(c->device));
+    if (hist_len > 32768u) { hist += hist_len - 32768u; hist_len = 32768u; }
+    const size_t base = ((size_t)hist_len + 1023u) & ~(size_t)1023u;   // the output region stays aligned; the history ends where it starts
+    int rc = zmi_reserve(c->st_in, (size_t)in_len + 64u);
+    if (!rc) rc = zmi_reserve(c->st_out, base + (size_t)out_cap + 64u);
+    if (!rc) rc = zmi_reserve(c->st_meta, 256u);
+    if (rc) return rc;
+    if (in_len) ZMI_HIP(hipMemcpy(c->st_in.p, in, in_len, hipMemcpyHostToDevice));
+    if (hist_len) ZMI_HIP(hipMemcpy((uint8_t*)c->st_out.p + base - hist_len, hist, hist_len, hipMemcpyHostToDevice));
+    // meta: in_off u64 | out_off u64 | in_len | out_cap | hist | in_bit || out_len | status | in_used | detail | resume[4]
+    struct { uint64_t in_off, out_off; uint32_t in_len, out_cap, hist, in_bit; } m = {0, (uint64_t)base, in_len, out_cap, hist_len, in_bit};
+    uint8_t* d = (uint8_t*)c->st_meta.p;
+    ZMI_HIP(hipMemcpy(d, &m, sizeof(m), hipMemcpyHostToDevice));
+    const uint64_t saved_limit = c->inflate_out_limit;
+    c->inflate_out_limit = (uint64_t)out_cap + (1ull << 16);
+    struct restore { zmi_ctx* c; uint64_t v; ~restore() { c->inflate_out_limit = v; } } restore_limit{c, saved_limit};
+    rc = zmi_inflate_resume_dev(c, c->st_in.p, (const uint64_t*)d, (const uint32_t*)(d + 16), (const uint32_t*)(d + 28), 1, c->st_out.p,
+                                (const uint64_t*)(d + 8), (const uint32_t*)(d + 20), (const uint32_t*)(d + 24), (uint32_t*)(d + 32),
+                                (int32_t*)(d + 36), (uint32_t*)(d + 40), (int32_t*)(d + 44), (uint32_t*)(d + 48), nullptr);
+    if (rc) return rc;
+    ZMI_HIP(hipDeviceSynchronize());
+    uint32_t r[8];
+    ZMI_HIP(hipMemcpy(r, d + 32, sizeof(r), hipMemcpyDeviceToHost));
+    *out_len = r[0];
+    *status = (int32_t)r[1];
+    *in_used = r[2];
+    *detail = (int32_t)r[3];
+    for (int i = 0; i < 4; ++i) resume[i] = r[4 + i];
+    const uint32_t n = r[0] < out_cap ? r[0] : out_cap;
+    if (n) ZMI_HIP(hipMemcpy(out, (const uint8_t*)c->st_out.p + base, n, hipMemcpyDeviceToHost));
     return ZMI_E_OK;
 }
