@@ -272,6 +272,7 @@ def test_checksums(engine):
 
 def test_resumable_inflate_from_block_checkpoints():
     """zmi_inflate_resume through the C ABI on the MI355X: cut streams restart at the reported block boundary"""
+    import oracle_lib
     import resume_checks
     import zmi_ctypes
     eng = zmi_ctypes.Engine(zmi_ctypes.load_product())
