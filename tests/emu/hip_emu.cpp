@@ -10,6 +10,38 @@ dim3 blockDim, gridDim;
 
 static const size_t kStack = 256 * 1024;
 
+#ifdef EMU_FAST_SWITCH
+// save the callee-saved registers on the current stack, park its stack pointer in *save, continue on `load`
+extern "C" void emu_switch(void** save, void* load);
+asm(R"(
+.text
+.globl emu_switch
+.type emu_switch,@function
+emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size emu_switch, .-emu_switch
+)");
+#define EMU_TO_SCHED(f) emu_switch(&(f).sp, g.sched)
+#define EMU_TO_FIBER(f) emu_switch(&g.sched, (f).sp)
+#else
+#define EMU_TO_SCHED(f) swapcontext(&(f).ctx, &g.sched)
+#define EMU_TO_FIBER(f) swapcontext(&g.sched, &(f).ctx)
+#endif
+
 static void fiber_entry() {
     g.body();
     Fiber& f = g.fibers[g.cur];
@@ -21,14 +53,15 @@ static void fiber_entry() {
     // if the peers were only waiting for this lane, release them
     if (w.live > 0 && w.arrived == w.live) { w.arrived = 0; w.gen++; }
     if (g.live_threads > 0 && g.bar_arrived == g.live_threads) { g.bar_arrived = 0; g.bar_gen++; }
-    swapcontext(&f.ctx, &g.sched);
+    EMU_TO_SCHED(f);
+    abort();   // a finished fiber is never resumed
 }
 
 void yield_wait(volatile int* var, int val) {
     Fiber& f = g.fibers[g.cur];
     f.wait_var = var;
     f.wait_val = val;
-    swapcontext(&f.ctx, &g.sched);
+    EMU_TO_SCHED(f);
     // resumed: restore ids (scheduler sets them)
 }
 
@@ -54,11 +87,21 @@ static void run_block(dim3 block, unsigned bx, size_t shmem) {
         f.tid = t;
         f.stack = stacks[t];
         g.waves[t >> 6].live++;
+#ifdef EMU_FAST_SWITCH
+        // first switch "returns" into fiber_entry: six zeroed callee-saved slots, the entry address in a 16-byte
+        // aligned slot (so the function starts with the stack alignment of a normal call), a null return address
+        void** top = (void**)((char*)f.stack + kStack);
+        top[-1] = nullptr;
+        top[-2] = (void*)fiber_entry;
+        for (int k = 3; k <= 8; ++k) top[-k] = nullptr;
+        f.sp = (void*)(top - 8);
+#else
         getcontext(&f.ctx);
         f.ctx.uc_stack.ss_sp = f.stack;
         f.ctx.uc_stack.ss_size = kStack;
         f.ctx.uc_link = nullptr;
         makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+#endif
     }
     blockIdx.x = bx; blockIdx.y = 0; blockIdx.z = 0;
     unsigned remaining = n;
@@ -77,7 +120,7 @@ static void run_block(dim3 block, unsigned bx, size_t shmem) {
             g.cur = t;
             threadIdx.x = t; threadIdx.y = 0; threadIdx.z = 0;
             g.last_yield_was_spin = false;
-            swapcontext(&g.sched, &f.ctx);
+            EMU_TO_FIBER(f);
             progressed = true;
             if (!g.last_yield_was_spin) real_progress = true;
             if (f.done) remaining--;

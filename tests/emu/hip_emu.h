@@ -12,7 +12,13 @@
 // is 64 as on CDNA4.  Cross-lane operations must be reached by every live lane of the wave
 // (wave-uniform control flow) -- the kernels are written that way.
 #pragma once
+// fiber switch: on x86-64 a dozen instructions of our own (callee-saved registers + stack pointer); glibc's
+// swapcontext makes a signal-mask system call per switch, which was half of the CPU test suite's run time
+#if defined(__x86_64__) && !defined(EMU_UCONTEXT)
+#define EMU_FAST_SWITCH 1
+#else
 #include <ucontext.h>
+#endif
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -29,7 +35,11 @@ struct uint3_emu { unsigned x, y, z; };
 
 namespace emu {
 struct Fiber {
+#ifdef EMU_FAST_SWITCH
+    void* sp = nullptr;
+#else
     ucontext_t ctx;
+#endif
     void* stack = nullptr;
     bool done = false;
     volatile int* wait_var = nullptr;
@@ -44,7 +54,11 @@ struct WaveSync {
     uint64_t pred[2];
 };
 struct State {
+#ifdef EMU_FAST_SWITCH
+    void* sched = nullptr;
+#else
     ucontext_t sched;
+#endif
     std::vector<Fiber> fibers;
     std::vector<WaveSync> waves;
     int bar_arrived = 0;
