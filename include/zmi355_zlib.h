@@ -34,7 +34,8 @@
  * 00 00 FF FF), which keeps the stream valid.  inflatePrime is accepted while no undecoded input is buffered (right
  * after init / reset or at a block boundary: the documented uses).  inflateSync, inflateSyncPoint, inflateMark,
  * inflateValidate, inflateUndermine, inflateBack* follow the reference; inflateCodesUsed reports 0 (the decode tables
- * live on the device).  Not exported: the gz* file API ("next").
+ * live on the device).
+ * The gz* file API (csrc/gz_api.hip) is host code around these entry points.
  */
 #ifndef ZMI355_ZLIB_H
 #define ZMI355_ZLIB_H
@@ -177,6 +178,50 @@ typedef int (*out_func)(void* desc, unsigned char* buf, unsigned len);          
 int inflateBackInit_(z_streamp strm, int windowBits, unsigned char* window, const char* version, int stream_size); /* lib.rs:697 */
 int inflateBack(z_streamp strm, in_func in, void* in_desc, out_func out, void* out_desc); /* lib.rs:741 */
 int inflateBackEnd(z_streamp strm);                                                      /* lib.rs:780 */
+
+/* ---- gz* file API (libz-rs-sys/src/gz.rs): gzip files through the stream ABI above; the reader accepts
+ * concatenated members (gz.rs:931-932, 1464-1506) and passes non-gzip files through unchanged ---- */
+#include <stdarg.h>
+typedef void* voidp;
+typedef const void* voidpc;
+struct gzFile_s {            /* public part of the handle, read by zlib.h's gzgetc() macro (gz.rs:27-41) */
+    unsigned have;
+    unsigned char* next;
+    long long pos;
+};
+typedef struct gzFile_s* gzFile;
+gzFile gzopen(const char* path, const char* mode);                                       /* gz.rs:230 */
+gzFile gzopen64(const char* path, const char* mode);                                     /* gz.rs:208 */
+gzFile gzdopen(int fd, const char* mode);                                                /* gz.rs:258 */
+int gzbuffer(gzFile file, unsigned size);                                                /* gz.rs:738 */
+int gzsetparams(gzFile file, int level, int strategy);                                   /* gz.rs:2467 */
+int gzread(gzFile file, voidp buf, unsigned len);                                        /* gz.rs:969 */
+z_size_t gzfread(voidp buf, z_size_t size, z_size_t nitems, gzFile file);                /* gz.rs:1029 */
+int gzwrite(gzFile file, voidpc buf, unsigned len);                                      /* gz.rs:1537 */
+z_size_t gzfwrite(voidpc buf, z_size_t size, z_size_t nitems, gzFile file);              /* gz.rs:1586 */
+int gzprintf(gzFile file, const char* format, ...);                                      /* gz.rs:2707 */
+int gzvprintf(gzFile file, const char* format, va_list va);                              /* gz.rs:2729 */
+int gzputs(gzFile file, const char* s);                                                  /* gz.rs:2137 */
+char* gzgets(gzFile file, char* buf, int len);                                           /* gz.rs:2356 */
+int gzputc(gzFile file, int c);                                                          /* gz.rs:2079 */
+int gzgetc(gzFile file);                                                                 /* gz.rs:2179 */
+int gzgetc_(gzFile file);                                                                /* gz.rs:2223 */
+int gzungetc(int c, gzFile file);                                                        /* gz.rs:2247 */
+int gzflush(gzFile file, int flush);                                                     /* gz.rs:1928 */
+long gzseek(gzFile file, long offset, int whence);                                       /* gz.rs:2650 */
+long long gzseek64(gzFile file, long long offset, int whence);                           /* gz.rs:2530 */
+int gzrewind(gzFile file);                                                               /* gz.rs:2667 */
+long gztell(gzFile file);                                                                /* gz.rs:2004 */
+long long gztell64(gzFile file);                                                         /* gz.rs:1971 */
+long gzoffset(gzFile file);                                                              /* gz.rs:2064 */
+long long gzoffset64(gzFile file);                                                       /* gz.rs:2024 */
+int gzeof(gzFile file);                                                                  /* gz.rs:870 */
+int gzdirect(gzFile file);                                                               /* gz.rs:910 */
+int gzclose(gzFile file);                                                                /* gz.rs:600 */
+int gzclose_r(gzFile file);                                                              /* gz.rs:627 */
+int gzclose_w(gzFile file);                                                              /* gz.rs:676 */
+const char* gzerror(gzFile file, int* errnum);                                           /* gz.rs:797 */
+void gzclearerr(gzFile file);                                                            /* gz.rs:833 */
 
 int compress(Bytef* dest, uLongf* destLen, const Bytef* source, uLong sourceLen);        /* lib.rs:1447 */
 int compress2(Bytef* dest, uLongf* destLen, const Bytef* source, uLong sourceLen, int level); /* lib.rs:1529 */

@@ -72,3 +72,10 @@ def test_streaming_entry_points():
     lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
     o = oracle_lib.load()
     H.streaming_checks(lib, o.gen_shard(0, 40000) + o.gen_shard(3, 30000), syslib=C.CDLL("libz.so.1"))
+
+
+def test_gz_file_api(tmp_path):
+    """gzopen ... gzclose against Python's gzip module and the system's libz (libz-rs-sys/src/gz.rs)"""
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    H.gz_checks(lib, tmp_path, oracle_lib.load().gen_shard(1, 60000), syslib=C.CDLL("libz.so.1"))

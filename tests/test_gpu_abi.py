@@ -82,3 +82,10 @@ def test_streaming_inflate_large_in_small_chunks_on_gpu():
         comp = co.compress(data) + co.flush()
         rc, out, unused = H.inflate_stream(lib, comp + b"tail", wbits=wbits, chunk_in=1 << 16, chunk_out=1 << 18)
         assert rc == H.Z_STREAM_END and out == data and unused == 4
+
+
+def test_gz_file_api_on_gpu(tmp_path):
+    """gzopen ... gzclose (libz-rs-sys/src/gz.rs) against Python's gzip module and the system's libz, 3 MiB members"""
+    from zlib_rs_amd import _build
+    lib = H.bind(C.CDLL(_build.ABI_LIB))
+    H.gz_checks(lib, tmp_path, oracle_lib.load(rebuild=False).gen_shard(1, 3 << 20), syslib=C.CDLL("libz.so.1"))

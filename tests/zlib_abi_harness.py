@@ -584,3 +584,179 @@ def streaming_checks(lib, data, syslib=None):
     rc = lib.inflateBack(C.byref(strm), IN_FUNC(pull), None, OUT_FUNC(lambda d, b, n: 1), None)
     assert rc == Z_BUF_ERROR and strm.next_in
     assert lib.inflateBackEnd(C.byref(strm)) == Z_OK
+
+
+def _bind_gz(lib):
+    vp = C.c_void_p
+    lib.gzopen.restype = vp
+    lib.gzopen.argtypes = [C.c_char_p, C.c_char_p]
+    lib.gzdopen.restype = vp
+    lib.gzdopen.argtypes = [C.c_int, C.c_char_p]
+    lib.gzbuffer.argtypes = [vp, C.c_uint]
+    lib.gzread.argtypes = [vp, vp, C.c_uint]
+    lib.gzwrite.argtypes = [vp, vp, C.c_uint]
+    lib.gzfread.restype = C.c_size_t
+    lib.gzfread.argtypes = [vp, C.c_size_t, C.c_size_t, vp]
+    lib.gzfwrite.restype = C.c_size_t
+    lib.gzfwrite.argtypes = [vp, C.c_size_t, C.c_size_t, vp]
+    lib.gzputs.argtypes = [vp, C.c_char_p]
+    lib.gzputc.argtypes = [vp, C.c_int]
+    lib.gzgetc.argtypes = [vp]
+    lib.gzungetc.argtypes = [C.c_int, vp]
+    lib.gzgets.restype = vp
+    lib.gzgets.argtypes = [vp, vp, C.c_int]
+    lib.gzprintf.argtypes = [vp, C.c_char_p]
+    lib.gzflush.argtypes = [vp, C.c_int]
+    lib.gzsetparams.argtypes = [vp, C.c_int, C.c_int]
+    lib.gzseek.restype = C.c_long
+    lib.gzseek.argtypes = [vp, C.c_long, C.c_int]
+    lib.gztell.restype = C.c_long
+    lib.gztell.argtypes = [vp]
+    lib.gzoffset.restype = C.c_long
+    lib.gzoffset.argtypes = [vp]
+    lib.gzrewind.argtypes = [vp]
+    lib.gzeof.argtypes = [vp]
+    lib.gzdirect.argtypes = [vp]
+    lib.gzclose.argtypes = [vp]
+    lib.gzclose_r.argtypes = [vp]
+    lib.gzclose_w.argtypes = [vp]
+    lib.gzerror.restype = C.c_char_p
+    lib.gzerror.argtypes = [vp, C.POINTER(C.c_int)]
+    lib.gzclearerr.argtypes = [vp]
+
+
+def _gz_read_all(lib, path, chunk=50000):
+    f = lib.gzopen(path.encode(), b"rb")
+    assert f
+    buf = C.create_string_buffer(chunk)
+    out = bytearray()
+    while True:
+        n = lib.gzread(f, buf, chunk)
+        assert n >= 0, lib.gzerror(f, None)
+        out += buf.raw[:n]
+        if n < chunk:
+            break
+    assert lib.gzeof(f) == 1
+    assert lib.gzclose(f) == Z_OK
+    return bytes(out)
+
+
+def gz_checks(lib, tmpdir, data, syslib=None):
+    """the gz* file API (libz-rs-sys/src/gz.rs) against Python's gzip module and, when given, the system's libz:
+    files written here are read there and the other way round; concatenated members, plain files, seeking, line and
+    character I/O, append, error reporting"""
+    import gzip
+    import os
+    _bind_gz(lib)
+    if syslib is not None:
+        _bind_gz(syslib)
+    p = lambda name: os.path.join(str(tmpdir), name)
+    text = b"".join(b"line %d of the test file\n" % i for i in range(3000))
+
+    # -- write here (one big write, small writes, puts / putc / printf, a flush in between), read with Python and libz
+    f = lib.gzopen(p("a.gz").encode(), b"wb6")
+    assert f and lib.gzdirect(f) == 0
+    src = C.create_string_buffer(data, len(data))
+    assert lib.gzwrite(f, src, len(data)) == len(data)
+    assert lib.gztell(f) == len(data)
+    for i in range(0, 3000, 7):
+        assert lib.gzwrite(f, C.addressof(src) + i, 7) == 7
+    assert lib.gzflush(f, Z_SYNC_FLUSH) == Z_OK
+    assert lib.gzputs(f, b"hello, ") == 7 and lib.gzputc(f, ord("w")) == ord("w")
+    assert lib.gzprintf(f, b"orld %d %s\n", 42, b"ok") == 11
+    assert lib.gzfwrite(src, 10, 5, f) == 5
+    assert lib.gzread(f, src, 1) == -1                       # a write handle does not read
+    assert lib.gzclose(f) == Z_OK
+    small = b"".join(data[i:i + 7] for i in range(0, 3000, 7))
+    expect = data + small + b"hello, world 42 ok\n" + data[:50]
+    assert gzip.open(p("a.gz"), "rb").read() == expect
+    assert _gz_read_all(lib, p("a.gz")) == expect
+    if syslib is not None:
+        assert _gz_read_all(syslib, p("a.gz")) == expect
+
+    # -- read files made elsewhere: several members (two writers + append here), then junk that is not gzip
+    with open(p("b.gz"), "wb") as fh:
+        fh.write(gzip.compress(data[:40000], 6))
+        fh.write(gzip.compress(text, 1))
+    f = lib.gzopen(p("b.gz").encode(), b"ab9")               # append: a third member
+    assert f and lib.gzwrite(f, src, 1234) == 1234 and lib.gzclose_w(f) == Z_OK
+    with open(p("b.gz"), "ab") as fh:
+        fh.write(b"\x00\x00 trailing junk that is no gzip member")
+    whole = data[:40000] + text + data[:1234]
+    assert _gz_read_all(lib, p("b.gz"), chunk=777) == whole
+    assert _gz_read_all(lib, p("b.gz"), chunk=1 << 20) == whole       # large requests decode into the caller's buffer
+    assert gzip.open(p("b.gz"), "rb").read(len(whole)) == whole
+
+    # -- lines, characters, push-back, positions
+    f = lib.gzopen(p("b.gz").encode(), b"r")
+    assert lib.gzbuffer(f, 4096) == 0
+    assert lib.gzseek(f, 40000, 0) == 40000 and lib.gztell(f) == 40000
+    line = C.create_string_buffer(100)
+    assert lib.gzgets(f, line, 100) and line.value == b"line 0 of the test file\n"
+    assert lib.gzbuffer(f, 8192) == -1                       # too late
+    assert lib.gzgets(f, line, 10) and line.value == b"line 1 of"      # len - 1 characters
+    assert lib.gzgetc(f) == ord(" ")
+    assert lib.gzungetc(ord("#"), f) == ord("#") and lib.gzungetc(ord("!"), f) == ord("!")
+    assert lib.gzgets(f, line, 100) and line.value == b"!#the test file\n"
+    at = lib.gztell(f)
+    assert at == 40000 + 2 * len(b"line 0 of the test file\n")
+    assert lib.gzseek(f, -20, 1) == at - 20                  # backwards: rewind and skip
+    got = C.create_string_buffer(20)
+    assert lib.gzread(f, got, 20) == 20 and got.raw == whole[at - 20:at]
+    assert lib.gzseek(f, 0, 2) == -1                         # SEEK_END is not supported (gz.rs:2530)
+    assert 0 < lib.gzoffset(f) <= os.path.getsize(p("b.gz"))
+    assert lib.gzrewind(f) == 0 and lib.gztell(f) == 0 and lib.gzgetc(f) == data[0]
+    assert lib.gzfread(got, 4, 5, f) == 5 and got.raw == whole[1:21]
+    assert lib.gzeof(f) == 0
+    assert lib.gzclose_r(f) == Z_OK
+
+    # -- a plain file is passed through (and can really seek); "T" writes one
+    f = lib.gzopen(p("plain.txt").encode(), b"wT")
+    assert f and lib.gzdirect(f) == 1
+    tsrc = C.create_string_buffer(text, len(text))
+    assert lib.gzwrite(f, tsrc, len(text)) == len(text) and lib.gzclose(f) == Z_OK
+    assert open(p("plain.txt"), "rb").read() == text
+    f = lib.gzopen(p("plain.txt").encode(), b"r")
+    assert lib.gzdirect(f) == 1
+    assert lib.gzseek(f, 5000, 0) == 5000
+    assert lib.gzread(f, got, 20) == 20 and got.raw == text[5000:5020]
+    assert lib.gzclose(f) == Z_OK
+    assert _gz_read_all(lib, p("plain.txt")) == text
+
+    # -- writing with a seek (zeros), changed parameters, an fd handle; read back by Python
+    fd = os.open(p("c.gz"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+    f = lib.gzdopen(fd, b"w1")
+    assert f and lib.gzwrite(f, src, 1000) == 1000
+    assert lib.gzsetparams(f, 9, 1) == Z_OK
+    assert lib.gzseek(f, -1, 1) == -1                        # forward only
+    assert lib.gzseek(f, 500, 1) == 1500                     # 500 zero bytes
+    assert lib.gzwrite(f, src, 1000) == 1000 and lib.gztell(f) == 2500
+    assert lib.gzclose(f) == Z_OK
+    assert gzip.open(p("c.gz"), "rb").read() == data[:1000] + bytes(500) + data[:1000]
+
+    # -- an empty file written and read; a missing file; a bad mode; a truncated file
+    f = lib.gzopen(p("empty.gz").encode(), b"w")
+    assert lib.gzclose(f) == Z_OK and gzip.open(p("empty.gz"), "rb").read() == b""
+    assert _gz_read_all(lib, p("empty.gz")) == b""
+    assert not lib.gzopen(p("nope.gz").encode(), b"r") and not lib.gzopen(p("x.gz").encode(), b"r+")
+    assert not lib.gzopen(p("x.gz").encode(), b"rT") and not lib.gzdopen(-1, b"r")
+    blob = open(p("a.gz"), "rb").read()
+    with open(p("cut.gz"), "wb") as fh:
+        fh.write(blob[:len(blob) // 2])
+    f = lib.gzopen(p("cut.gz").encode(), b"r")
+    big = C.create_string_buffer(len(expect) + 10)
+    n = lib.gzread(f, big, len(expect) + 10)
+    assert 0 < n < len(expect) and big.raw[:n] == expect[:n]
+    err = C.c_int(0)
+    msg = lib.gzerror(f, C.byref(err))
+    assert err.value == Z_BUF_ERROR and msg.endswith(b"unexpected end of file"), (err.value, msg)
+    lib.gzclearerr(f)
+    assert lib.gzerror(f, C.byref(err)) == b"" and err.value == Z_OK
+    assert lib.gzclose(f) in (Z_OK, Z_BUF_ERROR)
+    with open(p("bad.gz"), "wb") as fh:
+        fh.write(blob[:100] + bytes(200) + blob[300:])
+    f = lib.gzopen(p("bad.gz").encode(), b"r")
+    n = lib.gzread(f, big, len(expect))
+    msg = lib.gzerror(f, C.byref(err))
+    assert n == -1 or err.value == Z_DATA_ERROR, (n, err.value, msg)
+    assert lib.gzclose(f) == Z_OK
