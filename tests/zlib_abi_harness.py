@@ -625,9 +625,11 @@ def _bind_gz(lib):
     lib.gzclearerr.argtypes = [vp]
 
 
-def _gz_read_all(lib, path, chunk=50000):
+def _gz_read_all(lib, path, chunk=50000, bufsize=None):
     f = lib.gzopen(path.encode(), b"rb")
     assert f
+    if bufsize:
+        assert lib.gzbuffer(f, bufsize) == 0
     buf = C.create_string_buffer(chunk)
     out = bytearray()
     while True:
@@ -671,6 +673,7 @@ def gz_checks(lib, tmpdir, data, syslib=None):
     expect = data + small + b"hello, world 42 ok\n" + data[:50]
     assert gzip.open(p("a.gz"), "rb").read() == expect
     assert _gz_read_all(lib, p("a.gz")) == expect
+    assert _gz_read_all(lib, p("a.gz"), chunk=1000, bufsize=512) == expect     # far more output than the buffer holds
     if syslib is not None:
         assert _gz_read_all(syslib, p("a.gz")) == expect
 

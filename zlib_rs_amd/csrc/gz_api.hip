@@ -195,18 +195,24 @@ int gz_decomp(GzState* s) {   // gz.rs:1456-1509: inflate into strm.next_out unt
     const unsigned had = s->strm.avail_out;
     for (;;) {
         if (s->strm.avail_in == 0 && gz_avail(s) == -1) return -1;
-        if (s->strm.avail_in == 0) { gz_error(s, Z_BUF_ERROR, "unexpected end of file"); break; }
+        // this library's inflate() takes all input at once and hands the decoded bytes out over the following calls:
+        // no input left does not mean nothing to get.  Only a call that has no input AND yields nothing is the end.
+        const bool starved = s->strm.avail_in == 0;
         const int rc = inflate(&s->strm, Z_NO_FLUSH);
         if (rc == Z_STREAM_ERROR || rc == Z_NEED_DICT) { gz_error(s, Z_STREAM_ERROR, "internal error: inflate stream corrupt"); return -1; }
         if (rc == Z_MEM_ERROR) { gz_error(s, Z_MEM_ERROR, "out of memory"); return -1; }
         if (rc == Z_DATA_ERROR) { gz_error(s, Z_DATA_ERROR, s->strm.msg ? s->strm.msg : "compressed data error"); return -1; }
         if (rc == Z_STREAM_END) { s->how = LOOK; break; }
+        if (rc == Z_BUF_ERROR && starved) { gz_error(s, Z_BUF_ERROR, "unexpected end of file"); break; }
         if (s->strm.avail_out == 0) break;
     }
     s->have = had - s->strm.avail_out;
     s->next = s->strm.next_out - s->have;
     return 0;
 }
+// nothing more can come: the file is at its end, inflate() has taken all of it, and no member is open that could still
+// have decoded bytes queued (an open member that yields nothing any more has been reported as truncated: Z_BUF_ERROR)
+bool gz_drained(const GzState* s) { return s->eof && s->strm.avail_in == 0 && (s->how != GZIP || s->err == Z_BUF_ERROR); }
 int gz_fetch(GzState* s) {   // something into the output buffer
     do {
         if (s->how == LOOK) {
@@ -229,7 +235,7 @@ int gz_fetch(GzState* s) {   // something into the output buffer
             s->strm.next_out = s->out.data();
             if (gz_decomp(s) == -1) return -1;
         }
-    } while (s->have == 0 && (!s->eof || s->strm.avail_in));
+    } while (s->have == 0 && !gz_drained(s));
     return 0;
 }
 int gz_skip(GzState* s, int64_t len) {
@@ -237,7 +243,7 @@ int gz_skip(GzState* s, int64_t len) {
         if (s->have) {
             const unsigned n = (int64_t)s->have > len ? (unsigned)len : s->have;
             s->have -= n; s->next += n; s->pos += n; len -= n;
-        } else if (s->eof && s->strm.avail_in == 0) break;
+        } else if (gz_drained(s)) break;
         else if (gz_fetch(s) == -1) return -1;
     }
     return 0;
@@ -253,7 +259,7 @@ size_t gz_read(GzState* s, unsigned char* buf, size_t len) {   // gz.rs gz_read
             memcpy(buf, s->next, n);
             s->next += n;
             s->have -= n;
-        } else if (s->eof && s->strm.avail_in == 0) {
+        } else if (gz_drained(s)) {
             s->past = true;
             break;
         } else if (s->how == LOOK || n < (s->size << 1)) {
