@@ -493,8 +493,13 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     uint32_t* d_olen = (uint32_t*)A.get((size_t)n * 4);
     int32_t* d_st = (int32_t*)A.get((size_t)n * 4);
     if (!d_in || !d_off || !d_len || !d_out || !d_olen || !d_st) return zmi_fail(ZMI_E_NOMEM, "hipMalloc(batch buffers)");
-    for (uint32_t i = 0; i < n; ++i)
-        if (in_len[i]) ZMI_HIP(hipMemcpy(d_in + doff[i], in + in_off[i], in_len[i], hipMemcpyHostToDevice));
+    for (uint32_t i = 0; i < n;) {   // shards that lie back to back on both sides travel in one copy
+        uint32_t j = i;
+        uint64_t bytes = in_len[i];
+        while (j + 1 < n && in_off[j + 1] == in_off[j] + in_len[j] && doff[j + 1] == doff[j] + in_len[j] && bytes < (1ull << 30)) bytes += in_len[++j];
+        if (bytes) ZMI_HIP(hipMemcpy(d_in + doff[i], in + in_off[i], bytes, hipMemcpyHostToDevice));
+        i = j + 1;
+    }
     ZMI_HIP(hipMemcpy(d_off, doff.data(), (size_t)n * 8, hipMemcpyHostToDevice));
     ZMI_HIP(hipMemcpy(d_len, in_len, (size_t)n * 4, hipMemcpyHostToDevice));
     int rc = zmi_deflate_batch_dev(c, d_in, d_off, d_len, n, max_len, level, strategy, wrap, d_out, out_stride, d_olen, d_st,
@@ -549,9 +554,16 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     ZMI_HIP(hipDeviceSynchronize());
     ZMI_HIP(hipMemcpy(out_len, d_olen, (size_t)n * 4, hipMemcpyDeviceToHost));
     ZMI_HIP(hipMemcpy(status, d_st, (size_t)n * 4, hipMemcpyDeviceToHost));
-    for (uint32_t i = 0; i < n; ++i)
-        if (out_len[i] && out_len[i] <= out_cap[i])
-            ZMI_HIP(hipMemcpy(out + out_off[i], d_out + dooff[i], out_len[i], hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n;) {   // outputs that lie back to back on both sides travel in one copy
+        if (out_len[i] == 0 || out_len[i] > out_cap[i]) { ++i; continue; }
+        uint32_t j = i;
+        uint64_t bytes = out_len[i];
+        while (j + 1 < n && out_len[j + 1] && out_len[j + 1] <= out_cap[j + 1] && out_off[j + 1] == out_off[j] + out_len[j] &&
+               dooff[j + 1] == dooff[j] + out_len[j] && bytes < (1ull << 30))
+            bytes += out_len[++j];
+        ZMI_HIP(hipMemcpy(out + out_off[i], d_out + dooff[i], bytes, hipMemcpyDeviceToHost));
+        i = j + 1;
+    }
     return ZMI_E_OK;
 }
 
