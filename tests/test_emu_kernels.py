@@ -173,3 +173,41 @@ def test_resumable_inflate_from_block_checkpoints():
         resume_checks.resume_chain_checks(eng, oracle_lib.load(), sizes=(60000, 40000, 20000, 20000), trials=2)
     finally:
         eng.close()
+
+
+def test_host_batch_pipeline_chunks(monkeypatch):
+    """zmi_deflate_batch cuts a host batch into chunks that cycle through two device slots (copy-in / kernels /
+    copy-out on three streams): same bytes as the one-chunk path, every shard in its own slot of the output"""
+    import random
+    o = oracle_lib.load()
+    rnd = random.Random(11)
+    shards = [o.gen_shard(i % 8, rnd.choice([0, 1, 15, 16, 17, 1000, 4096, 9999, 20000])) for i in range(37)]
+    monkeypatch.delenv("ZMI_HOST_CHUNK", raising=False)
+    eng = zmi_ctypes.Engine(zmi_ctypes.load_emu())
+    try:
+        one, st1 = eng.deflate(shards, level=6, wrap=1)
+        for budget in ("30000", "20016", "1"):          # several shards per chunk ... one shard per chunk
+            monkeypatch.setenv("ZMI_HOST_CHUNK", budget)
+            many, st2 = eng.deflate(shards, level=6, wrap=1)
+            assert st1 == st2 == [0] * len(shards)
+            assert many == one
+        assert [zlib.decompress(x) for x in one] == shards
+        # and back: capacities that pack like the device slot (multiples of 16: one copy per chunk) and ragged ones
+        monkeypatch.delenv("ZMI_HOST_CHUNK", raising=False)
+        for caps in ([(len(x) + 15) & ~15 for x in shards], [len(x) + 3 for x in shards]):
+            ref, rst = eng.inflate(one, caps, wrap=1)
+            assert ref == shards and rst == [0] * len(shards)
+            for budget in ("30000", "1"):
+                monkeypatch.setenv("ZMI_HOST_CHUNK", budget)
+                got, gst = eng.inflate(one, caps, wrap=1)
+                assert got == shards and gst == rst
+            monkeypatch.delenv("ZMI_HOST_CHUNK", raising=False)
+        # a stream that fails in the middle of a chunk keeps its own status; its neighbours are untouched
+        hurt = list(one)
+        hurt[5] = hurt[5][:len(hurt[5]) // 2]
+        monkeypatch.setenv("ZMI_HOST_CHUNK", "30000")
+        got, gst = eng.inflate(hurt, [len(x) + 16 for x in shards], wrap=1)
+        assert gst[5] != 0 and all(v == 0 for i, v in enumerate(gst) if i != 5)
+        assert all(got[i] == shards[i] for i in range(len(shards)) if i != 5)
+    finally:
+        eng.close()

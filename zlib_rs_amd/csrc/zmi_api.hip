@@ -54,6 +54,10 @@ struct zmi_ctx {
     zmi_buf inf_tmp;  // in_used[n] check[n] adler[n] crc[n] bm_off[n] (u64)
     zmi_buf inf_bm;   // inflate: 1 bit per output byte of the batch (where back-references start)
     zmi_buf st_in, st_out, st_meta;  // zmi_inflate_resume: staging of one host stream (kept across calls)
+    // host-buffer batches (zmi_deflate_batch): two slots cycle through copy-in / kernels / copy-out on three streams
+    struct hb_slot { zmi_buf in, out, meta; hipEvent_t in_done, k_done, out_done; } hb[2];
+    hipStream_t hs_in = nullptr, hs_k = nullptr, hs_out = nullptr;
+    bool hb_live = false;
     uint64_t inflate_out_limit = 0;  // output bytes one inflate batch may cover; 0 = scratch_limit
 };
 
@@ -95,6 +99,15 @@ extern "C" int zmi_ctx_destroy(zmi_ctx* c) {
     if (c->st_in.p) (void)hipFree(c->st_in.p);
     if (c->st_out.p) (void)hipFree(c->st_out.p);
     if (c->st_meta.p) (void)hipFree(c->st_meta.p);
+    if (c->hb_live) {
+        for (auto& sl : c->hb) {
+            if (sl.in.p) (void)hipFree(sl.in.p);
+            if (sl.out.p) (void)hipFree(sl.out.p);
+            if (sl.meta.p) (void)hipFree(sl.meta.p);
+            (void)hipEventDestroy(sl.in_done); (void)hipEventDestroy(sl.k_done); (void)hipEventDestroy(sl.out_done);
+        }
+        (void)hipStreamDestroy(c->hs_in); (void)hipStreamDestroy(c->hs_k); (void)hipStreamDestroy(c->hs_out);
+    }
     delete c;
     return ZMI_E_OK;
 }
@@ -457,6 +470,19 @@ extern "C" int zmi_inflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_
 }
 
 // ---------------- host-buffer wrappers ----------------
+static int zmi_host_pipeline_init(zmi_ctx* c) {   // three streams (in / kernels / out) and the events of the two slots
+    if (c->hb_live) return 0;
+    ZMI_HIP(hipStreamCreateWithFlags(&c->hs_in, hipStreamNonBlocking));
+    ZMI_HIP(hipStreamCreateWithFlags(&c->hs_k, hipStreamNonBlocking));
+    ZMI_HIP(hipStreamCreateWithFlags(&c->hs_out, hipStreamNonBlocking));
+    for (auto& sl : c->hb) {
+        ZMI_HIP(hipEventCreateWithFlags(&sl.in_done, hipEventDisableTiming));
+        ZMI_HIP(hipEventCreateWithFlags(&sl.k_done, hipEventDisableTiming));
+        ZMI_HIP(hipEventCreateWithFlags(&sl.out_done, hipEventDisableTiming));
+    }
+    c->hb_live = true;
+    return 0;
+}
 struct zmi_dev_alloc {
     std::vector<void*> ptrs;
     ~zmi_dev_alloc() { for (void* p : ptrs) (void)hipFree(p); }
@@ -468,7 +494,7 @@ struct zmi_dev_alloc {
     }
 };
 
-extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
+static int zmi_deflate_batch_simple(zmi_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
                                  int level, int strategy, int wrap, uint8_t* out, uint64_t out_stride, uint32_t* out_len,
                                  int32_t* status) {
     if (!c || (!in && n) || !in_off || !in_len || !out || !out_len || !status) return zmi_fail(ZMI_E_ARG, "null argument");
@@ -514,7 +540,123 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     return ZMI_E_OK;
 }
 
-extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
+
+// Host buffers, pipelined.  The batch is cut into chunks of consecutive shards; chunk k is copied in on one stream,
+// compressed on a second and copied out on a third, with two device slots: while chunk k is being compressed, chunk
+// k+1 arrives and chunk k-1 leaves (PCIe is full duplex).  A chunk's compressed streams keep their out_stride layout and
+// leave in ONE copy of the whole slot -- as many bytes as came in, instead of a length round trip and a copy per shard.
+// Issue order per iteration is in(k), kernels(k), out(k-1): also with pageable host memory, where the "async" copies
+// hold the calling thread, the copy of one chunk runs beside the kernels of another.
+extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
+                                 int level, int strategy, int wrap, uint8_t* out, uint64_t out_stride, uint32_t* out_len,
+                                 int32_t* status) {
+    if (!c || (!in && n) || !in_off || !in_len || !out || !out_len || !status) return zmi_fail(ZMI_E_ARG, "null argument");
+    if (n == 0) return ZMI_E_OK;
+    uint64_t total = 0;
+    uint32_t max_len = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        total += ((uint64_t)in_len[i] + 15u) & ~15ull;
+        if (in_len[i] > max_len) max_len = in_len[i];
+    }
+    if (out_stride % 16u || out_stride < zmi_deflate_bound(max_len, wrap))
+        return zmi_fail(ZMI_E_ARG, "out_stride must be a multiple of 16 and >= zmi_deflate_bound(max_len)");
+    uint64_t budget = total / 8u;   // at least eight chunks in flight before the pipeline pays ...
+    if (budget > (128ull << 20)) budget = 128ull << 20;
+    if (budget < (16ull << 20)) budget = 16ull << 20;   // ... and no chunk so small that launches dominate
+    if (const char* e = getenv("ZMI_HOST_CHUNK")) { if (atoll(e) > 0) budget = (uint64_t)atoll(e); }
+    struct chunk { uint32_t first, count; uint64_t bytes; std::vector<uint64_t> doff; };
+    std::vector<chunk> chunks;
+    for (uint32_t i = 0; i < n;) {
+        chunk ck{i, 0, 0, {}};
+        while (i < n) {
+            const uint64_t a = ((uint64_t)in_len[i] + 15u) & ~15ull;
+            if (ck.count && ck.bytes + a > budget) break;
+            ck.doff.push_back(ck.bytes);
+            ck.bytes += a;
+            ++ck.count;
+            ++i;
+        }
+        chunks.push_back(std::move(ck));
+    }
+    const char* pl = getenv("ZMI_HOST_PIPELINE");   // 0: the plain copy-in / kernels / copy-out sequence
+    if (chunks.size() < 2 || (pl && !atoi(pl)))
+        return zmi_deflate_batch_simple(c, in, in_off, in_len, n, level, strategy, wrap, out, out_stride, out_len, status);
+    ZMI_HIP(hipSetDevice(c->device));
+    {
+        int irc = zmi_host_pipeline_init(c);
+        if (irc) return irc;
+    }
+    uint64_t max_bytes = 0;
+    uint32_t max_count = 0;
+    for (const chunk& ck : chunks) { if (ck.bytes > max_bytes) max_bytes = ck.bytes; if (ck.count > max_count) max_count = ck.count; }
+    for (auto& sl : c->hb) {
+        int rc = zmi_reserve(sl.in, (size_t)max_bytes + 64u);
+        if (!rc) rc = zmi_reserve(sl.out, (size_t)max_count * out_stride + 64u);
+        if (!rc) rc = zmi_reserve(sl.meta, (size_t)max_count * 24u);   // off u64 | len u32 | out_len u32 | status i32
+        if (rc) return rc;
+    }
+    const size_t K = chunks.size();
+    auto meta_off = [&](zmi_ctx::hb_slot& sl) { return (uint64_t*)sl.meta.p; };
+    auto meta_len = [&](zmi_ctx::hb_slot& sl) { return (uint32_t*)((uint8_t*)sl.meta.p + (size_t)max_count * 8u); };
+    auto meta_olen = [&](zmi_ctx::hb_slot& sl) { return (uint32_t*)((uint8_t*)sl.meta.p + (size_t)max_count * 12u); };
+    auto meta_st = [&](zmi_ctx::hb_slot& sl) { return (int32_t*)((uint8_t*)sl.meta.p + (size_t)max_count * 16u); };
+    auto issue_in = [&](size_t k) -> int {
+        chunk& ck = chunks[k];
+        zmi_ctx::hb_slot& sl = c->hb[k & 1u];
+        if (k >= 2) ZMI_HIP(hipStreamWaitEvent(c->hs_in, sl.k_done, 0));   // the kernels of chunk k-2 have read this slot
+        for (uint32_t i = 0; i < ck.count;) {   // shards that lie back to back on both sides travel in one copy
+            const uint32_t g = ck.first + i;
+            uint32_t j = i;
+            uint64_t bytes = in_len[g];
+            while (j + 1 < ck.count && in_off[ck.first + j + 1] == in_off[ck.first + j] + in_len[ck.first + j] &&
+                   ck.doff[j + 1] == ck.doff[j] + in_len[ck.first + j] && bytes < (1ull << 30))
+                bytes += in_len[ck.first + ++j];
+            if (bytes) ZMI_HIP(hipMemcpyAsync((uint8_t*)sl.in.p + ck.doff[i], in + in_off[g], bytes, hipMemcpyHostToDevice, c->hs_in));
+            i = j + 1;
+        }
+        ZMI_HIP(hipMemcpyAsync(meta_off(sl), ck.doff.data(), (size_t)ck.count * 8u, hipMemcpyHostToDevice, c->hs_in));
+        ZMI_HIP(hipMemcpyAsync(meta_len(sl), in_len + ck.first, (size_t)ck.count * 4u, hipMemcpyHostToDevice, c->hs_in));
+        ZMI_HIP(hipEventRecord(sl.in_done, c->hs_in));
+        return 0;
+    };
+    auto issue_k = [&](size_t k) -> int {
+        chunk& ck = chunks[k];
+        zmi_ctx::hb_slot& sl = c->hb[k & 1u];
+        ZMI_HIP(hipStreamWaitEvent(c->hs_k, sl.in_done, 0));
+        if (k >= 2) ZMI_HIP(hipStreamWaitEvent(c->hs_k, sl.out_done, 0));   // the output of chunk k-2 has left this slot
+        int rc = zmi_deflate_batch_dev(c, sl.in.p, meta_off(sl), meta_len(sl), ck.count, max_len, level, strategy, wrap, sl.out.p,
+                                       out_stride, meta_olen(sl), meta_st(sl), c->hs_k);
+        if (rc) return rc;
+        ZMI_HIP(hipEventRecord(sl.k_done, c->hs_k));
+        return 0;
+    };
+    auto issue_out = [&](size_t k) -> int {
+        chunk& ck = chunks[k];
+        zmi_ctx::hb_slot& sl = c->hb[k & 1u];
+        ZMI_HIP(hipStreamWaitEvent(c->hs_out, sl.k_done, 0));
+        ZMI_HIP(hipMemcpyAsync(out + (uint64_t)ck.first * out_stride, sl.out.p, (size_t)ck.count * out_stride, hipMemcpyDeviceToHost, c->hs_out));
+        ZMI_HIP(hipMemcpyAsync(out_len + ck.first, meta_olen(sl), (size_t)ck.count * 4u, hipMemcpyDeviceToHost, c->hs_out));
+        ZMI_HIP(hipMemcpyAsync(status + ck.first, meta_st(sl), (size_t)ck.count * 4u, hipMemcpyDeviceToHost, c->hs_out));
+        ZMI_HIP(hipEventRecord(sl.out_done, c->hs_out));
+        return 0;
+    };
+    int rc = 0;
+    for (size_t k = 0; k < K && !rc; ++k) {
+        rc = issue_in(k);
+        if (!rc) rc = issue_k(k);
+        if (!rc && k >= 1) rc = issue_out(k - 1);
+    }
+    if (!rc) rc = issue_out(K - 1);
+    // nothing of this call may still be in flight when it returns (the host vectors above are sources of copies)
+    (void)hipStreamSynchronize(c->hs_in);
+    (void)hipStreamSynchronize(c->hs_k);
+    (void)hipStreamSynchronize(c->hs_out);
+    if (rc) return rc;
+    ZMI_HIP(hipGetLastError());
+    return ZMI_E_OK;
+}
+
+static int zmi_inflate_batch_simple(zmi_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
                                  int wrap, uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len,
                                  int32_t* status) {
     if (!c || (!in && n) || !in_off || !in_len || !out_off || !out_cap || !out_len || !status)
@@ -564,6 +706,132 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         ZMI_HIP(hipMemcpy(out + out_off[i], d_out + dooff[i], bytes, hipMemcpyDeviceToHost));
         i = j + 1;
     }
+    return ZMI_E_OK;
+}
+
+// Host buffers, pipelined like zmi_deflate_batch: chunks of consecutive streams (by output capacity) cycle through the
+// two device slots.  A chunk's outputs leave in one copy when the caller's regions are laid out like the slot (capacities
+// back to back, 16-byte granules -- the usual array of equal shards), otherwise one copy per stream of its capacity.
+extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
+                                 int wrap, uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len,
+                                 int32_t* status) {
+    if (!c || (!in && n) || !in_off || !in_len || !out_off || !out_cap || !out_len || !status)
+        return zmi_fail(ZMI_E_ARG, "null argument");
+    if (n == 0) return ZMI_E_OK;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; ++i) total += ((uint64_t)out_cap[i] + 15u) & ~15ull;
+    uint64_t budget = total / 8u;
+    if (budget > (128ull << 20)) budget = 128ull << 20;
+    if (budget < (16ull << 20)) budget = 16ull << 20;
+    if (const char* e = getenv("ZMI_HOST_CHUNK")) { if (atoll(e) > 0) budget = (uint64_t)atoll(e); }
+    struct chunk { uint32_t first, count; uint64_t in_bytes, out_bytes; bool packed; std::vector<uint64_t> ioff, ooff; };
+    std::vector<chunk> chunks;
+    for (uint32_t i = 0; i < n;) {
+        chunk ck{i, 0, 0, 0, true, {}, {}};
+        while (i < n) {
+            const uint64_t ai = ((uint64_t)in_len[i] + 15u) & ~15ull, ao = ((uint64_t)out_cap[i] + 15u) & ~15ull;
+            if (ck.count && ck.out_bytes + ao > budget) break;
+            if (out_off[i] - out_off[ck.first] != ck.out_bytes) ck.packed = false;   // the caller's layout differs from the slot's
+            ck.ioff.push_back(ck.in_bytes);
+            ck.ooff.push_back(ck.out_bytes);
+            ck.in_bytes += ai;
+            ck.out_bytes += ao;
+            ++ck.count;
+            ++i;
+        }
+        chunks.push_back(std::move(ck));
+    }
+    const char* pl = getenv("ZMI_HOST_PIPELINE");
+    if (chunks.size() < 2 || (pl && !atoi(pl)))
+        return zmi_inflate_batch_simple(c, in, in_off, in_len, n, wrap, out, out_off, out_cap, out_len, status);
+    ZMI_HIP(hipSetDevice(c->device));
+    int rc = zmi_host_pipeline_init(c);
+    if (rc) return rc;
+    uint64_t max_in = 0, max_out = 0;
+    uint32_t max_count = 0;
+    for (const chunk& ck : chunks) {
+        if (ck.in_bytes > max_in) max_in = ck.in_bytes;
+        if (ck.out_bytes > max_out) max_out = ck.out_bytes;
+        if (ck.count > max_count) max_count = ck.count;
+    }
+    for (auto& sl : c->hb) {
+        rc = zmi_reserve(sl.in, (size_t)max_in + 64u);
+        if (!rc) rc = zmi_reserve(sl.out, (size_t)max_out + 64u);
+        if (!rc) rc = zmi_reserve(sl.meta, (size_t)max_count * 32u);   // in_off u64 | out_off u64 | in_len | out_cap | out_len | status
+        if (rc) return rc;
+    }
+    const uint64_t saved_limit = c->inflate_out_limit;
+    c->inflate_out_limit = max_out + (1ull << 20);   // bitmap scratch for the largest chunk, once
+    struct restore { zmi_ctx* c; uint64_t v; ~restore() { c->inflate_out_limit = v; } } restore_limit{c, saved_limit};
+    auto m_ioff = [&](zmi_ctx::hb_slot& sl) { return (uint64_t*)sl.meta.p; };
+    auto m_ooff = [&](zmi_ctx::hb_slot& sl) { return (uint64_t*)((uint8_t*)sl.meta.p + (size_t)max_count * 8u); };
+    auto m_ilen = [&](zmi_ctx::hb_slot& sl) { return (uint32_t*)((uint8_t*)sl.meta.p + (size_t)max_count * 16u); };
+    auto m_ocap = [&](zmi_ctx::hb_slot& sl) { return (uint32_t*)((uint8_t*)sl.meta.p + (size_t)max_count * 20u); };
+    auto m_olen = [&](zmi_ctx::hb_slot& sl) { return (uint32_t*)((uint8_t*)sl.meta.p + (size_t)max_count * 24u); };
+    auto m_st = [&](zmi_ctx::hb_slot& sl) { return (int32_t*)((uint8_t*)sl.meta.p + (size_t)max_count * 28u); };
+    auto issue_in = [&](size_t k) -> int {
+        chunk& ck = chunks[k];
+        zmi_ctx::hb_slot& sl = c->hb[k & 1u];
+        if (k >= 2) ZMI_HIP(hipStreamWaitEvent(c->hs_in, sl.k_done, 0));
+        for (uint32_t i = 0; i < ck.count;) {
+            const uint32_t g = ck.first + i;
+            uint32_t j = i;
+            uint64_t bytes = in_len[g];
+            while (j + 1 < ck.count && in_off[ck.first + j + 1] == in_off[ck.first + j] + in_len[ck.first + j] &&
+                   ck.ioff[j + 1] == ck.ioff[j] + in_len[ck.first + j] && bytes < (1ull << 30))
+                bytes += in_len[ck.first + ++j];
+            if (bytes) ZMI_HIP(hipMemcpyAsync((uint8_t*)sl.in.p + ck.ioff[i], in + in_off[g], bytes, hipMemcpyHostToDevice, c->hs_in));
+            i = j + 1;
+        }
+        ZMI_HIP(hipMemcpyAsync(m_ioff(sl), ck.ioff.data(), (size_t)ck.count * 8u, hipMemcpyHostToDevice, c->hs_in));
+        ZMI_HIP(hipMemcpyAsync(m_ooff(sl), ck.ooff.data(), (size_t)ck.count * 8u, hipMemcpyHostToDevice, c->hs_in));
+        ZMI_HIP(hipMemcpyAsync(m_ilen(sl), in_len + ck.first, (size_t)ck.count * 4u, hipMemcpyHostToDevice, c->hs_in));
+        ZMI_HIP(hipMemcpyAsync(m_ocap(sl), out_cap + ck.first, (size_t)ck.count * 4u, hipMemcpyHostToDevice, c->hs_in));
+        ZMI_HIP(hipEventRecord(sl.in_done, c->hs_in));
+        return 0;
+    };
+    auto issue_k = [&](size_t k) -> int {
+        chunk& ck = chunks[k];
+        zmi_ctx::hb_slot& sl = c->hb[k & 1u];
+        ZMI_HIP(hipStreamWaitEvent(c->hs_k, sl.in_done, 0));
+        if (k >= 2) ZMI_HIP(hipStreamWaitEvent(c->hs_k, sl.out_done, 0));
+        int r = zmi_inflate_batch_dev(c, sl.in.p, m_ioff(sl), m_ilen(sl), ck.count, wrap, sl.out.p, m_ooff(sl), m_ocap(sl), m_olen(sl),
+                                      m_st(sl), c->hs_k);
+        if (r) return r;
+        ZMI_HIP(hipEventRecord(sl.k_done, c->hs_k));
+        return 0;
+    };
+    auto issue_out = [&](size_t k) -> int {
+        chunk& ck = chunks[k];
+        zmi_ctx::hb_slot& sl = c->hb[k & 1u];
+        ZMI_HIP(hipStreamWaitEvent(c->hs_out, sl.k_done, 0));
+        if (ck.packed) {
+            const uint64_t last = ck.ooff[ck.count - 1u] + out_cap[ck.first + ck.count - 1u];   // not past the caller's last region
+            ZMI_HIP(hipMemcpyAsync(out + out_off[ck.first], sl.out.p, (size_t)last, hipMemcpyDeviceToHost, c->hs_out));
+        } else {
+            for (uint32_t i = 0; i < ck.count; ++i)
+                if (out_cap[ck.first + i])
+                    ZMI_HIP(hipMemcpyAsync(out + out_off[ck.first + i], (uint8_t*)sl.out.p + ck.ooff[i], out_cap[ck.first + i],
+                                           hipMemcpyDeviceToHost, c->hs_out));
+        }
+        ZMI_HIP(hipMemcpyAsync(out_len + ck.first, m_olen(sl), (size_t)ck.count * 4u, hipMemcpyDeviceToHost, c->hs_out));
+        ZMI_HIP(hipMemcpyAsync(status + ck.first, m_st(sl), (size_t)ck.count * 4u, hipMemcpyDeviceToHost, c->hs_out));
+        ZMI_HIP(hipEventRecord(sl.out_done, c->hs_out));
+        return 0;
+    };
+    const size_t K = chunks.size();
+    rc = 0;
+    for (size_t k = 0; k < K && !rc; ++k) {
+        rc = issue_in(k);
+        if (!rc) rc = issue_k(k);
+        if (!rc && k >= 1) rc = issue_out(k - 1);
+    }
+    if (!rc) rc = issue_out(K - 1);
+    (void)hipStreamSynchronize(c->hs_in);
+    (void)hipStreamSynchronize(c->hs_k);
+    (void)hipStreamSynchronize(c->hs_out);
+    if (rc) return rc;
+    ZMI_HIP(hipGetLastError());
     return ZMI_E_OK;
 }
 
