@@ -29,7 +29,7 @@ def main():
     ln = np.full(S, B, dtype=np.uint32)
     olen = np.zeros(S, dtype=np.uint32)
     st = np.zeros(S, dtype=np.int32)
-    for kind in ("pageable", "pinned"):
+    for kind in os.environ.get("PROBE_KINDS", "pageable,pinned").split(","):
         host_in = dev.cpu()
         host_out = torch.empty(S * stride, dtype=torch.uint8)
         if kind == "pinned":
@@ -43,6 +43,8 @@ def main():
         ratio = S * B / float(olen.astype(np.int64).sum())
         print("deflate host buffers (%s): %.2f GiB/s of input incl. PCIe both ways, ratio %.3f, %d shards" %
               (kind, S * B / 2**30 / dt, ratio, S))
+        if os.environ.get("PROBE_DEFLATE_ONLY"):
+            continue
         # and back: compressed streams from host memory, output to host memory
         back = torch.empty(S * B, dtype=torch.uint8)
         if kind == "pinned":

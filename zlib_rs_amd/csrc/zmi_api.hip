@@ -552,25 +552,23 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
                                  int32_t* status) {
     if (!c || (!in && n) || !in_off || !in_len || !out || !out_len || !status) return zmi_fail(ZMI_E_ARG, "null argument");
     if (n == 0) return ZMI_E_OK;
-    uint64_t total = 0;
     uint32_t max_len = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        total += ((uint64_t)in_len[i] + 15u) & ~15ull;
+    for (uint32_t i = 0; i < n; ++i)
         if (in_len[i] > max_len) max_len = in_len[i];
-    }
     if (out_stride % 16u || out_stride < zmi_deflate_bound(max_len, wrap))
         return zmi_fail(ZMI_E_ARG, "out_stride must be a multiple of 16 and >= zmi_deflate_bound(max_len)");
-    uint64_t budget = total / 8u;   // at least eight chunks in flight before the pipeline pays ...
-    if (budget > (128ull << 20)) budget = 128ull << 20;
-    if (budget < (16ull << 20)) budget = 16ull << 20;   // ... and no chunk so small that launches dominate
-    if (const char* e = getenv("ZMI_HOST_CHUNK")) { if (atoll(e) > 0) budget = (uint64_t)atoll(e); }
+    // A chunk must fill the chip by itself: one workgroup per shard on 256 CUs wants >= 1024 shards per launch (measured:
+    // 128-shard chunks made the kernels, not PCIe, the bottleneck).  ZMI_HOST_CHUNK (bytes) overrides both bounds (tests).
+    uint64_t budget = 256ull << 20;
+    uint32_t min_count = 1024u;
+    if (const char* e = getenv("ZMI_HOST_CHUNK")) { if (atoll(e) > 0) { budget = (uint64_t)atoll(e); min_count = 1u; } }
     struct chunk { uint32_t first, count; uint64_t bytes; std::vector<uint64_t> doff; };
     std::vector<chunk> chunks;
     for (uint32_t i = 0; i < n;) {
         chunk ck{i, 0, 0, {}};
         while (i < n) {
             const uint64_t a = ((uint64_t)in_len[i] + 15u) & ~15ull;
-            if (ck.count && ck.bytes + a > budget) break;
+            if (ck.count >= min_count && ck.bytes + a > budget) break;
             ck.doff.push_back(ck.bytes);
             ck.bytes += a;
             ++ck.count;
@@ -579,7 +577,7 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         chunks.push_back(std::move(ck));
     }
     const char* pl = getenv("ZMI_HOST_PIPELINE");   // 0: the plain copy-in / kernels / copy-out sequence
-    if (chunks.size() < 2 || (pl && !atoi(pl)))
+    if (chunks.size() < 3 || (pl && !atoi(pl)))   // two chunks overlap too little to pay for the whole-slot copies
         return zmi_deflate_batch_simple(c, in, in_off, in_len, n, level, strategy, wrap, out, out_stride, out_len, status);
     ZMI_HIP(hipSetDevice(c->device));
     {
@@ -718,19 +716,18 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     if (!c || (!in && n) || !in_off || !in_len || !out_off || !out_cap || !out_len || !status)
         return zmi_fail(ZMI_E_ARG, "null argument");
     if (n == 0) return ZMI_E_OK;
-    uint64_t total = 0;
-    for (uint32_t i = 0; i < n; ++i) total += ((uint64_t)out_cap[i] + 15u) & ~15ull;
-    uint64_t budget = total / 8u;
-    if (budget > (128ull << 20)) budget = 128ull << 20;
-    if (budget < (16ull << 20)) budget = 16ull << 20;
-    if (const char* e = getenv("ZMI_HOST_CHUNK")) { if (atoll(e) > 0) budget = (uint64_t)atoll(e); }
+    // one wave per stream: a launch wants >= 8192 streams to keep the chip busy (2048 streams run at
+    // 17 GiB/s, 16384 at 41), so only very large host batches are cut.  ZMI_HOST_CHUNK (bytes) overrides both bounds (tests).
+    uint64_t budget = 1ull << 30;
+    uint32_t min_count = 8192u;
+    if (const char* e = getenv("ZMI_HOST_CHUNK")) { if (atoll(e) > 0) { budget = (uint64_t)atoll(e); min_count = 1u; } }
     struct chunk { uint32_t first, count; uint64_t in_bytes, out_bytes; bool packed; std::vector<uint64_t> ioff, ooff; };
     std::vector<chunk> chunks;
     for (uint32_t i = 0; i < n;) {
         chunk ck{i, 0, 0, 0, true, {}, {}};
         while (i < n) {
             const uint64_t ai = ((uint64_t)in_len[i] + 15u) & ~15ull, ao = ((uint64_t)out_cap[i] + 15u) & ~15ull;
-            if (ck.count && ck.out_bytes + ao > budget) break;
+            if (ck.count >= min_count && ck.out_bytes + ao > budget) break;
             if (out_off[i] - out_off[ck.first] != ck.out_bytes) ck.packed = false;   // the caller's layout differs from the slot's
             ck.ioff.push_back(ck.in_bytes);
             ck.ooff.push_back(ck.out_bytes);
@@ -742,7 +739,7 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         chunks.push_back(std::move(ck));
     }
     const char* pl = getenv("ZMI_HOST_PIPELINE");
-    if (chunks.size() < 2 || (pl && !atoi(pl)))
+    if (chunks.size() < 3 || (pl && !atoi(pl)))
         return zmi_inflate_batch_simple(c, in, in_off, in_len, n, wrap, out, out_off, out_cap, out_len, status);
     ZMI_HIP(hipSetDevice(c->device));
     int rc = zmi_host_pipeline_init(c);
