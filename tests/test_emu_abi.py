@@ -79,3 +79,12 @@ def test_gz_file_api(tmp_path):
     zmi_ctypes.load_emu()
     lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
     H.gz_checks(lib, tmp_path, oracle_lib.load().gen_shard(1, 60000), syslib=C.CDLL("libz.so.1"))
+
+
+def test_reference_inflate_vectors_through_the_stream_abi():
+    """the golden bitstreams / fixtures of the reference's tests through inflate(), whole and in steps"""
+    import json
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    vectors = json.load(open(os.path.join(zmi_ctypes.ROOT, "tests", "golden", "inflate_vectors.json")))
+    assert H.golden_inflate_checks(lib, vectors) > 50

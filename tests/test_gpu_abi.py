@@ -89,3 +89,12 @@ def test_gz_file_api_on_gpu(tmp_path):
     from zlib_rs_amd import _build
     lib = H.bind(C.CDLL(_build.ABI_LIB))
     H.gz_checks(lib, tmp_path, oracle_lib.load(rebuild=False).gen_shard(1, 3 << 20), syslib=C.CDLL("libz.so.1"))
+
+
+def test_reference_inflate_vectors_through_the_stream_abi_on_gpu():
+    """the golden bitstreams / fixtures of the reference's tests through inflate(), whole and in steps"""
+    import json
+    from zlib_rs_amd import _build
+    lib = H.bind(C.CDLL(_build.ABI_LIB))
+    vectors = json.load(open(os.path.join(ROOT, "tests", "golden", "inflate_vectors.json")))
+    assert H.golden_inflate_checks(lib, vectors, steps=(0, 1, 2, 3, 5, 17, 64)) > 100

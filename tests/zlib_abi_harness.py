@@ -763,3 +763,43 @@ def gz_checks(lib, tmpdir, data, syslib=None):
     msg = lib.gzerror(f, C.byref(err))
     assert n == -1 or err.value == Z_DATA_ERROR, (n, err.value, msg)
     assert lib.gzclose(f) == Z_OK
+
+
+def golden_inflate_checks(lib, vectors, steps=(0, 1, 3, 17)):
+    """the reference's own inflate vectors (tests/golden/inflate_vectors.json: hand-made bitstreams with their
+    expected error, test-libz-rs-sys/src/inflate.rs:734-1030, and its test-data files) through inflate(), whole and
+    in steps -- the verdict must not depend on how the input arrives (inflate.rs:2376-2457)"""
+    import base64
+    import zlib
+    ver, zs = lib.zlibVersion(), C.sizeof(ZStream)
+    wb = {0: -15, 1: 15, 2: 31, 3: 47}
+    n = 0
+    for v in vectors["bitstreams"] + vectors["files"]:
+        blob = bytes.fromhex(v["input"]) if "input" in v else base64.b64decode(v["data_b64"])
+        expect_ok = v.get("expect", "ok") == "ok"
+        want = None
+        if expect_ok:
+            d = zlib.decompressobj(wb[v["wrap"]])
+            want = d.decompress(blob)
+        for step in (steps if len(blob) <= 600 else (0, max(700, len(blob) // 5))):   # long fixtures only in large pieces
+            strm = ZStream()
+            assert lib.inflateInit2_(C.byref(strm), wb[v["wrap"]], ver, zs) == Z_OK
+            src = C.create_string_buffer(blob, len(blob) or 1)
+            got = bytearray()
+            rc = Z_OK
+            pieces = [(0, len(blob))] if not step else [(a, min(step, len(blob) - a)) for a in range(0, len(blob), step)]
+            for a, ln in pieces:
+                rc = _feed(lib, strm, C.addressof(src) + a, ln, got)
+                if rc not in (Z_OK, Z_BUF_ERROR):
+                    break
+            if rc in (Z_OK, Z_BUF_ERROR):     # the input is used up: what Z_FINISH says now is the verdict
+                rc = _feed(lib, strm, C.addressof(src), 0, got, Z_FINISH)
+            if expect_ok:
+                assert rc == Z_STREAM_END and bytes(got) == want, (v["source"], step, rc, len(got))
+            elif v["expect"] == "data_error":
+                assert rc == Z_DATA_ERROR, (v["source"], step, rc)
+            else:
+                assert rc in (Z_BUF_ERROR, Z_DATA_ERROR), (v["source"], step, rc)
+            assert lib.inflateEnd(C.byref(strm)) == Z_OK
+            n += 1
+    return n

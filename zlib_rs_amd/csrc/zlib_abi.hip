@@ -302,6 +302,7 @@ struct InflateState {
     uint32_t check = 1;            // Adler-32 / CRC-32 of the bytes handed to the caller
     uint32_t want_check = 0;       // trailer values, compared when the last byte has been handed out
     uint32_t want_len = 0;
+    bool check_seen = false;       // the trailer's check value has arrived
     uint64_t total = 0;            // bytes decoded
     bool verify = true;            // inflateValidate
     int error = 0;
@@ -631,14 +632,25 @@ int inflate_run(z_streamp strm, InflateState* s) {
             break;
         }
         case IM_TRAILER: {
-            const size_t need = s->form == 1 ? 4 : (s->form == 2 ? 8 : 0);
-            if (s->in.size() < need) return Z_OK;
-            if (s->form == 1) s->want_check = ((uint32_t)s->in[0] << 24) | ((uint32_t)s->in[1] << 16) | ((uint32_t)s->in[2] << 8) | s->in[3];
-            else if (s->form == 2) {
-                s->want_check = s->in[0] | ((uint32_t)s->in[1] << 8) | ((uint32_t)s->in[2] << 16) | ((uint32_t)s->in[3] << 24);
-                s->want_len = s->in[4] | ((uint32_t)s->in[5] << 8) | ((uint32_t)s->in[6] << 16) | ((uint32_t)s->in[7] << 24);
+            if (s->form == 0) { s->mode = IM_DONE; return Z_OK; }
+            if (s->form == 1) {
+                if (s->in.size() < 4) return Z_OK;
+                s->want_check = ((uint32_t)s->in[0] << 24) | ((uint32_t)s->in[1] << 16) | ((uint32_t)s->in[2] << 8) | s->in[3];
+                s->in.erase(s->in.begin(), s->in.begin() + 4);
+                s->check_seen = true;
+                s->mode = IM_DONE;
+                return Z_OK;
             }
-            s->in.erase(s->in.begin(), s->in.begin() + need);
+            // gzip: the CRC is judged as soon as it is there, before the length arrives (inflate.rs Mode::Check, Mode::Length)
+            if (!s->check_seen) {
+                if (s->in.size() < 4) return Z_OK;
+                s->want_check = s->in[0] | ((uint32_t)s->in[1] << 8) | ((uint32_t)s->in[2] << 16) | ((uint32_t)s->in[3] << 24);
+                s->in.erase(s->in.begin(), s->in.begin() + 4);
+                s->check_seen = true;
+            }
+            if (s->in.size() < 4) return Z_OK;
+            s->want_len = s->in[0] | ((uint32_t)s->in[1] << 8) | ((uint32_t)s->in[2] << 16) | ((uint32_t)s->in[3] << 24);
+            s->in.erase(s->in.begin(), s->in.begin() + 4);
             s->mode = IM_DONE;
             return Z_OK;
         }
@@ -1007,6 +1019,11 @@ int inflate(z_streamp strm, int flush) {
     // block, +128 right behind a block
     const bool at_boundary = s->mode == IM_BLOCKS && s->pend == 0 && s->in.size() <= (s->sbit ? 1u : 0u) && s->form >= 0;
     strm->data_type = (int)((s->sbit && s->mode == IM_BLOCKS ? 8u - s->sbit : 0u) + (s->last_block ? 64 : 0) + (at_boundary ? 128 : 0));
+    if (s->mode == IM_TRAILER && s->check_seen && drained && s->verify && s->check != s->want_check) {
+        inf_bad(s, "incorrect data check");   // a gzip trailer that ends behind a wrong CRC is an error already
+        strm->msg = s->errmsg;
+        return Z_DATA_ERROR;
+    }
     if (s->mode == IM_DONE && drained) {
         if (s->verify && s->form > 0 && s->check != s->want_check) { inf_bad(s, "incorrect data check"); strm->msg = s->errmsg; return Z_DATA_ERROR; }
         if (s->verify && s->form == 2 && (uint32_t)s->total != s->want_len) { inf_bad(s, "incorrect length check"); strm->msg = s->errmsg; return Z_DATA_ERROR; }
