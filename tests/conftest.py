@@ -12,6 +12,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    # no single test may hold the suite for long (a state-machine bug once looped for an hour): pytest-timeout, if there
+    if config.pluginmanager.hasplugin("timeout"):
+        for item in items:
+            if item.get_closest_marker("timeout") is None:
+                item.add_marker(pytest.mark.timeout(600))
+
+
 @pytest.fixture(scope="session")
 def engine():
     import torch

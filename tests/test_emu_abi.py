@@ -88,3 +88,20 @@ def test_reference_inflate_vectors_through_the_stream_abi():
     lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
     vectors = json.load(open(os.path.join(zmi_ctypes.ROOT, "tests", "golden", "inflate_vectors.json")))
     assert H.golden_inflate_checks(lib, vectors) > 50
+
+
+def test_inflate_attempt_limits(monkeypatch):
+    """the bounds inside inflate(): one device decode sees a limited slice of the buffered input, and decoding pauses
+    while the caller has not fetched what is queued -- shrunk through the environment so that a small stream gets there"""
+    import zlib
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    o = oracle_lib.load()
+    data = o.gen_shard(0, 90000) + o.gen_shard(6, 60000) + o.gen_shard(3, 50000)
+    comp = zlib.compress(data, 6) + b"rest"
+    for take, queue in (("3000", "20000"), ("100", "1000000"), ("1000000", "5000"), ("100", "3000")):
+        monkeypatch.setenv("ZMI_ABI_TAKE", take)
+        monkeypatch.setenv("ZMI_ABI_QUEUE", queue)
+        rc, out, unused = H.inflate_stream(lib, comp, wbits=15, chunk_in=1 << 30, chunk_out=7000)
+        # (bytes behind the end of the stream come back only from the call that delivered them)
+        assert rc == H.Z_STREAM_END and out == data and unused in (0, 4), (take, queue, rc, len(out), unused)

@@ -506,7 +506,15 @@ void inf_keep_hist(InflateState* s, const uint8_t* p, size_t n) {
         if (s->hist.size() > 32768u) s->hist.erase(s->hist.begin(), s->hist.end() - 32768);
     }
 }
-const size_t kQueueLimit = (size_t)32 << 20;   // decoded bytes waiting for the caller before decoding pauses
+// decoded bytes waiting for the caller before decoding pauses / input bytes handed to one device decode.
+// ZMI_ABI_QUEUE and ZMI_ABI_TAKE (bytes) override them so that tests reach these paths with small streams.
+size_t abi_limit(const char* name, size_t dflt) {
+    const char* e = getenv(name);
+    const long long v = e ? atoll(e) : 0;
+    return v > 0 ? (size_t)v : dflt;
+}
+size_t queue_limit() { return abi_limit("ZMI_ABI_QUEUE", (size_t)32 << 20); }
+size_t take_limit() { return abi_limit("ZMI_ABI_TAKE", (size_t)256 << 20); }
 
 // Decode what is buffered, from the checkpoint.  Queues every new byte, moves the checkpoint to the last block
 // boundary reached, and changes the mode when the final block ended or the data is invalid.
@@ -514,7 +522,8 @@ int inflate_attempt(InflateState* s) {
     std::lock_guard<std::mutex> lk(g_mu);
     zmi_ctx* c = abi_ctx();
     if (!c) return Z_MEM_ERROR;
-    size_t take = s->in.size() < ((size_t)256 << 20) ? s->in.size() : ((size_t)256 << 20);
+    const size_t kTake = take_limit(), kQueueLimit = queue_limit();
+    size_t take = s->in.size() < kTake ? s->in.size() : kTake;
     size_t cap = take * 4 + 65536;
     if (cap > ((size_t)64 << 20)) cap = (size_t)64 << 20;
     for (;;) {
@@ -553,8 +562,9 @@ int inflate_attempt(InflateState* s) {
             break;
         }
         // more input or more room needed: everything in front of the checkpoint is settled
+        // (an attempt on a shorter slice of the input may decode less than an earlier one has already queued)
         inf_keep_hist(s, s->tmp.data(), res[2]);
-        s->pend = eff - res[2];
+        s->pend = (eff > s->pend ? eff : s->pend) - res[2];
         s->in.erase(s->in.begin(), s->in.begin() + res[0]);
         if (res[0] || res[1] != s->sbit) s->primed = 0;
         s->sbit = res[1];
@@ -567,7 +577,7 @@ int inflate_attempt(InflateState* s) {
                 if (res[0] == 0 && det != 2) {   // no block boundary inside what was given: give more
                     if (take >= 0xF0000000ull || take == s->in.size()) break;
                     take = s->in.size() < take * 2 ? s->in.size() : take * 2;
-                } else take = s->in.size() < ((size_t)256 << 20) ? s->in.size() : ((size_t)256 << 20);
+                } else take = s->in.size() < kTake ? s->in.size() : kTake;
             }
             continue;
         }
@@ -625,7 +635,7 @@ int inflate_run(z_streamp strm, InflateState* s) {
             return Z_NEED_DICT;
         case IM_BLOCKS: {
             if (s->in.empty() || s->tried == s->in.size()) return Z_OK;
-            if (s->out.size() - s->out_pos > kQueueLimit) return Z_OK;
+            if (s->out.size() - s->out_pos > queue_limit()) return Z_OK;
             const int rc = inflate_attempt(s);
             if (rc != Z_OK) return rc;
             if (s->mode == IM_BLOCKS) return Z_OK;
@@ -1003,17 +1013,22 @@ int inflate(z_streamp strm, int flush) {
         taken = in0;
         s->in_sync = false;
     }
-    const int was = s->mode;
-    const int rc = inflate_run(strm, s);
-    if (rc == Z_NEED_DICT) return Z_NEED_DICT;
-    if (rc != Z_OK) { strm->msg = zError(rc); return rc; }
-    if (s->mode == IM_DONE && was != IM_DONE && !s->in.empty()) {
-        // bytes behind the end of the stream belong to the caller: hand them back (they came with this call)
-        const size_t unused = s->in.size() < taken ? s->in.size() : taken;
-        strm->next_in -= unused; strm->total_in -= unused; strm->avail_in += (uInt)unused;
-        s->in.clear();
+    for (;;) {
+        const int was = s->mode;
+        const int rc = inflate_run(strm, s);
+        if (rc == Z_NEED_DICT) return Z_NEED_DICT;
+        if (rc != Z_OK) { strm->msg = zError(rc); return rc; }
+        if (s->mode == IM_DONE && was != IM_DONE && !s->in.empty()) {
+            // bytes behind the end of the stream belong to the caller: hand them back -- as far as they came with this
+            // call (what an earlier call took cannot be returned any more)
+            const size_t unused = s->in.size() < taken ? s->in.size() : taken;
+            strm->next_in -= unused; strm->total_in -= unused; strm->avail_in += (uInt)unused;
+            s->in.clear();
+        }
+        inflate_drain(strm, s);
+        // decoding pauses while much output is queued; a caller who still has room gets the rest in this same call
+        if (strm->avail_out == 0 || s->mode != IM_BLOCKS || s->in.empty() || s->tried == s->in.size()) break;
     }
-    inflate_drain(strm, s);
     const bool drained = s->out_pos >= s->out.size();
     // data_type as the reference reports it (inflate.rs:2440-2448): unused bits of the last byte, +64 in the last
     // block, +128 right behind a block
