@@ -21,7 +21,8 @@
  *              last block boundary it reached -- with the 32 KiB of output in front of it as history
  *              (zmi_inflate_resume, include/zmi355.h; the reference's Mode / BitReader / Window,
  *              zlib-rs/src/inflate.rs:288-320): a block is decoded again only while it is incomplete, memory
- *              is bounded by the block size.  Wrapper header / trailer are parsed on the host.  Z_BLOCK and
+ *              is bounded by the block size.  Bytes behind the end of the stream are handed back (avail_in) as
+ *              far as they arrived with the call that reaches the end.  Wrapper header / trailer are parsed on the host.  Z_BLOCK and
  *              Z_TREES do not stop at block ends (they behave like Z_NO_FLUSH).  The bytes in front of a corrupt
  *              spot are delivered before Z_DATA_ERROR, as the reference does; header and trailer errors carry the
  *              reference's messages, errors inside the deflate data a generic one.

@@ -4,8 +4,9 @@
 // version / enum checks) over the stream state machines zlib-rs/src/deflate.rs:2489-2803 and
 // zlib-rs/src/inflate.rs:2376-2457.  Here the veneer does the same argument checking and return
 // codes, but the state behind `strm->state` is a host-side staging object; the compression work is
-// the batch path of zmi_api.hip (1 MiB segments, Z_FULL_FLUSH semantics between segments, the
-// stitch recipe of zlib-rs/src/deflate.rs:4149-4221).
+// the batch path of zmi_api.hip (deflate: 1 MiB segments compressed in parallel with the window carried
+// over, joined by the stitch recipe of zlib-rs/src/deflate.rs:4149-4221; inflate: the resumable device
+// decode zmi_inflate_resume, restarted at block checkpoints).
 //
 // No exception may cross the C boundary (the reference builds with panic=abort,
 // libz-rs-sys-cdylib/src/lib.rs:5-6): every export is noexcept and catches std::bad_alloc.
