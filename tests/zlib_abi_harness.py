@@ -737,6 +737,36 @@ def gz_checks(lib, tmpdir, data, syslib=None):
     assert lib.gzclose(f) == Z_OK
     assert gzip.open(p("c.gz"), "rb").read() == data[:1000] + bytes(500) + data[:1000]
 
+    # -- long formatted output, lines longer than the buffer, push-back until the buffer is full
+    f = lib.gzopen(p("d.gz").encode(), b"w")
+    assert lib.gzbuffer(f, 64) == 0
+    longarg = b"x" * 5000
+    assert lib.gzprintf(f, b"[%s]\n", longarg) == 5003          # longer than any internal scratch
+    assert lib.gzputs(f, b"") == 0 and lib.gzwrite(f, src, 0) == 0
+    assert lib.gzclose(f) == Z_OK
+    f = lib.gzopen(p("d.gz").encode(), b"r")
+    assert lib.gzbuffer(f, 64) == 0
+    linebuf = C.create_string_buffer(6000)
+    assert lib.gzgets(f, linebuf, 6000) and linebuf.value == b"[" + longarg + b"]\n"     # a line of many buffers
+    assert not lib.gzgets(f, linebuf, 6000) and lib.gzeof(f) == 1                        # nothing left
+    assert lib.gzgetc(f) == -1
+    pushed = 0
+    while lib.gzungetc(ord("a") + pushed % 26, f) >= 0:                                # 2 x 64 bytes of room
+        pushed += 1
+        assert pushed <= 128
+    assert pushed == 128 and lib.gzeof(f) == 0
+    err = C.c_int(0)
+    assert lib.gzerror(f, C.byref(err)).endswith(b"out of room to push characters") and err.value == Z_DATA_ERROR
+    lib.gzclearerr(f)
+    back = C.create_string_buffer(200)
+    assert lib.gzread(f, back, 200) == 0           # a fatal error drops what was buffered (gz.rs:467-500), the file is at its end
+    assert lib.gzrewind(f) == 0
+    for i in range(100):                           # within the room: comes back in reverse order of the pushes
+        assert lib.gzungetc(ord("a") + i % 26, f) >= 0
+    assert lib.gzread(f, back, 101) == 101
+    assert back.raw[:101] == bytes(ord("a") + i % 26 for i in reversed(range(100))) + b"["
+    assert lib.gzclose(f) == Z_OK
+
     # -- an empty file written and read; a missing file; a bad mode; a truncated file
     f = lib.gzopen(p("empty.gz").encode(), b"w")
     assert lib.gzclose(f) == Z_OK and gzip.open(p("empty.gz"), "rb").read() == b""
