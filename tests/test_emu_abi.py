@@ -105,3 +105,12 @@ def test_inflate_attempt_limits(monkeypatch):
         rc, out, unused = H.inflate_stream(lib, comp, wbits=15, chunk_in=1 << 30, chunk_out=7000)
         # (bytes behind the end of the stream come back only from the call that delivered them)
         assert rc == H.Z_STREAM_END and out == data and unused in (0, 4), (take, queue, rc, len(out), unused)
+
+
+def test_random_streaming_roundtrips():
+    """randomised pieces / rooms / flush arguments through inflate() against streams of the system's zlib"""
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    o = oracle_lib.load()
+    for seed in range(40):
+        H.random_streaming_roundtrips(lib, o, 6, seed)

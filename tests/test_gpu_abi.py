@@ -98,3 +98,12 @@ def test_reference_inflate_vectors_through_the_stream_abi_on_gpu():
     lib = H.bind(C.CDLL(_build.ABI_LIB))
     vectors = json.load(open(os.path.join(ROOT, "tests", "golden", "inflate_vectors.json")))
     assert H.golden_inflate_checks(lib, vectors, steps=(0, 1, 2, 3, 5, 17, 64)) > 100
+
+
+def test_random_streaming_roundtrips_on_gpu():
+    """randomised pieces / rooms / flush arguments through inflate() against streams of the system's zlib"""
+    from zlib_rs_amd import _build
+    lib = H.bind(C.CDLL(_build.ABI_LIB))
+    o = oracle_lib.load(rebuild=False)
+    for seed in range(1000, 1008):
+        H.random_streaming_roundtrips(lib, o, 3, seed, max_len=200000)

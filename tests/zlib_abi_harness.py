@@ -833,3 +833,55 @@ def golden_inflate_checks(lib, vectors, steps=(0, 1, 3, 17)):
             assert lib.inflateEnd(C.byref(strm)) == Z_OK
             n += 1
     return n
+
+
+def random_streaming_roundtrips(lib, o, rounds, seed, max_len=60000):
+    """randomised drive of inflate(): streams from the system's zlib (random level, wrapper, flush points, sometimes
+    a preset-free raw stream), delivered in random pieces into output buffers of random size, with random flush
+    arguments; the result must be the data, the end must be reported exactly once, trailing bytes of the last piece
+    must come back"""
+    import random
+    import zlib
+    rnd = random.Random(seed)
+    ver, zs = lib.zlibVersion(), C.sizeof(ZStream)
+    for r in range(rounds):
+        n = rnd.choice([0, 1, 10, 300, 5000, rnd.randrange(max_len)])
+        data = o.gen_shard(rnd.randrange(8), n) if rnd.random() < 0.8 else bytes(rnd.randrange(256) for _ in range(min(n, 3000)))
+        wbits = rnd.choice([15, 31, -15])
+        co = zlib.compressobj(rnd.choice([0, 1, 6, 9]), zlib.DEFLATED, wbits)
+        comp, at = b"", 0
+        while at < len(data):
+            k = rnd.randrange(1, len(data) + 1)
+            comp += co.compress(data[at:at + k])
+            if rnd.random() < 0.4:
+                comp += co.flush(rnd.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH]))
+            at += k
+        comp += co.flush()
+        junk = bytes(rnd.randrange(256) for _ in range(rnd.choice([0, 0, 5])))
+        blob = comp + junk
+        strm = ZStream()
+        init_bits = wbits if wbits != 31 or rnd.random() < 0.5 else 47
+        assert lib.inflateInit2_(C.byref(strm), init_bits, ver, zs) == Z_OK
+        src = C.create_string_buffer(blob, len(blob) or 1)
+        out = bytearray()
+        pos, rc, calls = 0, Z_OK, 0
+        while rc != Z_STREAM_END:
+            calls += 1
+            assert calls < 100000, "no end in sight"
+            piece = min(len(blob) - pos, rnd.choice([1, 2, 7, 100, 4096, 1 << 20]))
+            room = rnd.choice([1, 3, 64, 1000, 70000])
+            obuf = C.create_string_buffer(room)
+            strm.next_in, strm.avail_in = C.addressof(src) + pos, piece
+            strm.next_out, strm.avail_out = C.addressof(obuf), room
+            rc = lib.inflate(C.byref(strm), rnd.choice([Z_NO_FLUSH, Z_SYNC_FLUSH, Z_NO_FLUSH, 5]))
+            assert rc in (Z_OK, Z_STREAM_END, Z_BUF_ERROR), (r, rc, strm.msg)
+            pos += piece - strm.avail_in
+            out += obuf.raw[:room - strm.avail_out]
+            if rc == Z_BUF_ERROR:
+                assert piece == 0 and room - strm.avail_out == 0          # only a call that could do nothing
+                assert pos < len(blob) or len(out) < len(data), "stuck with everything delivered"
+        assert bytes(out) == data, (r, len(out), len(data))
+        assert strm.total_out == len(data)
+        assert len(blob) - pos <= len(junk) and strm.total_in == pos
+        assert lib.inflateEnd(C.byref(strm)) == Z_OK
+    return rounds
