@@ -114,3 +114,23 @@ def test_random_streaming_roundtrips():
     o = oracle_lib.load()
     for seed in range(40):
         H.random_streaming_roundtrips(lib, o, 6, seed)
+
+
+def test_random_deflate_streams(monkeypatch):
+    """randomised deflate(): level, strategy, wrapper, input pieces, output room, flush points, primed bits; the
+    system's zlib must read every stream back"""
+    import random
+    import zlib
+    monkeypatch.setenv("ZMI_ABI_SEGMENT", "8192")
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    o = oracle_lib.load()
+    rnd = random.Random(77)
+    for r in range(60):
+        n = rnd.choice([0, 1, 700, 9000, rnd.randrange(40000), rnd.randrange(150000)])
+        data = o.gen_shard(rnd.randrange(8), n)
+        wbits = rnd.choice([15, 31, -15])
+        comp = H.deflate_stream(lib, data, level=rnd.choice([1, 3, 6, 9]), wbits=wbits, chunk_in=rnd.choice([None, 1000, 7777]),
+                                chunk_out=rnd.choice([64, 4096, 100000]), flush_every=rnd.choice([None, 1, 3]),
+                                strategy=rnd.choice([0, 0, 1, 2, 3, 4]))
+        assert zlib.decompressobj(wbits).decompress(comp) == data, (r, n, wbits)
