@@ -1118,7 +1118,10 @@ int inflateCopy(z_streamp dest, z_streamp source) {
     *dest = *source;
     InflateState* d = alloc_state<InflateState>(dest);
     if (!d) { dest->state = nullptr; return Z_MEM_ERROR; }
+    std::vector<uint8_t> scratch;
+    scratch.swap(s->tmp);   // the decode target of the last attempt is no state: not copied
     *d = *s;
+    scratch.swap(s->tmp);
     dest->state = (internal_state*)d;
     return Z_OK;
     ZMI_ABI_CATCH(Z_MEM_ERROR)
