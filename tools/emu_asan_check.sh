@@ -1,0 +1,33 @@
+#!/bin/bash
+# The kernels and the host ABI code on the CPU emulator under AddressSanitizer: LDS / global overruns, host buffer
+# arithmetic (gzungetc, the inflate checkpoint bookkeeping).  Test infrastructure; takes about two minutes.
+set -e
+cd "$(dirname "$0")/.."
+make -s -C tests/emu libzmi355_emu_asan.so
+ASAN=$(gcc -print-file-name=libasan.so)
+export ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0
+LD_PRELOAD=$ASAN python - <<'PY'
+import ctypes as C, json, os, sys, tempfile, zlib
+sys.path.insert(0, "tests")
+import oracle_lib, resume_checks, zlib_abi_harness as H, zmi_ctypes
+so = os.path.join("tests", "emu", "libzmi355_emu_asan.so")
+o = oracle_lib.load()
+lib = H.bind(C.CDLL(so))
+with tempfile.TemporaryDirectory() as d:
+    H.gz_checks(lib, d, o.gen_shard(1, 60000))
+H.streaming_checks(lib, o.gen_shard(0, 40000) + o.gen_shard(3, 30000))
+for seed in range(10):
+    H.random_streaming_roundtrips(lib, o, 4, seed, max_len=30000)
+H.golden_inflate_checks(lib, json.load(open("tests/golden/inflate_vectors.json")))
+os.environ["ZMI_ABI_SEGMENT"] = "4096"
+H.run_abi_checks(lib, o, sizes=(0, 1, 100, 5000, 20000))
+H.header_copy_checks(lib, o.gen_shard(2, 40000))
+eng = zmi_ctypes.Engine(zmi_ctypes._bind(C.CDLL(so)))
+resume_checks.resume_chain_checks(eng, o, sizes=(60000, 40000, 20000, 20000), trials=2)
+shards = [o.gen_shard(i % 8, n) for i, n in enumerate([0, 1, 15, 16, 17, 1000, 4096, 9999, 20000] * 3)]
+for lvl in (1, 6, 9):
+    for strat in (0, 2, 3, 4):
+        outs, st = eng.deflate(shards, level=lvl, strategy=strat, wrap=2)
+        assert [zlib.decompress(x, 31) for x in outs] == shards
+print("asan check ok")
+PY
