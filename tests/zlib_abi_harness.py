@@ -741,7 +741,9 @@ def gz_checks(lib, tmpdir, data, syslib=None):
     f = lib.gzopen(p("d.gz").encode(), b"w")
     assert lib.gzbuffer(f, 64) == 0
     longarg = b"x" * 5000
-    assert lib.gzprintf(f, b"[%s]\n", longarg) == 5003          # longer than any internal scratch
+    assert lib.gzprintf(f, b"[%s]\n", longarg) == 0             # does not fit the buffer: nothing written (gz.rs:2729-2810)
+    assert lib.gzprintf(f, b"%s", b"y" * 64) == 0 and lib.gzprintf(f, b"%s", b"") == 0
+    assert lib.gzputc(f, ord("[")) == ord("[") and lib.gzputs(f, longarg) == 5000 and lib.gzprintf(f, b"%c%c", ord("]"), 10) == 2
     assert lib.gzputs(f, b"") == 0 and lib.gzwrite(f, src, 0) == 0
     assert lib.gzclose(f) == Z_OK
     f = lib.gzopen(p("d.gz").encode(), b"r")

@@ -541,20 +541,18 @@ int gzputs(gzFile file, const char* str) {
     GZ_CATCH(-1)
 }
 int gzvprintf(gzFile file, const char* format, va_list va) {
+    // gz.rs:2729-2810: the formatted text must fit the buffer (one less than the size given to gzbuffer(), default
+    // 128 KiB - 1); longer output writes nothing and returns 0, as in the reference
     GZ_TRY
     GzState* s = st_of(file);
     if (!s || !format) return Z_STREAM_ERROR;
     if (s->mode != GZ_WRITE || s->err != Z_OK) return Z_STREAM_ERROR;
-    va_list copy;
-    va_copy(copy, va);
-    char small[1024];
-    const int need = vsnprintf(small, sizeof small, format, copy);
-    va_end(copy);
-    if (need < 0) return 0;
-    if ((size_t)need < sizeof small) return (int)gz_write(s, (const unsigned char*)small, (size_t)need);
-    std::vector<char> big((size_t)need + 1);
-    vsnprintf(big.data(), big.size(), format, va);
-    return (int)gz_write(s, (const unsigned char*)big.data(), (size_t)need);
+    if (s->size == 0 && gz_init(s) == -1) return s->err;
+    if (s->seek) { s->seek = false; if (gz_zero(s, s->skip) == -1) return s->err; }
+    std::vector<char> text(s->size);
+    const int need = vsnprintf(text.data(), text.size(), format, va);
+    if (need <= 0 || (size_t)need >= s->size) return 0;
+    return (int)gz_write(s, (const unsigned char*)text.data(), (size_t)need);
     GZ_CATCH(Z_MEM_ERROR)
 }
 int gzprintf(gzFile file, const char* format, ...) {
