@@ -25,6 +25,8 @@
 //           holes in order; every source lies in the ring (distance <= 32 KiB), so copies are LDS -> LDS.
 // Algorithmic HBM traffic: (1/ratio) B read + 1 B written per output byte; the two-pass split adds one more
 // read and write of the output plus the bitmap (1/8 B per byte).
+// The decode kernel has a second instantiation for streams that arrive in pieces (zmi_inflate_resume_dev): it can
+// start at a bit offset and reports the last block boundary it reached, see the comment at the kernel.
 #include "zmi_device.h"
 #include "zmi_kernels.h"
 
