@@ -152,8 +152,15 @@ static __device__ __forceinline__ zmi_b16 zmi_ld16(const uint8_t* p, uint32_t nv
         uint4 v = *q;
         r.w[0] = v.x; r.w[1] = v.y; r.w[2] = v.z; r.w[3] = v.w;
     } else {
-        r.w[0] = r.w[1] = r.w[2] = r.w[3] = 0;
-        for (uint32_t i = 0; i < 16u && i < nvalid; ++i) r.w[i >> 2] |= (uint32_t)p[i] << (8u * (i & 3u));
+        // byte-wise (unaligned start or the last bytes of a shard).  Two 64-bit accumulators selected by a compare: an
+        // array indexed with the loop counter would be placed in scratch memory by the compiler.
+        uint64_t lo = 0, hi = 0;
+        const uint32_t m = nvalid < 16u ? nvalid : 16u;
+        for (uint32_t i = 0; i < m; ++i) {
+            const uint64_t b = (uint64_t)p[i] << (8u * (i & 7u));
+            if (i < 8u) lo |= b; else hi |= b;
+        }
+        r.w[0] = (uint32_t)lo; r.w[1] = (uint32_t)(lo >> 32); r.w[2] = (uint32_t)hi; r.w[3] = (uint32_t)(hi >> 32);
     }
     return r;
 }
