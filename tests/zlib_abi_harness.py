@@ -797,7 +797,17 @@ def gz_checks(lib, tmpdir, data, syslib=None):
     assert lib.gzclose(f) == Z_OK
 
 
-def golden_inflate_checks(lib, vectors, steps=(0, 1, 3, 17)):
+MESSAGES = {
+    "invalid_stored_block_length": b"invalid stored block lengths", "invalid_block_type": b"invalid block type",
+    "too_many_length_or_distance_symbols": b"too many length or distance symbols", "invalid_code_lengths_set": b"invalid code lengths set",
+    "invalid_bit_length_repeat_1": b"invalid bit length repeat", "invalid_bit_length_repeat_2": b"invalid bit length repeat",
+    "invalid_code_missing_end_of_block": b"invalid code -- missing end-of-block", "invalid_literal_lengths_set": b"invalid literal/lengths set",
+    "invalid_distances_set": b"invalid distances set", "invalid_distance_too_far_back": b"invalid distance too far back",
+    "incorrect_data_check": b"incorrect data check", "incorrect_length_check": b"incorrect length check",
+}
+
+
+def golden_inflate_checks(lib, vectors, steps=(0, 1, 3, 17), check_messages=True):
     """the reference's own inflate vectors (tests/golden/inflate_vectors.json: hand-made bitstreams with their
     expected error, test-libz-rs-sys/src/inflate.rs:734-1030, and its test-data files) through inflate(), whole and
     in steps -- the verdict must not depend on how the input arrives (inflate.rs:2376-2457)"""
@@ -830,6 +840,11 @@ def golden_inflate_checks(lib, vectors, steps=(0, 1, 3, 17)):
                 assert rc == Z_STREAM_END and bytes(got) == want, (v["source"], step, rc, len(got))
             elif v["expect"] == "data_error":
                 assert rc == Z_DATA_ERROR, (v["source"], step, rc)
+                # the vector's name in the reference's test file is its message (test-libz-rs-sys/src/inflate.rs:734-1030)
+                name = v["source"].split(":")[-1]
+                want_msg = MESSAGES.get(name)
+                if want_msg is not None and check_messages:
+                    assert strm.msg == want_msg, (name, step, strm.msg)
             else:
                 assert rc in (Z_BUF_ERROR, Z_DATA_ERROR), (v["source"], step, rc)
             assert lib.inflateEnd(C.byref(strm)) == Z_OK

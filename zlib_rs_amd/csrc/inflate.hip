@@ -34,6 +34,11 @@
 #define ZMI_TRAILER_SHORT (-1005)     // gzip: CRC present, ISIZE cut off   -> data error if CRC wrong, else buf error
 #define ZMI_LENGTH_MISMATCH (-1003)   // gzip: ISIZE wrong                  -> data error either way
 #define ZMI_NEED_OUTPUT (-1006)       // output capacity exhausted          -> Z_BUF_ERROR (detail 2)
+// data errors by cause: -3000 - k, reported as Z_DATA_ERROR with detail 16 + k (k indexes the reference's messages,
+// zlib-rs/src/inflate.rs: the strings passed to State::bad); plain ZMI_DATA_ERROR stays "cause not recorded"
+#define ZMI_DERR(k) (-3000 - (int32_t)(k))
+enum { DE_STORED_LEN = 1, DE_BLOCK_TYPE, DE_TOO_MANY_SYMS, DE_CODE_LENGTHS_SET, DE_BIT_LENGTH_REPEAT, DE_MISSING_EOB,
+       DE_LITLEN_SET, DE_DIST_SET, DE_TOO_FAR_BACK, DE_HEADER_CHECK, DE_CODE };
 #define INF_CHUNK 1024u
 #define RES_RING 36864u              // resolve pass: output history kept in LDS: 32768 + RES_SPAN + 258 + RES_BLK and slack; a
                                      // multiple of RES_BLK; with the chunk tables 39.5 KiB per stream, four streams per CU
@@ -482,7 +487,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             uint32_t l = inf_byte(B, B.ipos) | ((uint32_t)inf_byte(B, B.ipos + 1u) << 8);
             uint32_t nl = inf_byte(B, B.ipos + 2u) | ((uint32_t)inf_byte(B, B.ipos + 3u) << 8);
             B.ipos += 4u;
-            if ((l ^ 0xFFFFu) != nl) { st = ZMI_DATA_ERROR; break; }   // "invalid stored block lengths"
+            if ((l ^ 0xFFFFu) != nl) { st = ZMI_DERR(DE_STORED_LEN); break; }   // "invalid stored block lengths"
             if (B.ipos + l > B.n) { st = ZMI_BUF_ERROR; break; }
             if (opos + l > cap) { st = ZMI_NEED_OUTPUT; break; }
             for (uint32_t i = lane; i < l; i += 64u) dst[opos + i] = B.src[B.ipos + i];
@@ -490,7 +495,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             B.ipos += l;
             continue;
         }
-        if (type == 3u) { st = ZMI_DATA_ERROR; break; }  // "invalid block type"
+        if (type == 3u) { st = ZMI_DERR(DE_BLOCK_TYPE); break; }  // "invalid block type"
         if (type == 1u) {
             if (!fixed_ready) {
                 for (uint32_t i = lane; i < 288u; i += 64u) S->lens[i] = (uint8_t)(i < 144u ? 8u : (i < 256u ? 9u : (i < 280u ? 7u : 8u)));
@@ -508,7 +513,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             uint32_t nlen = inf_peek(B, 5) + 257u; inf_drop(B, 5);
             uint32_t ndist = inf_peek(B, 5) + 1u; inf_drop(B, 5);
             uint32_t ncode = inf_peek(B, 4) + 4u; inf_drop(B, 4);
-            if (nlen > 286u || ndist > 30u) { st = ZMI_DATA_ERROR; break; }  // "too many length or distance symbols"
+            if (nlen > 286u || ndist > 30u) { st = ZMI_DERR(DE_TOO_MANY_SYMS); break; }  // "too many length or distance symbols"
             const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
             if (lane < 19u) S->lens[lane] = 0;
             zmi_wave_sync();
@@ -521,7 +526,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             if (st != ZMI_OK) break;
             zmi_wave_sync();
             // code-length code table lives at the start of dtab (128 entries, root 7)
-            if (zmi_uniform(inf_build(S, 0u, 19u, S->dtab, 7u, INF_DSIZE))) { st = ZMI_DATA_ERROR; break; }  // "invalid code lengths set"
+            if (zmi_uniform(inf_build(S, 0u, 19u, S->dtab, 7u, INF_DSIZE))) { st = ZMI_DERR(DE_CODE_LENGTHS_SET); break; }  // "invalid code lengths set"
             // ---- the nlen + ndist code lengths, run-length coded with the code-length code ----
             // Same scheme as the symbol rounds below: lane i decodes the code-length token (<= 7 + 7 bits) that would
             // start at bit P + i, the real chain is walked with scalar lane reads, a wave scan places the runs.  Zero
@@ -558,7 +563,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                     uint64_t M = 0;
                     inf_walk(tw, pos, M, w);
                     int32_t rst = ZMI_OK;
-                    if (pos < 64u) rst = (w & 128u) ? ZMI_BUF_ERROR : ZMI_DATA_ERROR;
+                    if (pos < 64u) rst = (w & 128u) ? ZMI_BUF_ERROR : ZMI_DERR(DE_CODE_LENGTHS_SET);
                     bool on = (M >> lane) & 1ull;
                     const uint32_t rep = on ? (sym < 16u ? 1u : (sym == 18u ? 11u + x : 3u + x)) : 0u;
                     const uint32_t incl = zmi_wave_incl_scan(rep), excl = incl - rep;
@@ -567,7 +572,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                     const uint64_t ends = __ballot(on && have + incl == total);
                     const uint32_t kb = badrep ? (uint32_t)__ffsll((unsigned long long)badrep) - 1u : 64u;
                     const uint32_t ke = ends ? (uint32_t)__ffsll((unsigned long long)ends) - 1u : 64u;
-                    if (kb < 64u && kb <= ke) { st = ZMI_DATA_ERROR; break; }
+                    if (kb < 64u && kb <= ke) { st = ZMI_DERR(DE_BIT_LENGTH_REPEAT); break; }
                     if (ke < 64u) {   // the token in lane ke completes the header; nothing behind it belongs to it
                         M &= (2ull << ke) - 1ull;
                         on = (M >> lane) & 1ull;
@@ -603,11 +608,11 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             zmi_wave_sync();
             for (uint32_t i = lane; i < nlen; i += 64u) S->lens[i] = S->stage[i];
             zmi_wave_sync();
-            if (zmi_uniform(S->lens[256]) == 0) { st = ZMI_DATA_ERROR; break; }  // "invalid code -- missing end-of-block"
-            if (zmi_uniform(inf_build(S, 1u, nlen, S->ltab, INF_LROOT, INF_LSIZE))) { st = ZMI_DATA_ERROR; break; }  // "invalid literal/lengths set"
+            if (zmi_uniform(S->lens[256]) == 0) { st = ZMI_DERR(DE_MISSING_EOB); break; }  // "invalid code -- missing end-of-block"
+            if (zmi_uniform(inf_build(S, 1u, nlen, S->ltab, INF_LROOT, INF_LSIZE))) { st = ZMI_DERR(DE_LITLEN_SET); break; }  // "invalid literal/lengths set"
             if (lane < ndist) S->lens[lane] = S->stage[nlen + lane];
             zmi_wave_sync();
-            if (zmi_uniform(inf_build(S, 2u, ndist, S->dtab, INF_DROOT, INF_DSIZE))) { st = ZMI_DATA_ERROR; break; }  // "invalid distances set"
+            if (zmi_uniform(inf_build(S, 2u, ndist, S->dtab, INF_DROOT, INF_DSIZE))) { st = ZMI_DERR(DE_DIST_SET); break; }  // "invalid distances set"
         }
 
         // ---- symbol rounds ----
@@ -654,7 +659,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                         if (inB) MB |= 1ull << pos; else MA |= 1ull << pos;
                         pos += w & 63u;
                         eob = true;
-                    } else rst = (w & 128u) ? ZMI_BUF_ERROR : ZMI_DATA_ERROR;
+                    } else rst = (w & 128u) ? ZMI_BUF_ERROR : ZMI_DERR(DE_CODE);
                 }
                 if (inB) pos += 64u;   // bits consumed
 
@@ -692,7 +697,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                     onA = (MA >> lane) & 1ull;
                     onB = (MB >> lane) & 1ull;
                     eob = false;
-                    rst = fb ? ZMI_DATA_ERROR : ZMI_NEED_OUTPUT;
+                    rst = fb ? ZMI_DERR(DE_TOO_FAR_BACK) : ZMI_NEED_OUTPUT;
                 } else {
                     tot = zmi_readlane(inclB, 63u);
                 }
@@ -1047,6 +1052,7 @@ __global__ void __launch_bounds__(256) zmi_inflate_verify_kernel(const uint8_t* 
     int32_t st = status[s];
     int32_t det = 0;
     if (st == ZMI_NEED_OUTPUT) { st = ZMI_BUF_ERROR; det = 2; }
+    else if (st <= ZMI_DERR(1)) { det = 16 + (-3000 - st); st = ZMI_DATA_ERROR; }   // the cause travels in detail
     else if (st == ZMI_BUF_ERROR) det = 1;
     else if (st == ZMI_OK || st == ZMI_TRAILER_SHORT || st == ZMI_LENGTH_MISMATCH) {
         uint32_t kind = wrap;

@@ -559,7 +559,13 @@ int inflate_attempt(InflateState* s) {
         if (st != Z_BUF_ERROR) {
             // the bytes decoded in front of the error are valid output: they are handed out first, as the reference
             // does, and the error is reported once they are gone
-            inf_bad(s, "invalid or corrupt deflate stream");
+            // the device reports the cause in `detail` (16 + k, inflate.hip DE_*): the reference's messages (inflate.rs State::bad)
+            static const char* const kCause[] = {"invalid or corrupt deflate stream", "invalid stored block lengths", "invalid block type",
+                                                 "too many length or distance symbols", "invalid code lengths set", "invalid bit length repeat",
+                                                 "invalid code -- missing end-of-block", "invalid literal/lengths set", "invalid distances set",
+                                                 "invalid distance too far back", "incorrect header check", "invalid literal/length or distance code"};
+            const int k = det >= 16 && det < 16 + (int)(sizeof(kCause) / sizeof(kCause[0])) ? det - 16 : 0;
+            inf_bad(s, kCause[k]);
             break;
         }
         // more input or more room needed: everything in front of the checkpoint is settled
