@@ -96,6 +96,13 @@ int zmi_deflate_chain_dict_dev(zmi_ctx* ctx, const void* d_in, const uint64_t* d
                                uint32_t n_shards, uint32_t max_len, int level, int strategy, int finish,
                                uint32_t dict_len, void* d_out, uint64_t out_stride, uint32_t* d_out_len,
                                int32_t* d_status, void* stream);
+/* The chained form for a stream opened with windowBits 9..14 (deflateInit2_, zlib-rs/src/deflate.rs:252-312):
+ * back-references reach at most 2^window_bits - 262 bytes (the reference's max_dist, deflate.rs:1423-1425), so an
+ * inflater that allocates only the announced window can read the stream.  window_bits 15 = zmi_deflate_chain_dict_dev. */
+int zmi_deflate_chain_window_dev(zmi_ctx* ctx, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                 uint32_t n_shards, uint32_t max_len, int level, int strategy, int finish,
+                                 uint32_t dict_len, uint32_t window_bits, void* d_out, uint64_t out_stride,
+                                 uint32_t* d_out_len, int32_t* d_status, void* stream);
 /* As zmi_inflate_batch_dev, additionally reporting the consumed input bytes and why a stream
  * stopped (d_detail: 0 done/error, 1 needs more input, 2 needs more output space). */
 int zmi_inflate_batch_dev_ex(zmi_ctx* ctx, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,

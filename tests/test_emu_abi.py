@@ -134,3 +134,11 @@ def test_random_deflate_streams(monkeypatch):
                                 chunk_out=rnd.choice([64, 4096, 100000]), flush_every=rnd.choice([None, 1, 3]),
                                 strategy=rnd.choice([0, 0, 1, 2, 3, 4]))
         assert zlib.decompressobj(wbits).decompress(comp) == data, (r, n, wbits)
+
+
+def test_config_matrix_roundtrips(monkeypatch):
+    """end_to_end.rs's property over level x windowBits x memLevel x strategy; small windows must bound the distances"""
+    monkeypatch.setenv("ZMI_ABI_SEGMENT", "16384")
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    H.config_matrix_roundtrips(lib, oracle_lib.load(), 60, seed=5)

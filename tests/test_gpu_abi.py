@@ -107,3 +107,10 @@ def test_random_streaming_roundtrips_on_gpu():
     o = oracle_lib.load(rebuild=False)
     for seed in range(1000, 1008):
         H.random_streaming_roundtrips(lib, o, 3, seed, max_len=200000)
+
+
+def test_config_matrix_roundtrips_on_gpu():
+    """end_to_end.rs's property over level x windowBits x memLevel x strategy on the device path"""
+    from zlib_rs_amd import _build
+    lib = H.bind(C.CDLL(_build.ABI_LIB))
+    H.config_matrix_roundtrips(lib, oracle_lib.load(rebuild=False), 40, seed=11, max_len=300000)

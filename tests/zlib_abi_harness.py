@@ -46,11 +46,11 @@ def bind(lib):
     return lib
 
 
-def deflate_stream(lib, data, level=6, wbits=15, chunk_in=None, chunk_out=4096, flush_every=None, strategy=0):
+def deflate_stream(lib, data, level=6, wbits=15, chunk_in=None, chunk_out=4096, flush_every=None, strategy=0, mem_level=8):
     """the blogpost-compress.rs loop: feed input in chunks, drain output in chunks"""
     strm = ZStream()
     ver = lib.zlibVersion()
-    assert lib.deflateInit2_(C.byref(strm), level, 8, wbits, 8, strategy, ver, C.sizeof(ZStream)) == Z_OK
+    assert lib.deflateInit2_(C.byref(strm), level, 8, wbits, mem_level, strategy, ver, C.sizeof(ZStream)) == Z_OK
     src = C.create_string_buffer(data, len(data) or 1)
     out = bytearray()
     obuf = C.create_string_buffer(chunk_out)
@@ -159,7 +159,7 @@ def dictionary_checks(lib, data, zdict, expect_gain=True):
     """deflateSetDictionary / inflateSetDictionary (libz-rs-sys/src/lib.rs:1689, :1121) against system zlib"""
     import zlib
     Z_NEED_DICT = 2
-    for wbits in (15, -15):
+    for wbits in (15, -15, 10, -11):   # small windows: only the dictionary's last 2^windowBits - 262 bytes are reachable
         strm = ZStream()
         assert lib.deflateInit2_(C.byref(strm), 6, 8, wbits, 8, 0, lib.zlibVersion(), C.sizeof(ZStream)) == Z_OK
         assert lib.deflateSetDictionary(C.byref(strm), zdict, len(zdict)) == Z_OK
@@ -177,7 +177,7 @@ def dictionary_checks(lib, data, zdict, expect_gain=True):
         d = zlib.decompressobj(wbits, zdict=zdict)
         assert d.decompress(comp) + d.flush() == data
         plain = deflate_stream(lib, data, level=6, wbits=wbits)
-        if expect_gain:
+        if expect_gain and abs(wbits) == 15:
             assert len(comp) < len(plain), (len(comp), len(plain))
         # our inflate: Z_NEED_DICT for the wrapped stream, then the data; a wrong dictionary is refused
         ref = zlib.compressobj(6, zlib.DEFLATED, wbits, zdict=zdict)
@@ -902,3 +902,40 @@ def random_streaming_roundtrips(lib, o, rounds, seed, max_len=60000):
         assert len(blob) - pos <= len(junk) and strm.total_in == pos
         assert lib.inflateEnd(C.byref(strm)) == Z_OK
     return rounds
+
+
+def config_matrix_roundtrips(lib, o, rounds, seed, max_len=70000):
+    """the property of test-libz-rs-sys/src/end_to_end.rs:5-85 over DeflateConfig::arbitrary (zlib-rs/src/deflate.rs:193-219:
+    level 0-9, windowBits 9..15 / 25..31 / -15..-9, memLevel 1-9, the five strategies): whatever the configuration, an
+    inflater that allocates ONLY the announced window (the system's zlib opened with the same windowBits) reads the data
+    back, and so does this library's own inflate().  A back-reference farther than 2^windowBits - 262 would fail the first."""
+    import random
+    import zlib
+    rnd = random.Random(seed)
+    worst = 0
+    for r in range(rounds):
+        n = rnd.choice([0, 1, 600, 5000, rnd.randrange(max_len), rnd.randrange(max_len)])
+        data = o.gen_shard(rnd.randrange(8), n) if rnd.random() < 0.85 else bytes(rnd.randrange(4) for _ in range(min(n, 4000)))
+        w = rnd.randrange(9, 16)
+        wbits = rnd.choice([w, w + 16, -w])
+        level, strategy, mem_level = rnd.randrange(0, 10), rnd.randrange(0, 5), rnd.randrange(1, 10)
+        comp = deflate_stream(lib, data, level=level, wbits=wbits, chunk_in=rnd.choice([None, None, 3000, 20000]),
+                              chunk_out=rnd.choice([100, 4096, 200000]), flush_every=rnd.choice([None, 2]), strategy=strategy,
+                              mem_level=mem_level)
+        cfg = (r, n, level, wbits, mem_level, strategy)
+        d = zlib.decompressobj(wbits)
+        assert d.decompress(comp) == data and d.eof and not d.unused_data, cfg
+        rc, out, unused = inflate_stream(lib, comp, wbits, chunk_in=rnd.choice([1 << 30, 1000]), chunk_out=rnd.choice([8192, 100000]))
+        assert rc == Z_STREAM_END and out == data and unused == 0, cfg
+        if wbits > 0 and wbits < 16:   # the zlib header announces the window (CINFO = windowBits - 8, deflate.rs:1572-1589)
+            assert (comp[0] >> 4) + 8 == w and ((comp[0] << 8) | comp[1]) % 31 == 0, cfg
+        if n:
+            worst = max(worst, len(comp) - n)
+    # windowBits 8 is accepted for the zlib wrapper only and means 9 (deflate.rs:293-301)
+    data = o.gen_shard(1, 9000)
+    comp = deflate_stream(lib, data, level=6, wbits=8)
+    assert comp[0] == 0x18 and zlib.decompressobj(9).decompress(comp) == data
+    strm = ZStream()
+    for bad in (-8, 24, 7, 16, 32, -16):
+        assert lib.deflateInit2_(C.byref(strm), 6, 8, bad, 8, 0, lib.zlibVersion(), C.sizeof(ZStream)) == Z_STREAM_ERROR, bad
+    return worst

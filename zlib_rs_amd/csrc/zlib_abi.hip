@@ -26,6 +26,10 @@ extern "C" int zmi_deflate_chain_dev(zmi_ctx* c, const void* d_in, const uint64_
 extern "C" int zmi_deflate_chain_dict_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                           uint32_t n, uint32_t max_len, int level, int strategy, int finish, uint32_t dict_len,
                                           void* d_out, uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream);
+extern "C" int zmi_deflate_chain_window_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                            uint32_t n, uint32_t max_len, int level, int strategy, int finish, uint32_t dict_len,
+                                            uint32_t window_bits, void* d_out, uint64_t out_stride, uint32_t* d_out_len,
+                                            int32_t* d_status, void* stream);
 extern "C" int zmi_checksum_batch_dev(zmi_ctx* c, const void* d_data, const uint64_t* d_off, const uint32_t* d_len, uint32_t n,
                                       int kind, uint32_t* d_adler, uint32_t* d_crc, void* stream);
 extern "C" int zmi_ctx_set_inflate_out_limit(zmi_ctx* c, uint64_t bytes);
@@ -151,7 +155,8 @@ size_t segment_bytes() {  // 1 MiB segments; ZMI_ABI_SEGMENT (bytes, multiple of
 // wrap 1 / 2: *check receives the Adler-32 / CRC-32 of the n bytes (per segment on the GPU, where the data is;
 // stitched with the combine algebra, crc32/combine.rs, adler32 combine lib.rs:372)
 int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_t hist_len, int level, int strategy, bool finish,
-                         std::vector<uint8_t>& out, int wrap = 0, uint32_t* check = nullptr, size_t* last_at = nullptr) {
+                         std::vector<uint8_t>& out, int wrap = 0, uint32_t* check = nullptr, size_t* last_at = nullptr,
+                         int wbits = 15) {
     if (check) *check = wrap == 1 ? 1u : 0u;
     if (last_at) *last_at = out.size();
     if (n == 0) {
@@ -182,9 +187,10 @@ int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_
     if (hipMemcpy((uint8_t*)d_in.p + base, in, n, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
     if (hipMemcpy(d_off.p, off.data(), nseg * 8, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
     if (hipMemcpy(d_len.p, len.data(), nseg * 4, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
-    if (zmi_deflate_chain_dict_dev(c, d_in.p, (const uint64_t*)d_off.p, (const uint32_t*)d_len.p, nseg, max_len, level, strategy,
-                                   finish ? 1 : 0, (uint32_t)hist_len, d_out.p, stride, (uint32_t*)d_olen.p, (int32_t*)d_st.p,
-                                   nullptr) != 0)
+    // windowBits < 15: distances stay inside the window the header announces (deflate.rs:1423-1425)
+    if (zmi_deflate_chain_window_dev(c, d_in.p, (const uint64_t*)d_off.p, (const uint32_t*)d_len.p, nseg, max_len, level, strategy,
+                                     finish ? 1 : 0, (uint32_t)hist_len, (uint32_t)wbits, d_out.p, stride, (uint32_t*)d_olen.p,
+                                     (int32_t*)d_st.p, nullptr) != 0)
         return Z_MEM_ERROR;
     DevBuf d_sum;
     if (check && wrap != 0) {
@@ -451,7 +457,7 @@ int compress_buffered(DeflateState* s, bool finish, bool full_flush = false) {
     uint32_t part = 0;   // checksum of this call's input, computed on the GPU next to the compression
     size_t last_at = 0;
     int rc = gpu_deflate_segments(s->in.data(), s->in.size(), s->hist.data(), s->hist.size(), s->level, s->strategy, finish, s->pending,
-                                  s->wrap, &part, &last_at);
+                                  s->wrap, &part, &last_at, s->wbits);
     if (rc == Z_OK) {
         s->last_seg.assign(s->pending.begin() + last_at, s->pending.end());
         s->last_seg_final = finish;

@@ -221,12 +221,13 @@ extern "C" int zmi_gen_shards_dev(zmi_ctx* c, void* d_out, uint64_t seed, uint32
 
 static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
                             uint32_t max_len, int level, int strategy, int wrap, uint32_t chain_mode, uint32_t dict_len,
-                            void* d_out, uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_);
+                            uint32_t window_bits, void* d_out, uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status,
+                            void* stream_);
 
 extern "C" int zmi_deflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                      uint32_t n, uint32_t max_len, int level, int strategy, int wrap, void* d_out,
                                      uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_) {
-    return zmi_deflate_impl(c, d_in, d_in_off, d_in_len, n, max_len, level, strategy, wrap, 0u, 0u, d_out, out_stride,
+    return zmi_deflate_impl(c, d_in, d_in_off, d_in_len, n, max_len, level, strategy, wrap, 0u, 0u, 15u, d_out, out_stride,
                             d_out_len, d_status, stream_);
 }
 
@@ -237,7 +238,7 @@ extern "C" int zmi_deflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_
 extern "C" int zmi_deflate_chain_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                      uint32_t n, uint32_t max_len, int level, int strategy, int finish, void* d_out,
                                      uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_) {
-    return zmi_deflate_impl(c, d_in, d_in_off, d_in_len, n, max_len, level, strategy, ZMI_WRAP_RAW, finish ? 1u : 2u, 0u,
+    return zmi_deflate_impl(c, d_in, d_in_off, d_in_len, n, max_len, level, strategy, ZMI_WRAP_RAW, finish ? 1u : 2u, 0u, 15u,
                             d_out, out_stride, d_out_len, d_status, stream_);
 }
 
@@ -249,12 +250,25 @@ extern "C" int zmi_deflate_chain_dict_dev(zmi_ctx* c, const void* d_in, const ui
                                           void* d_out, uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status,
                                           void* stream_) {
     return zmi_deflate_impl(c, d_in, d_in_off, d_in_len, n, max_len, level, strategy, ZMI_WRAP_RAW, finish ? 1u : 2u, dict_len,
-                            d_out, out_stride, d_out_len, d_status, stream_);
+                            15u, d_out, out_stride, d_out_len, d_status, stream_);
+}
+
+// The chained form for a stream opened with windowBits < 15 (deflateInit2_, zlib-rs/src/deflate.rs:252-312): no
+// back-reference may reach farther than the reference's max_dist = 2^windowBits - MIN_LOOKAHEAD (deflate.rs:1423-1425),
+// or an inflater that allocates the window the header announces rejects the stream ("invalid distance too far back").
+extern "C" int zmi_deflate_chain_window_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
+                                            uint32_t n, uint32_t max_len, int level, int strategy, int finish, uint32_t dict_len,
+                                            uint32_t window_bits, void* d_out, uint64_t out_stride, uint32_t* d_out_len,
+                                            int32_t* d_status, void* stream_) {
+    if (window_bits < 9u || window_bits > 15u) return zmi_fail(ZMI_E_ARG, "window_bits must be 9..15");
+    return zmi_deflate_impl(c, d_in, d_in_off, d_in_len, n, max_len, level, strategy, ZMI_WRAP_RAW, finish ? 1u : 2u, dict_len,
+                            window_bits, d_out, out_stride, d_out_len, d_status, stream_);
 }
 
 static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,
                             uint32_t max_len, int level, int strategy, int wrap, uint32_t chain_mode, uint32_t dict_len,
-                            void* d_out, uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream_) {
+                            uint32_t window_bits, void* d_out, uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status,
+                            void* stream_) {
     if (!c) return zmi_fail(ZMI_E_ARG, "null context");
     if (level == -1) level = 6;
     if (level < 0 || level > 9) return zmi_fail(ZMI_E_ARG, "level must be -1..9");
@@ -284,12 +298,13 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     lp.nice_len = L.nice;
     lp.good_len = L.good;
     lp.max_dist = 32768u;  // clamped to the ring-buffer limit by the launcher
+    if (window_bits < 15u) lp.max_dist = (1u << window_bits) - 262u;   // w_size - MIN_LOOKAHEAD (deflate.rs:1423-1425)
     lp.hash6 = 1u;  // 6-byte-hash chain + one 4-byte probe: ~1.5x fewer chain steps than a 4-byte chain at equal ratio
     lp.claim = 64u;
     const char* claim_env = getenv("ZMI_CLAIM");
     if (claim_env) lp.claim = (uint32_t)atoi(claim_env);
     const char* md_env = getenv("ZMI_MAXDIST");
-    if (md_env && atoi(md_env) > 0) lp.max_dist = (uint32_t)atoi(md_env);
+    if (md_env && atoi(md_env) > 0 && (uint32_t)atoi(md_env) < lp.max_dist) lp.max_dist = (uint32_t)atoi(md_env);
     const char* h6_env = getenv("ZMI_HASH6");
     if (h6_env) lp.hash6 = atoi(h6_env) ? 1u : 0u;
     zmi_enc_params ep;
