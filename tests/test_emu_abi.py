@@ -142,3 +142,10 @@ def test_config_matrix_roundtrips(monkeypatch):
     zmi_ctypes.load_emu()
     lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
     H.config_matrix_roundtrips(lib, oracle_lib.load(), 60, seed=5)
+
+
+def test_misc_entry_points():
+    """allocators, deflateBound as a guarantee, deflateParams / Tune / ResetKeep / inflateReset2, _z one-shots, combine operators"""
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    H.misc_symbol_checks(lib, oracle_lib.load())

@@ -114,3 +114,10 @@ def test_config_matrix_roundtrips_on_gpu():
     from zlib_rs_amd import _build
     lib = H.bind(C.CDLL(_build.ABI_LIB))
     H.config_matrix_roundtrips(lib, oracle_lib.load(rebuild=False), 40, seed=11, max_len=300000)
+
+
+def test_misc_entry_points_on_gpu():
+    """allocators, deflateBound as a guarantee, deflateParams / Tune / ResetKeep / inflateReset2, _z one-shots, combine operators"""
+    from zlib_rs_amd import _build
+    lib = H.bind(C.CDLL(_build.ABI_LIB))
+    H.misc_symbol_checks(lib, oracle_lib.load(rebuild=False))

@@ -2,9 +2,11 @@
 reference's own examples (test-libz-rs-sys/examples/blogpost-compress.rs:43-122,
 blogpost-uncompress.rs:6-44, libz-rs-sys-cdylib/zpipe.c) make."""
 import ctypes as C
+import os
 
 Z_NO_FLUSH, Z_SYNC_FLUSH, Z_FULL_FLUSH, Z_FINISH = 0, 2, 3, 4
 Z_OK, Z_STREAM_END, Z_DATA_ERROR, Z_BUF_ERROR, Z_STREAM_ERROR, Z_VERSION_ERROR = 0, 1, -3, -5, -2, -6
+Z_MEM_ERROR = -4
 
 
 class ZStream(C.Structure):
@@ -939,3 +941,168 @@ def config_matrix_roundtrips(lib, o, rounds, seed, max_len=70000):
     for bad in (-8, 24, 7, 16, 32, -16):
         assert lib.deflateInit2_(C.byref(strm), 6, 8, bad, 8, 0, lib.zlibVersion(), C.sizeof(ZStream)) == Z_STREAM_ERROR, bad
     return worst
+
+
+def misc_symbol_checks(lib, o):
+    """the entry points nothing else drives: caller-supplied allocators (the fault-injecting zalloc of
+    test-libz-rs-sys/src/inflate.rs:31-160 / zlib-rs/src/deflate.rs:3428-3444), deflateBound as a guarantee,
+    deflateParams / deflateTune / *ResetKeep / inflateReset2, the _z one-shots, the combine operators, get_crc_table"""
+    import random
+    import zlib
+    ver, zs = lib.zlibVersion(), C.sizeof(ZStream)
+    P = C.POINTER(ZStream)
+    # --- allocators: the state is obtained through zalloc and returned through zfree; a failing zalloc is Z_MEM_ERROR
+    libc = C.CDLL(None)
+    libc.malloc.restype, libc.malloc.argtypes, libc.free.argtypes = C.c_void_p, [C.c_size_t], [C.c_void_p]
+    live, fail = {}, [False]
+
+    def za(opaque, items, size):
+        if fail[0]:
+            return None
+        p = libc.malloc(items * size)
+        live[p] = items * size
+        return p
+
+    def zf(opaque, p):
+        assert p in live, "zfree of a pointer zalloc never returned"
+        del live[p]
+        libc.free(p)
+    za_c, zf_c = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_uint, C.c_uint)(za), C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)(zf)
+    data = o.gen_shard(3, 30000)
+    for failing in (True, False):
+        fail[0] = failing
+        s = ZStream()
+        s.zalloc, s.zfree = C.cast(za_c, C.c_void_p), C.cast(zf_c, C.c_void_p)
+        rc = lib.deflateInit2_(C.byref(s), 6, 8, 15, 8, 0, ver, zs)
+        assert rc == (Z_MEM_ERROR if failing else Z_OK) and bool(s.state) == (not failing)
+        if not failing:
+            assert len(live) >= 1
+            cap = lib.deflateBound(C.byref(s), len(data))
+            src, dst = C.create_string_buffer(data, len(data)), C.create_string_buffer(cap)
+            s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), len(data), C.addressof(dst), cap
+            assert lib.deflate(C.byref(s), Z_FINISH) == Z_STREAM_END
+            comp = dst.raw[:cap - s.avail_out]
+            assert lib.deflateEnd(C.byref(s)) == Z_OK and not live
+        s = ZStream()
+        s.zalloc, s.zfree = C.cast(za_c, C.c_void_p), C.cast(zf_c, C.c_void_p)
+        rc = lib.inflateInit2_(C.byref(s), 15, ver, zs)
+        assert rc == (Z_MEM_ERROR if failing else Z_OK) and bool(s.state) == (not failing)
+        if not failing:
+            src, dst = C.create_string_buffer(comp, len(comp)), C.create_string_buffer(len(data))
+            s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), len(comp), C.addressof(dst), len(data)
+            assert lib.inflate(C.byref(s), Z_FINISH) == Z_STREAM_END and dst.raw == data
+            assert lib.inflateEnd(C.byref(s)) == Z_OK and not live
+    # --- deflateBound is a guarantee: one deflate(Z_FINISH) into that much room ends the stream, whatever the configuration
+    rnd = random.Random(3)
+    for r in range(60):
+        n = rnd.choice([0, 1, 2, 5, 8, 9, 10, 100, 1000, 65535, 65536, 70000, rnd.randrange(150000)])
+        raw = os.urandom(n) if r % 2 else bytes(rnd.randrange(200, 256) for _ in range(n))
+        w = rnd.randrange(9, 16)
+        wbits = rnd.choice([w, w + 16, -w])
+        cfg = (n, rnd.randrange(10), wbits, rnd.randrange(1, 10), rnd.randrange(5))
+        s = ZStream()
+        assert lib.deflateInit2_(C.byref(s), cfg[1], 8, wbits, cfg[3], cfg[4], ver, zs) == Z_OK
+        cap = lib.deflateBound(C.byref(s), n)
+        src, dst = C.create_string_buffer(raw, n or 1), C.create_string_buffer(cap)
+        s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), n, C.addressof(dst), cap
+        assert lib.deflate(C.byref(s), Z_FINISH) == Z_STREAM_END, cfg
+        assert zlib.decompressobj(wbits).decompress(dst.raw[:cap - s.avail_out]) == raw, cfg
+        assert lib.deflateEnd(C.byref(s)) == Z_OK
+    # --- deflateParams between two halves (lib.rs:1658, deflate.rs:441-497); deflateTune accepted; out-of-range refused
+    lib.deflateParams.argtypes = [P, C.c_int, C.c_int]
+    lib.deflateTune.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int]
+    for (l0, s0), (l1, s1) in (((1, 0), (9, 0)), ((6, 0), (0, 0)), ((0, 0), (6, 0)), ((6, 0), (6, 3)), ((6, 2), (4, 1)), ((6, 0), (-1, 4))):
+        s = ZStream()
+        assert lib.deflateInit2_(C.byref(s), l0, 8, 15, 8, s0, ver, zs) == Z_OK
+        assert lib.deflateTune(C.byref(s), 4, 8, 32, 64) == Z_OK
+        assert lib.deflateParams(C.byref(s), 10, 0) == Z_STREAM_ERROR and lib.deflateParams(C.byref(s), 6, 5) == Z_STREAM_ERROR
+        half = len(data) // 2
+        src, dst = C.create_string_buffer(data, len(data)), C.create_string_buffer(len(data) + 1000)
+        s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), half, C.addressof(dst), len(data) + 1000
+        assert lib.deflate(C.byref(s), Z_NO_FLUSH) == Z_OK
+        assert lib.deflateParams(C.byref(s), l1, s1) == Z_OK and s.avail_in == 0
+        s.avail_in = len(data) - half
+        assert lib.deflate(C.byref(s), Z_FINISH) == Z_STREAM_END
+        assert zlib.decompress(dst.raw[:len(data) + 1000 - s.avail_out]) == data, (l0, s0, l1, s1)
+        assert lib.deflateEnd(C.byref(s)) == Z_OK
+    assert lib.deflateParams(None, 6, 0) == Z_STREAM_ERROR and lib.deflateTune(None, 1, 1, 1, 1) == Z_STREAM_ERROR
+    # --- deflateResetKeep / inflateReset2: the stream object serves a second, differently wrapped, stream
+    lib.deflateResetKeep.argtypes = [P]
+    lib.inflateReset2.argtypes = [P, C.c_int]
+    s = ZStream()
+    assert lib.deflateInit2_(C.byref(s), 6, 8, 31, 8, 0, ver, zs) == Z_OK
+    outs = []
+    for part in (data[:1000], data[1000:9000]):
+        src, dst = C.create_string_buffer(part, len(part)), C.create_string_buffer(len(part) + 100)
+        s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), len(part), C.addressof(dst), len(part) + 100
+        assert lib.deflate(C.byref(s), Z_FINISH) == Z_STREAM_END
+        outs.append(dst.raw[:len(part) + 100 - s.avail_out])
+        assert s.total_in == len(part)
+        assert lib.deflateResetKeep(C.byref(s)) == Z_OK and s.total_in == 0 and s.total_out == 0
+    assert lib.deflateEnd(C.byref(s)) == Z_OK
+    assert zlib.decompress(outs[0], 31) == data[:1000] and zlib.decompress(outs[1], 31) == data[1000:9000]
+    s = ZStream()
+    assert lib.inflateInit2_(C.byref(s), 15, ver, zs) == Z_OK
+    for wb, blob, want in ((31, outs[1], data[1000:9000]), (-15, zlib.compress(data, 6)[2:-4], data), (47, zlib.compress(data), data)):
+        assert lib.inflateReset2(C.byref(s), wb) == Z_OK
+        src, dst = C.create_string_buffer(blob, len(blob)), C.create_string_buffer(len(want))
+        s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), len(blob), C.addressof(dst), len(want)
+        assert lib.inflate(C.byref(s), Z_FINISH) == Z_STREAM_END and dst.raw == want, wb
+    assert lib.inflateReset2(C.byref(s), 7) == Z_STREAM_ERROR and lib.inflateReset2(C.byref(s), 64) == Z_STREAM_ERROR
+    lib.inflateUndermine.argtypes = [P, C.c_int]
+    lib.inflateCodesUsed.argtypes, lib.inflateCodesUsed.restype = [P], C.c_ulong
+    assert lib.inflateUndermine(C.byref(s), 1) in (Z_OK, Z_DATA_ERROR) and lib.inflateUndermine(None, 1) == Z_STREAM_ERROR
+    assert lib.inflateCodesUsed(C.byref(s)) < 1332 + 592 + 1   # never more than ENOUGH (zlib-rs/src/lib.rs:88-102)
+    assert lib.inflateEnd(C.byref(s)) == Z_OK
+    # --- the _z one-shots (lib.rs:1379-1561, :433-583)
+    zsz = C.c_size_t
+    lib.compressBound_z.restype, lib.compressBound_z.argtypes = zsz, [zsz]
+    lib.compress_z.argtypes = [C.c_void_p, C.POINTER(zsz), C.c_void_p, zsz]
+    lib.compress2_z.argtypes = [C.c_void_p, C.POINTER(zsz), C.c_void_p, zsz, C.c_int]
+    lib.uncompress_z.argtypes = [C.c_void_p, C.POINTER(zsz), C.c_void_p, zsz]
+    lib.uncompress2_z.argtypes = [C.c_void_p, C.POINTER(zsz), C.c_void_p, C.POINTER(zsz)]
+    for n, want in ((1024, 1161), (4096, 4617), (65536, 73737)):     # doctest of compress_bound, deflate.rs:2966-2968
+        assert lib.compressBound_z(n) == want == lib.compressBound(n)
+    cap = zsz(lib.compressBound_z(len(data)))
+    dst = C.create_string_buffer(cap.value)
+    assert lib.compress_z(dst, C.byref(cap), data, len(data)) == Z_OK and zlib.decompress(dst.raw[:cap.value]) == data
+    cap9 = zsz(lib.compressBound_z(len(data)))
+    dst9 = C.create_string_buffer(cap9.value)
+    assert lib.compress2_z(dst9, C.byref(cap9), data, len(data), 9) == Z_OK and zlib.decompress(dst9.raw[:cap9.value]) == data
+    small = zsz(10)
+    assert lib.compress2_z(dst9, C.byref(small), data, len(data), 6) == Z_BUF_ERROR
+    assert lib.compress2_z(dst9, C.byref(cap9), data, len(data), 11) == Z_STREAM_ERROR
+    blob = dst.raw[:cap.value] + b"xyz"
+    ocap, icap = zsz(len(data)), zsz(len(blob))
+    back = C.create_string_buffer(len(data))
+    assert lib.uncompress2_z(back, C.byref(ocap), blob, C.byref(icap)) == Z_OK and back.raw == data and icap.value == cap.value
+    ocap = zsz(len(data))
+    assert lib.uncompress_z(back, C.byref(ocap), blob, cap.value) == Z_OK and ocap.value == len(data)
+    # --- checksum variants and the combine operators (lib.rs:149-412; crc32/combine.rs)
+    for f in ("adler32_z", "crc32_z"):
+        getattr(lib, f).restype, getattr(lib, f).argtypes = C.c_ulong, [C.c_ulong, C.c_void_p, zsz]
+    assert lib.crc32_z(0, bytes([1, 2, 3]), 3) == 1438416925                      # lib.rs:146,179
+    assert lib.adler32_z(1, data, len(data)) == zlib.adler32(data) and lib.crc32_z(0, data, len(data)) == zlib.crc32(data)
+    assert lib.adler32_z(7, None, 0) == 1 and lib.crc32_z(7, None, 0) == 0           # NULL buffer = the initial value
+    for f, a in (("adler32_combine64", C.c_longlong), ("crc32_combine64", C.c_longlong)):
+        getattr(lib, f).restype, getattr(lib, f).argtypes = C.c_ulong, [C.c_ulong, C.c_ulong, a]
+    lib.crc32_combine_gen.restype, lib.crc32_combine_gen.argtypes = C.c_ulong, [C.c_long]
+    lib.crc32_combine_gen64.restype, lib.crc32_combine_gen64.argtypes = C.c_ulong, [C.c_longlong]
+    lib.crc32_combine_op.restype, lib.crc32_combine_op.argtypes = C.c_ulong, [C.c_ulong, C.c_ulong, C.c_ulong]
+    for k in (0, 1, 777, len(data) - 1, len(data)):
+        a, b = data[:k], data[k:]
+        assert lib.adler32_combine64(zlib.adler32(a), zlib.adler32(b), len(b)) == zlib.adler32(data)
+        assert lib.crc32_combine64(zlib.crc32(a), zlib.crc32(b), len(b)) == zlib.crc32(data)
+        op = lib.crc32_combine_gen(len(b))
+        assert op == lib.crc32_combine_gen64(len(b))
+        assert lib.crc32_combine_op(zlib.crc32(a), zlib.crc32(b), op) == zlib.crc32(data)
+    lib.get_crc_table.restype = C.POINTER(C.c_uint32)
+    t = lib.get_crc_table()
+    for i in (0, 1, 2, 128, 255):
+        c = i
+        for _ in range(8):
+            c = (c >> 1) ^ (0xEDB88320 if c & 1 else 0)
+        assert t[i] == c
+    lib.zlibCompileFlags.restype = C.c_ulong
+    fl = lib.zlibCompileFlags()
+    assert fl == (1 | 2 << 2 | 2 << 4 | 2 << 6)      # uInt 32 bit; uLong, pointers, z_off_t 64 bit; no feature bits (lib.rs:2219-2270)

@@ -715,7 +715,12 @@ size_t inflate_drain(z_streamp strm, InflateState* s) {
 extern "C" {
 
 const char* zlibVersion(void) { return ZLIB_VERSION; }
-uLong zlibCompileFlags(void) { return (uLong)(sizeof(uInt) / 2 - 1) | ((sizeof(uLong) / 2 - 1) << 2) | ((sizeof(void*) / 2 - 1) << 4) | ((sizeof(long) / 2 - 1) << 6); }
+// lib.rs:2219-2270: sizes of uInt / uLong / voidpf / z_off_t in two bits each (2 -> 0, 4 -> 1, 8 -> 2, other -> 3); every
+// optional-feature bit is 0, as in the reference
+static constexpr uLong size_code(size_t n) { return n == 2 ? 0u : (n == 4 ? 1u : (n == 8 ? 2u : 3u)); }
+uLong zlibCompileFlags(void) {
+    return size_code(sizeof(uInt)) | (size_code(sizeof(uLong)) << 2) | (size_code(sizeof(void*)) << 4) | (size_code(sizeof(long)) << 6);
+}
 const char* zError(int err) { int i = 2 - err; return (i >= 0 && i < 10) ? kErrMsg[i] : ""; }
 
 // ---------------------------------------------------------------- deflate
