@@ -211,3 +211,41 @@ def test_host_batch_pipeline_chunks(monkeypatch):
         assert all(got[i] == shards[i] for i in range(len(shards)) if i != 5)
     finally:
         eng.close()
+
+
+def test_batch_api_argument_errors(eng):
+    """the batch entry points refuse bad arguments with ZMI_E_ARG and a message, and an empty batch is a no-op"""
+    import ctypes as C
+    import numpy as np
+    lib, E_ARG = eng.lib, -103
+    data = np.frombuffer(b"hello hello hello hello" + bytes(9), dtype=np.uint8).copy()
+    off, ln = np.zeros(1, np.uint64), np.array([23], np.uint32)
+    stride = int(lib.zmi_deflate_bound(23, 1))
+    assert stride % 16 == 0 and stride >= 23 + 11
+    out, olen, st = np.zeros(stride, np.uint8), np.zeros(1, np.uint32), np.zeros(1, np.int32)
+    u64p, u32p, i32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int32)
+
+    def call(ctx=eng.ctx, n=1, level=6, strategy=0, wrap=1, stride=stride):
+        return lib.zmi_deflate_batch(ctx, data.ctypes.data, off.ctypes.data_as(u64p), ln.ctypes.data_as(u32p), n, level, strategy,
+                                     wrap, out.ctypes.data, stride, olen.ctypes.data_as(u32p), st.ctypes.data_as(i32p))
+    assert call() == 0 and st[0] == 0 and zlib.decompress(bytes(out[:olen[0]])) == bytes(data[:23])
+    assert call(level=-1) == 0          # Z_DEFAULT_COMPRESSION
+    for kw in (dict(ctx=None), dict(level=10), dict(level=-2), dict(strategy=5), dict(strategy=-1), dict(wrap=3), dict(wrap=-1),
+               dict(stride=stride - 16), dict(stride=stride + 8)):
+        assert call(**kw) == E_ARG, kw
+        assert lib.zmi_last_error()
+    assert call(n=0) == 0
+    comp = np.frombuffer(zlib.compress(bytes(data[:23])) + bytes(8), dtype=np.uint8).copy()
+    clen, cap, ooff = np.array([len(comp) - 8], np.uint32), np.array([64], np.uint32), np.zeros(1, np.uint64)
+    back = np.zeros(64, np.uint8)
+
+    def icall(ctx=eng.ctx, n=1, wrap=1):
+        return lib.zmi_inflate_batch(ctx, comp.ctypes.data, off.ctypes.data_as(u64p), clen.ctypes.data_as(u32p), n, wrap,
+                                     back.ctypes.data, ooff.ctypes.data_as(u64p), cap.ctypes.data_as(u32p),
+                                     olen.ctypes.data_as(u32p), st.ctypes.data_as(i32p))
+    assert icall() == 0 and st[0] == 0 and bytes(back[:olen[0]]) == bytes(data[:23])
+    assert icall(wrap=3) == 0 and st[0] == 0       # ZMI_WRAP_AUTO: zlib or gzip by the first bytes (inflate.rs:2298-2327, +32)
+    assert icall(wrap=2) == 0 and st[0] == -3      # a zlib stream is not a gzip member: per-stream Z_DATA_ERROR, the call succeeds
+    for kw in (dict(ctx=None), dict(wrap=4), dict(wrap=-1)):
+        assert icall(**kw) == E_ARG, kw
+    assert icall(n=0) == 0
