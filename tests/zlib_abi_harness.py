@@ -1008,6 +1008,60 @@ def misc_symbol_checks(lib, o):
         assert lib.deflate(C.byref(s), Z_FINISH) == Z_STREAM_END, cfg
         assert zlib.decompressobj(wbits).decompress(dst.raw[:cap - s.avail_out]) == raw, cfg
         assert lib.deflateEnd(C.byref(s)) == Z_OK
+    # --- deflateBound follows the stream's wrapper (deflate.rs:3193-3287; test-libz-rs-sys deflate.rs:620-675): the gzip header
+    # fields handed in with deflateSetHeader count, a preset dictionary adds the 4-byte DICTID, no stream = the zlib wrapper
+    lib.deflateSetHeader.argtypes = [P, C.POINTER(GzHeader)]
+    n = len(data)
+    comp_len = n + ((n + 7) >> 3) + ((n + 63) >> 6) + 5
+    assert lib.deflateBound(None, n) == comp_len + 6
+    for wb, lvl, want in ((15, 6, n + ((n + 7) >> 3) + 3 + 6), (-15, 6, n + ((n + 7) >> 3) + 3), (31, 6, n + ((n + 7) >> 3) + 3 + 18),
+                          (12, 6, comp_len + 6), (-12, 0, n + (n >> 5) + (n >> 7) + (n >> 11) + 7), (28, 3, comp_len + 18)):
+        s = ZStream()
+        assert lib.deflateInit2_(C.byref(s), lvl, 8, wb, 8, 0, ver, zs) == Z_OK
+        assert lib.deflateBound(C.byref(s), n) == want, (wb, lvl)
+        if wb == 15:
+            assert lib.deflateSetDictionary(C.byref(s), data[:100], 100) == Z_OK and lib.deflateBound(C.byref(s), n) == want + 4
+        assert lib.deflateEnd(C.byref(s)) == Z_OK
+    extra, name, comment = C.create_string_buffer(b"EXTRA-FIELD", 11), C.create_string_buffer(b"a-file-name.txt"), C.create_string_buffer(b"c" * 300)
+    s = ZStream()
+    assert lib.deflateInit2_(C.byref(s), 9, 8, 31, 3, 4, ver, zs) == Z_OK
+    h = GzHeader(text=-1, time=1234567, os=7, extra=C.addressof(extra), extra_len=11, name=C.addressof(name), comment=C.addressof(comment), hcrc=-1)
+    assert lib.deflateSetHeader(C.byref(s), C.byref(h)) == Z_OK
+    cap = lib.deflateBound(C.byref(s), 5)
+    assert cap == 5 + 1 + 1 + 3 + 18 + (2 + 11) + 16 + 301 + 2
+    src, dst = C.create_string_buffer(b"hello", 5), C.create_string_buffer(cap)
+    s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), 5, C.addressof(dst), cap
+    assert lib.deflate(C.byref(s), Z_FINISH) == Z_STREAM_END
+    gz = dst.raw[:cap - s.avail_out]
+    assert gz[3] == 0x1F and gz[9] == 7          # FTEXT | FHCRC | FEXTRA | FNAME | FCOMMENT: text / hcrc are "!= 0" (deflate.rs test :678)
+    assert zlib.decompress(gz, 31) == b"hello"
+    assert lib.deflateEnd(C.byref(s)) == Z_OK
+    # --- a one-shot into too little room is Z_BUF_ERROR at every size below the need (test_issue_455, test-libz-rs-sys deflate.rs:3078)
+    lib.compress.argtypes = [C.c_void_p, C.POINTER(C.c_ulong), C.c_void_p, C.c_ulong]
+    tiny = bytes([0, 0, 0, 0, 252, 0, 0, 62, 255, 255, 255, 42, 255, 255, 247, 255, 247, 255, 255, 255, 156, 70, 255, 255])
+    dst, ln = C.create_string_buffer(64), C.c_ulong(64)
+    assert lib.compress(dst, C.byref(ln), tiny, len(tiny)) == Z_OK and zlib.decompress(dst.raw[:ln.value]) == tiny
+    need = ln.value
+    for room in range(need + 1):
+        ln = C.c_ulong(room)
+        assert lib.compress(dst, C.byref(ln), tiny, len(tiny)) == (Z_OK if room >= need else Z_BUF_ERROR), room
+    # --- deflateReset leaves nothing of the earlier stream behind (reset_deterministic, deflate.rs:3101-3190, issue 459)
+    def one(strm, d):
+        src, dst = C.create_string_buffer(d, len(d)), C.create_string_buffer(1024)
+        strm.next_in, strm.avail_in, strm.next_out, strm.avail_out = C.addressof(src), len(d), C.addressof(dst), 1024
+        assert lib.deflate(C.byref(strm), Z_FINISH) == Z_STREAM_END
+        return dst.raw[:strm.total_out]
+    da = b"\0AAAA\0AAAAAAAA"
+    s = ZStream()
+    assert lib.deflateInit2_(C.byref(s), 6, 8, 15, 8, 0, ver, zs) == Z_OK
+    first = one(s, da)
+    assert lib.deflateEnd(C.byref(s)) == Z_OK
+    s = ZStream()
+    assert lib.deflateInit2_(C.byref(s), 6, 8, 15, 8, 0, ver, zs) == Z_OK
+    one(s, bytes([1]) * (len(da) + 1))
+    assert lib.deflateReset(C.byref(s)) == Z_OK
+    assert one(s, da) == first and zlib.decompress(first) == da
+    assert lib.deflateEnd(C.byref(s)) == Z_OK
     # --- deflateParams between two halves (lib.rs:1658, deflate.rs:441-497); deflateTune accepted; out-of-range refused
     lib.deflateParams.argtypes = [P, C.c_int, C.c_int]
     lib.deflateTune.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -1078,6 +1132,21 @@ def misc_symbol_checks(lib, o):
     assert lib.uncompress2_z(back, C.byref(ocap), blob, C.byref(icap)) == Z_OK and back.raw == data and icap.value == cap.value
     ocap = zsz(len(data))
     assert lib.uncompress_z(back, C.byref(ocap), blob, cap.value) == Z_OK and ocap.value == len(data)
+    # --- uncompress edge cases (test-libz-rs-sys/src/inflate.rs:1337-1358; zlib-rs/src/inflate.rs:195-284): no input is a data
+    # error; no room is a data error unless the stream is complete and empty; *destLen reports what was written either way
+    hello = zlib.compress(b"Hello World!\n", 6)
+    one = C.create_string_buffer(1)
+    for room, blob, want_rc, want_len in ((0, b"", Z_DATA_ERROR, 0), (1, b"", Z_DATA_ERROR, 0), (0, hello, Z_DATA_ERROR, 0),
+                                          (0, zlib.compress(b""), Z_OK, 0), (1, hello, Z_BUF_ERROR, 1), (1, hello[:-6], Z_BUF_ERROR, 1)):
+        ocap = zsz(room)
+        src = C.create_string_buffer(blob, len(blob) or 1)
+        assert lib.uncompress_z(one, C.byref(ocap), src, len(blob)) == want_rc, (room, len(blob))
+        assert ocap.value == want_len, (room, len(blob), ocap.value)
+    big = C.create_string_buffer(64)
+    ocap = zsz(64)
+    assert lib.uncompress_z(big, C.byref(ocap), hello[:-6], len(hello) - 6) == Z_DATA_ERROR and big.raw[:ocap.value] == b"Hello World!\n"[:ocap.value]
+    assert lib.uncompress_z(None, C.byref(ocap), hello, len(hello)) == Z_STREAM_ERROR
+    assert lib.uncompress_z(big, None, hello, len(hello)) == Z_STREAM_ERROR
     # --- checksum variants and the combine operators (lib.rs:149-412; crc32/combine.rs)
     for f in ("adler32_z", "crc32_z"):
         getattr(lib, f).restype, getattr(lib, f).argtypes = C.c_ulong, [C.c_ulong, C.c_void_p, zsz]

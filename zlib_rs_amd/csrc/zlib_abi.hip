@@ -825,11 +825,30 @@ int deflateParams(z_streamp strm, int level, int strategy) {
 }
 int deflateTune(z_streamp strm, int, int, int, int) { return dstate(strm) ? Z_OK : Z_STREAM_ERROR; }
 z_size_t deflateBound_z(z_streamp strm, z_size_t sourceLen) {
-    // compress_bound (deflate.rs:2975-2991) + the 5-byte segment markers this engine inserts per 1 MiB
-    int wrap = 1;
-    if (DeflateState* s = dstate(strm)) wrap = s->wrap;
-    z_size_t w = wrap == 1 ? 6 : (wrap == 2 ? 18 : 0);
-    return sourceLen + (sourceLen == 0) + (sourceLen < 9) + ((sourceLen + 7) >> 3) + 3 + w;
+    // bound (deflate.rs:3193-3287): the wrapper's length follows the stream (DICTID, the gzip header fields handed in with
+    // deflateSetHeader), a window other than 32 KiB gets the conservative formula, the default configuration
+    // compress_bound_help (deflate.rs:2975-2991).  This engine's own overhead -- a 5-byte marker per 1 MiB segment,
+    // 5 bytes per 64 KiB stored block -- stays far inside the (n + 7) / 8 term (test: misc_symbol_checks).
+    const z_size_t n = sourceLen;
+    const z_size_t comp_len = n + ((n + 7) >> 3) + ((n + 63) >> 6) + 5;
+    DeflateState* s = dstate(strm);
+    if (!s) return comp_len + 6;
+    z_size_t wrap_len = 0;
+    if (s->wrap == 1) wrap_len = 6 + ((s->dict_set || s->total_len != 0 || !s->in.empty()) ? 4 : 0);
+    else if (s->wrap == 2) {
+        wrap_len = 18;
+        if (const gz_header* h = s->gzhead) {
+            if (h->extra) wrap_len += 2 + h->extra_len;
+            if (h->name) wrap_len += strlen((const char*)h->name) + 1;
+            if (h->comment) wrap_len += strlen((const char*)h->comment) + 1;
+            if (h->hcrc) wrap_len += 2;
+        }
+    }
+    if (s->wbits != 15) {
+        if (s->level == 0) return n + (n >> 5) + (n >> 7) + (n >> 11) + 7 + wrap_len;
+        return comp_len + wrap_len;
+    }
+    return n + (n == 0) + (n < 9) + ((n + 7) >> 3) + 3 + wrap_len;
 }
 uLong deflateBound(z_streamp strm, uLong sourceLen) { return (uLong)deflateBound_z(strm, sourceLen); }
 int deflatePending(z_streamp strm, unsigned* pending, int* bits) {
@@ -1341,15 +1360,18 @@ int uncompress2_z(Bytef* dest, z_size_t* destLen, const Bytef* source, z_size_t*
     std::vector<uint8_t> out;
     uint32_t used = 0;
     int32_t st = 0, detail = 0;
-    int rc = gpu_inflate_stream(source, *sourceLen, ZMI_WRAP_ZLIB, out, *destLen, &used, &st, &detail);
+    const z_size_t room = *destLen;
+    int rc = gpu_inflate_stream(source, *sourceLen, ZMI_WRAP_ZLIB, out, room, &used, &st, &detail);
     if (rc != Z_OK) return rc;
     *sourceLen = used;
-    if (st == Z_OK) {
-        memcpy(dest, out.data(), out.size());
-        *destLen = out.size();
-        return Z_OK;
-    }
-    if (st == Z_BUF_ERROR && detail == 2) { memcpy(dest, out.data(), out.size()); return Z_BUF_ERROR; }
+    // whatever the outcome, *destLen reports what was written (inflate.rs:260-283: dest_len = total_out)
+    const size_t got = out.size() < room ? out.size() : room;
+    if (got) memcpy(dest, out.data(), got);
+    *destLen = got;
+    if (st == Z_OK) return Z_OK;
+    // no room at all: the reference decodes into a one-byte buffer of its own only to tell a complete empty stream (Z_OK
+    // above) from everything else, which is a data error (inflate.rs:202-217, :263-275; uncompress_edge_cases)
+    if (st == Z_BUF_ERROR && detail == 2) return room == 0 ? Z_DATA_ERROR : Z_BUF_ERROR;
     if (st == Z_BUF_ERROR) return Z_DATA_ERROR;  // input ended inside the stream: uncompress reports a data error (inflate.rs:268-284)
     return st == Z_NEED_DICT ? Z_DATA_ERROR : st;
     ZMI_ABI_CATCH(Z_MEM_ERROR)
