@@ -249,6 +249,8 @@ def header_copy_checks(lib, data):
     strm.next_in, strm.avail_in = C.addressof(src), half
     strm.next_out, strm.avail_out = C.addressof(dst), cap
     assert lib.deflate(C.byref(strm), Z_NO_FLUSH) == Z_OK
+    head = dst.raw[:cap - strm.avail_out]     # at least the gzip header: the first call writes it (deflate.rs:2543-2627)
+    assert head[:4] == b"\x1f\x8b\x08\x1f"
     # deflateCopy in the middle of a stream: both copies finish it identically
     twin = ZStream()
     assert lib.deflateCopy(C.byref(twin), C.byref(strm)) == Z_OK
@@ -265,7 +267,7 @@ def header_copy_checks(lib, data):
         outs.append(d2.raw[:cap - st_.avail_out])
         assert lib.deflateEnd(C.byref(st_)) == Z_OK
     assert outs[0] == outs[1]
-    comp = outs[0]
+    comp = head + outs[0]
     assert comp[:4] == b"\x1f\x8b\x08\x1f" and comp[4:8] == (1234567890).to_bytes(4, "little")
     g = gzip.GzipFile(fileobj=io.BytesIO(comp))
     assert g.read() == data and g.mtime == 1234567890
@@ -1062,6 +1064,18 @@ def misc_symbol_checks(lib, o):
     assert lib.deflateReset(C.byref(s)) == Z_OK
     assert one(s, da) == first and zlib.decompress(first) == da
     assert lib.deflateEnd(C.byref(s)) == Z_OK
+    # --- a fresh stream's first call without input is Z_OK (the wrapper's header goes out; old_flush starts at -2), the same
+    # call again is Z_BUF_ERROR, a higher-ranked flush is work again, and the stream counts as started (deflate.rs:2505-2533, :728-743)
+    for wb, hdr in ((15, 2), (31, 10), (-15, 0)):
+        s = ZStream()
+        assert lib.deflateInit2_(C.byref(s), 6, 8, wb, 8, 0, ver, zs) == Z_OK
+        dst = C.create_string_buffer(100)
+        s.next_in, s.avail_in, s.next_out, s.avail_out = None, 0, C.addressof(dst), 100
+        assert lib.deflate(C.byref(s), Z_NO_FLUSH) == Z_OK and 100 - s.avail_out == hdr, wb
+        assert lib.deflate(C.byref(s), Z_NO_FLUSH) == Z_BUF_ERROR
+        assert lib.deflate(C.byref(s), Z_SYNC_FLUSH) == Z_OK and dst.raw[hdr:100 - s.avail_out][-4:] == b"\0\0\xff\xff"
+        assert lib.deflate(C.byref(s), Z_SYNC_FLUSH) == Z_BUF_ERROR
+        assert lib.deflateEnd(C.byref(s)) == Z_DATA_ERROR
     # --- deflateParams between two halves (lib.rs:1658, deflate.rs:441-497); deflateTune accepted; out-of-range refused
     lib.deflateParams.argtypes = [P, C.c_int, C.c_int]
     lib.deflateTune.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int]

@@ -772,6 +772,10 @@ int deflate(z_streamp strm, int flush) {
         strm->avail_in = 0;
     }
     int rc = Z_OK;
+    // the first call writes the wrapper's header even without input, and from then on the stream counts as started
+    // (deflate.rs:2543-2627: Status::Init -> Busy; deflateEnd then reports Z_DATA_ERROR, deflate.rs:728-743)
+    if (!s->header_done && !s->finished) put_header(s);
+    const int old_flush = s->last_flush;
     if (!s->finished) {
         if (flush == Z_FINISH) rc = compress_buffered(s, true);
         else if (flush != Z_NO_FLUSH) { if (!s->in.empty() || s->last_flush != flush || in0) rc = compress_buffered(s, false, flush == Z_FULL_FLUSH); }
@@ -782,7 +786,10 @@ int deflate(z_streamp strm, int flush) {
     drain(strm, s->pending, s->pending_pos);
     strm->adler = s->wrap == 2 ? s->crc : s->adler;
     if (s->finished && s->pending.empty()) return Z_STREAM_END;
-    if (in0 == 0 && out0 == strm->avail_out && flush != Z_FINISH) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; }
+    // a call that had nothing to do is an error only if it asks for no more than the call before it (deflate.rs:2526-2533:
+    // rank_flush(flush) <= rank_flush(old_flush); a fresh stream starts at -2, so its first empty call is Z_OK)
+    auto rank = [](int f) { return f * 2 - (f > 4 ? 9 : 0); };
+    if (in0 == 0 && out0 == strm->avail_out && flush != Z_FINISH && rank(flush) <= rank(old_flush)) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; }
     return Z_OK;
     ZMI_ABI_CATCH(Z_MEM_ERROR)
 }
