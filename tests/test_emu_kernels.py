@@ -46,11 +46,30 @@ def test_deflate_multi_piece_streams(eng, o, monkeypatch):
         assert zlib.decompress(c, 31) == b
 
 
+def strategy_token_rules(raw_stream, strategy):
+    """what the strategy promises about the tokens (zlib-rs/src/deflate/algorithm/huff.rs, rle.rs; Strategy::Fixed in
+    zng_tr_flush_block, deflate.rs:2316-2434): Z_HUFFMAN_ONLY no matches at all, Z_RLE distance 1 only, Z_FIXED no dynamic
+    block.  Shared with the GPU test."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import deflate_dump
+    blocks, out = deflate_dump.dump(raw_stream, 0)
+    if strategy == 2:
+        assert sum(b["matches"] for b in blocks) == 0
+    if strategy == 3:
+        assert max(b["maxdist"] for b in blocks) <= 1
+    if strategy == 4:
+        assert all(b["type"] in (0, 1) for b in blocks)
+    return out
+
+
 def test_deflate_strategies(eng, o):
-    d = o.gen_shard(4, 1 << 13)
-    for strat in (1, 2, 3, 4):
-        outs, st = eng.deflate([d], level=6, strategy=strat, wrap=1)
-        assert st == [0] and zlib.decompress(outs[0]) == d
+    for cls in (0, 4):
+        d = o.gen_shard(cls, 1 << 13) + bytes(300) + b"ab" * 100
+        for strat in (1, 2, 3, 4):
+            outs, st = eng.deflate([d], level=6, strategy=strat, wrap=1)
+            assert st == [0] and zlib.decompress(outs[0]) == d
+            assert strategy_token_rules(outs[0][2:-4], strat) == d
 
 
 def test_inflate_kernel_matches_oracle(eng, o):

@@ -127,6 +127,8 @@ def test_deflate_strategies(engine, strategy):
     assert (st == 0).all()
     for s, o in zip(shards, outs):
         assert zlib.decompress(o) == s
+    from test_emu_kernels import strategy_token_rules     # pure-Python token walk: one shard is enough
+    assert strategy_token_rules(bytes(outs[0])[2:-4], strategy) == bytes(shards[0])
 
 
 def test_deflate_unaligned_offsets(engine):

@@ -36,7 +36,7 @@ def dump(raw, start=0, verbose=False):
     b=Bits(raw,start); blocks=[]; out=bytearray()
     while True:
         fin=b.get(1); typ=b.get(2); p0=b.p
-        info={'final':fin,'type':typ,'lits':0,'matches':0,'mlen':0,'hdr_bits':0}
+        info={'final':fin,'type':typ,'lits':0,'matches':0,'mlen':0,'hdr_bits':0,'maxdist':0}
         if typ==0:
             b.p=(b.p+7)&~7; l=b.get(16); b.get(16)
             out+=raw[b.p>>3:(b.p>>3)+l]; b.p+=8*l; info['stored']=l
@@ -64,7 +64,7 @@ def dump(raw, start=0, verbose=False):
                 else:
                     l=LBASE[s-257]+b.get(LEXT[s-257]); d=decode(b,dt); dist=DBASE[d]+b.get(DEXT[d])
                     for _ in range(l): out.append(out[-dist])
-                    info['matches']+=1; info['mlen']+=l
+                    info['matches']+=1; info['mlen']+=l; info['maxdist']=max(info['maxdist'],dist)
                     if verbose: print('match',l,dist)
         info['bits']=b.p-p0
         blocks.append(info)

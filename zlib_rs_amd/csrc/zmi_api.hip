@@ -316,7 +316,9 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     ep.chain_mode = chain_mode;
     ep.last_shard = n - 1u;
     if (level == 0) ep.strategy = 100u;           // stored blocks only (deflate_stored)
-    if (strategy == 2) lp.max_chain = 0;          // Z_HUFFMAN_ONLY: literals only
+    if (strategy == 2) { lp.max_chain = 0; lp.max_dist = 0; }   // Z_HUFFMAN_ONLY: literals only -- with no distance allowed no
+                                                                 // position gets a candidate (a zero chain budget alone still
+                                                                 // examines the first one)
     if (strategy == 3) lp.max_dist = 1;           // Z_RLE: distance-1 matches only
     const char* chain_env = getenv("ZMI_CHAIN");  // tuning aid: override the chain budget of the selected level
     if (chain_env && atoi(chain_env) > 0 && level > 0 && strategy != 2) lp.max_chain = (uint32_t)atoi(chain_env);
