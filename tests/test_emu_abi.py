@@ -149,3 +149,9 @@ def test_misc_entry_points():
     zmi_ctypes.load_emu()
     lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
     H.misc_symbol_checks(lib, oracle_lib.load())
+
+
+def test_streams_on_concurrent_threads():
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    H.threaded_roundtrips(lib, oracle_lib.load(), threads=4, rounds=3)

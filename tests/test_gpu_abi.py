@@ -121,3 +121,9 @@ def test_misc_entry_points_on_gpu():
     from zlib_rs_amd import _build
     lib = H.bind(C.CDLL(_build.ABI_LIB))
     H.misc_symbol_checks(lib, oracle_lib.load(rebuild=False))
+
+
+def test_streams_on_concurrent_threads_on_gpu():
+    from zlib_rs_amd import _build
+    lib = H.bind(C.CDLL(_build.ABI_LIB))
+    H.threaded_roundtrips(lib, oracle_lib.load(rebuild=False), threads=8, rounds=5)

@@ -1189,3 +1189,32 @@ def misc_symbol_checks(lib, o):
     lib.zlibCompileFlags.restype = C.c_ulong
     fl = lib.zlibCompileFlags()
     assert fl == (1 | 2 << 2 | 2 << 4 | 2 << 6)      # uInt 32 bit; uLong, pointers, z_off_t 64 bit; no feature bits (lib.rs:2219-2270)
+
+
+def threaded_roundtrips(lib, o, threads=4, rounds=5):
+    """different streams on different threads at the same time (SURVEY 8b threading: no shared stream state; the reference
+    declares its streams Send + Sync, zlib-rs/src/deflate.rs:53-54).  ctypes releases the GIL inside every call, so the
+    calls really overlap; each thread drives its own deflate and inflate streams in small pieces."""
+    import threading
+    import zlib
+    errors = []
+
+    def work(t):
+        try:
+            for r in range(rounds):
+                data = o.gen_shard((t + r) % 8, 20000 + 7000 * t + 13 * r)
+                wbits = (15, 31, -15)[(t + r) % 3]
+                comp = deflate_stream(lib, data, level=(1, 6, 9)[r % 3], wbits=wbits, chunk_in=5000, chunk_out=3000, flush_every=2)
+                assert zlib.decompressobj(wbits).decompress(comp) == data
+                rc, out, unused = inflate_stream(lib, comp, wbits, chunk_in=777, chunk_out=4096)
+                assert rc == Z_STREAM_END and out == data and unused == 0
+                assert lib.crc32(0, data, len(data)) == zlib.crc32(data)
+        except BaseException as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
