@@ -65,7 +65,19 @@ def cpu_baseline(shard_bytes, level, budget_s=15.0):
     n = min(cores * per_thread, 16384, max(cores * 8, int(24 * GIB / shard_bytes)))
     n -= n % 8
     tall = o.lib.zo_bench_deflate(0x5A4C4942, 0, n, shard_bytes, level, cores, C.byref(tot))
-    return {"value": n * shard_bytes / GIB / tall, "unit": "GiB/s", "cores": cores, "kind": "port",
+    # labelled secondary reference: the system's zlib, compress2(level) of the same 8 shards, one thread
+    secondary = None
+    try:
+        import zlib
+        shards = [o.gen_shard(i, shard_bytes) for i in range(8)]
+        ts = time.perf_counter()
+        csz = sum(len(zlib.compress(d, level)) for d in shards)
+        tz = time.perf_counter() - ts
+        secondary = {"library": "system zlib " + zlib.ZLIB_RUNTIME_VERSION, "single_thread_GiB_s": 8 * shard_bytes / GIB / tz,
+                     "ratio": 8 * shard_bytes / float(csz), "sample": "8 x %d B (classes 0-7)" % shard_bytes}
+    except Exception:  # noqa: BLE001
+        pass
+    return {"value": n * shard_bytes / GIB / tall, "unit": "GiB/s", "cores": cores, "kind": "port", "system_zlib": secondary,
             "sample": "%d x %d B synthetic shards (classes 0-7), oracle zo_deflate level %d, %d POSIX threads, %.1f s"
                       % (n, shard_bytes, level, cores, tall),
             "single_thread_GiB_s": one, "ratio": n * shard_bytes / float(tot.value)}
