@@ -22,6 +22,9 @@ H.golden_inflate_checks(lib, json.load(open("tests/golden/inflate_vectors.json")
 os.environ["ZMI_ABI_SEGMENT"] = "4096"
 H.run_abi_checks(lib, o, sizes=(0, 1, 100, 5000, 20000))
 H.header_copy_checks(lib, o.gen_shard(2, 40000))
+H.misc_symbol_checks(lib, o)                      # device-buffer pool reuse with changing sizes, allocators, bounds
+H.config_matrix_roundtrips(lib, o, 25, seed=3, max_len=40000)
+H.threaded_roundtrips(lib, o, threads=3, rounds=2)
 eng = zmi_ctypes.Engine(zmi_ctypes._bind(C.CDLL(so)))
 resume_checks.resume_chain_checks(eng, o, sizes=(60000, 40000, 20000, 20000), trials=2)
 shards = [o.gen_shard(i % 8, n) for i, n in enumerate([0, 1, 15, 16, 17, 1000, 4096, 9999, 20000] * 3)]

@@ -133,10 +133,49 @@ zmi_ctx* abi_ctx() {
     }
     return g_ctx;
 }
+// Device buffers of one call.  They come from a small pool that outlives the call: hipMalloc / hipFree cost far more than
+// the kernels of a small compress2() (hipFree also waits for the device), and a caller that compresses many small buffers
+// repeats the same sizes.  The pool is only touched under g_mu (every user of DevBuf holds it); buffers above kPoolKeep are
+// returned to the driver at once so that one large call does not pin its memory.
+struct PoolSlot { void* p = nullptr; size_t cap = 0; bool busy = false; };
+constexpr int kPoolSlots = 12;
+constexpr size_t kPoolKeep = (size_t)256 << 20;
+PoolSlot g_pool[kPoolSlots];
 struct DevBuf {
     void* p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    bool alloc(size_t n) { return hipMalloc(&p, n ? n : 16) == hipSuccess; }
+    int slot = -1;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() {
+        if (slot >= 0) {
+            PoolSlot& q = g_pool[slot];
+            q.busy = false;
+            if (q.cap > kPoolKeep) { (void)hipFree(q.p); q.p = nullptr; q.cap = 0; }
+        } else if (p) (void)hipFree(p);
+    }
+    bool alloc(size_t n) {
+        if (n == 0) n = 16;
+        int fit = -1, spare = -1;
+        for (int i = 0; i < kPoolSlots; ++i) {
+            const PoolSlot& q = g_pool[i];
+            if (q.busy) continue;
+            if (q.cap >= n && (fit < 0 || q.cap < g_pool[fit].cap)) fit = i;                 // smallest buffer that is large enough
+            if (q.cap < n && (spare < 0 || q.cap < g_pool[spare].cap)) spare = i;            // too small: an empty slot first, else the smallest
+        }
+        if (fit >= 0) { g_pool[fit].busy = true; slot = fit; p = g_pool[fit].p; return true; }
+        if (spare < 0) return hipMalloc(&p, n) == hipSuccess;                                // pool exhausted: a plain allocation
+        PoolSlot& q = g_pool[spare];
+        if (q.p) { (void)hipFree(q.p); q.p = nullptr; q.cap = 0; }
+        const size_t want = n + n / 4 + 256;                                                 // some room for the next, slightly larger, call
+        if (hipMalloc(&q.p, want) != hipSuccess) {
+            q.p = nullptr;
+            if (hipMalloc(&q.p, n) != hipSuccess) { q.p = nullptr; return false; }
+            q.cap = n;
+        } else q.cap = want;
+        q.busy = true; slot = spare; p = q.p;
+        return true;
+    }
 };
 
 size_t segment_bytes() {  // 1 MiB segments; ZMI_ABI_SEGMENT (bytes, multiple of 64) overrides for tests
