@@ -200,7 +200,11 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
     uint32_t hist = 0;
     if (prm.carry) {
         const uint64_t before = off[s] - off[0] + prm.dict_len;   // history bytes of this stream in front of the segment
-        const uint32_t reach = prm.max_dist & ~(LZ_T - 1u);
+        // whole tiles of history: max_dist rounded up (a small window -- windowBits 9..12 -- would otherwise see no history
+        // or dictionary at all; positions farther back than max_dist are hashed but never reached), at most the 27 KiB
+        // that the full window gets
+        uint32_t reach = (prm.max_dist + LZ_T - 1u) & ~(LZ_T - 1u);
+        if (reach > LZ_WSIZE - 5u * LZ_T) reach = LZ_WSIZE - 5u * LZ_T;
         hist = before < reach ? (uint32_t)before & ~15u : reach;  // multiples of 16 keep the 16-byte load path
     }
     const uint8_t* src = data + off[s] - hist;
