@@ -88,7 +88,9 @@ int zmi_inflate_batch_dev(zmi_ctx* ctx, const void* d_in, const uint64_t* d_in_o
  * Z_SYNC_FLUSH, zlib-rs/src/deflate.rs:2733-2738) and matches into the up to 27 KiB in front of it
  * (window carry-over); finish != 0 makes the last shard end the stream.  The _dict form also treats the
  * dict_len bytes in front of the first segment as history: a preset dictionary (deflateSetDictionary,
- * deflate.rs:499-564) or the tail of the input of an earlier call on the same stream. */
+ * deflate.rs:499-564) or the tail of the input of an earlier call on the same stream.
+ * out_stride: zmi_deflate_bound(max_len, raw) + 16 -- a segment that does not end the stream carries the 5-byte sync
+ * marker behind its last block, which the bound of a finished stream does not cover for segments of a few bytes. */
 int zmi_deflate_chain_dev(zmi_ctx* ctx, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                           uint32_t n_shards, uint32_t max_len, int level, int strategy, int finish, void* d_out,
                           uint64_t out_stride, uint32_t* d_out_len, int32_t* d_status, void* stream);

@@ -1076,6 +1076,19 @@ def misc_symbol_checks(lib, o):
         assert lib.deflate(C.byref(s), Z_SYNC_FLUSH) == Z_OK and dst.raw[hdr:100 - s.avail_out][-4:] == b"\0\0\xff\xff"
         assert lib.deflate(C.byref(s), Z_SYNC_FLUSH) == Z_BUF_ERROR
         assert lib.deflateEnd(C.byref(s)) == Z_DATA_ERROR
+    # --- short packets with a flush behind each (a protocol that flushes every message): every size from 1 byte up, incompressible
+    # and text -- an 11-byte packet once overflowed its device slot (block + sync marker > compress_bound(11) = 16)
+    for base_ in (os.urandom(80), b"abcdefghijklmnopqrstuvwxyz0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZ!?" * 2):
+        s = ZStream()
+        assert lib.deflateInit2_(C.byref(s), 6, 8, -15, 8, 0, ver, zs) == Z_OK
+        rd = zlib.decompressobj(-15)
+        for k in range(1, 70):
+            pkt = base_[:k]
+            src, dst = C.create_string_buffer(pkt, k), C.create_string_buffer(400)
+            s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), k, C.addressof(dst), 400
+            assert lib.deflate(C.byref(s), Z_SYNC_FLUSH if k % 3 else Z_FULL_FLUSH) == Z_OK, k
+            assert rd.decompress(dst.raw[:400 - s.avail_out]) == pkt, k
+        assert lib.deflateEnd(C.byref(s)) == Z_DATA_ERROR
     # --- deflateParams between two halves (lib.rs:1658, deflate.rs:441-497); deflateTune accepted; out-of-range refused
     lib.deflateParams.argtypes = [P, C.c_int, C.c_int]
     lib.deflateTune.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int]

@@ -217,7 +217,10 @@ int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_
         len[i] = (uint32_t)((n - at < kSegment) ? n - at : kSegment);
     }
     const uint32_t max_len = len[0];
-    const uint64_t stride = zmi_deflate_bound(max_len, ZMI_WRAP_RAW);
+    // + 16: a segment that does not end the stream is followed by the 5-byte marker of a sync flush, which compress_bound
+    // (the reference's bound for a finished stream) does not cover for very short incompressible segments (11 bytes: 13 bytes
+    // of fixed-Huffman block + marker = 17 > bound 16)
+    const uint64_t stride = zmi_deflate_bound(max_len, ZMI_WRAP_RAW) + 16u;
     DevBuf d_in, d_off, d_len, d_out, d_olen, d_st;
     if (!d_in.alloc(base + n + 16) || !d_off.alloc(nseg * 8) || !d_len.alloc(nseg * 4) || !d_out.alloc((size_t)nseg * stride) ||
         !d_olen.alloc(nseg * 4) || !d_st.alloc(nseg * 4))
