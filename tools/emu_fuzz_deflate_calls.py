@@ -1,6 +1,6 @@
 """Random call sequences on one deflate stream of the stream ABI (CPU emulator build): input pieces with every flush value,
 output rooms from 1 byte up, deflateParams / deflatePending / deflateCopy / deflateTune in between, sometimes a preset
-dictionary or primed bits; the system's zlib must read the result back and the counters must add up.
+dictionary; the system's zlib must read the result back and the counters must add up.
 usage: python tools/emu_fuzz_deflate_calls.py SEED SECONDS   (test infrastructure; the product path needs an MI355X)"""
 import ctypes as C
 import os
