@@ -108,22 +108,3 @@ def test_random_streaming_roundtrips_on_gpu():
     for seed in range(1000, 1008):
         H.random_streaming_roundtrips(lib, o, 3, seed, max_len=200000)
 
-
-def test_config_matrix_roundtrips_on_gpu():
-    """end_to_end.rs's property over level x windowBits x memLevel x strategy on the device path"""
-    from zlib_rs_amd import _build
-    lib = H.bind(C.CDLL(_build.ABI_LIB))
-    H.config_matrix_roundtrips(lib, oracle_lib.load(rebuild=False), 40, seed=11, max_len=300000)
-
-
-def test_misc_entry_points_on_gpu():
-    """allocators, deflateBound as a guarantee, deflateParams / Tune / ResetKeep / inflateReset2, _z one-shots, combine operators"""
-    from zlib_rs_amd import _build
-    lib = H.bind(C.CDLL(_build.ABI_LIB))
-    H.misc_symbol_checks(lib, oracle_lib.load(rebuild=False))
-
-
-def test_streams_on_concurrent_threads_on_gpu():
-    from zlib_rs_amd import _build
-    lib = H.bind(C.CDLL(_build.ABI_LIB))
-    H.threaded_roundtrips(lib, oracle_lib.load(rebuild=False), threads=8, rounds=5)
