@@ -24,8 +24,12 @@
  *              is bounded by the block size.  Bytes behind the end of the stream are handed back (avail_in) as
  *              far as they arrived with the call that reaches the end.  Wrapper header / trailer are parsed on the host.  Z_BLOCK and
  *              Z_TREES do not stop at block ends (they behave like Z_NO_FLUSH).  The bytes in front of a corrupt
- *              spot are delivered before Z_DATA_ERROR, as the reference does; header and trailer errors carry the
- *              reference's messages, errors inside the deflate data a generic one.
+ *              spot are delivered before Z_DATA_ERROR, as the reference does; header, trailer and deflate-data errors
+ *              carry the reference's messages ("invalid stored block lengths", "invalid distance too far back", ...:
+ *              the decode kernel reports the cause, inflate.rs State::bad).
+ *   windowBits 9..14 bound the back-references (2^windowBits - 262, deflate.rs:1423-1425); deflateBound is the
+ *              reference's bound() (deflate.rs:3193-3287: wrapper, gzip header fields, DICTID, small windows);
+ *              the first deflate() call writes the wrapper's header even without input (deflate.rs:2543-2627).
  * Preset dictionaries (deflateSetDictionary / inflateSetDictionary, incl. Z_NEED_DICT and the DICTID check) are
  * supported: the dictionary is the window in front of the first segment.
  * gzip header fields (deflateSetHeader / inflateGetHeader), deflateCopy / inflateCopy, *ResetKeep and *GetDictionary
