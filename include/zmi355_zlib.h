@@ -53,13 +53,68 @@ extern "C" {
 
 #define ZLIB_VERSION "1.3.0-zmi355-0.1.0"
 #define ZLIB_VERNUM 0x1300
+#define ZLIB_VER_MAJOR 1
+#define ZLIB_VER_MINOR 3
+#define ZLIB_VER_REVISION 0
+#define ZLIB_VER_SUBREVISION 0
 
+/* ---- what zlib's zconf.h supplies (libz-rs-sys/include/zconf.h): type names, const-ness and linkage macros that
+ * programs written against zlib.h spell out (libz-rs-sys-cdylib/example.c uses z_const and z_off64_t) ---- */
+#if defined(ZLIB_CONST) && !defined(z_const)
+#  define z_const const          /* libz-rs-sys/include/zlib.h:95,103,1069 */
+#elif !defined(z_const)
+#  define z_const
+#endif
+#ifndef ZEXTERN
+#  define ZEXTERN extern
+#endif
+#ifndef ZEXPORT
+#  define ZEXPORT
+#endif
+#ifndef ZEXPORTVA
+#  define ZEXPORTVA
+#endif
+#ifndef Z_EXTERN
+#  define Z_EXTERN extern
+#endif
+#ifndef Z_EXPORT
+#  define Z_EXPORT
+#endif
+#ifndef Z_EXPORTVA
+#  define Z_EXPORTVA
+#endif
+#ifndef OF
+#  define OF(args) args
+#endif
+#ifndef FAR
+#  define FAR
+#endif
+#ifndef MAX_MEM_LEVEL
+#  define MAX_MEM_LEVEL 9
+#endif
+#ifndef MIN_WBITS
+#  define MIN_WBITS 8
+#endif
+
+typedef unsigned char Byte;
 typedef unsigned char Bytef;
 typedef unsigned int uInt;
 typedef unsigned long uLong;
+typedef char charf;
+typedef int intf;
+typedef uInt uIntf;
 typedef uLong uLongf;
 typedef void* voidpf;
+typedef void* voidp;
+typedef const void* voidpc;
 typedef size_t z_size_t;
+typedef unsigned int z_crc_t;
+#ifndef z_off_t
+typedef long z_off_t;            /* libz-rs-sys/include/zlib.h:1714,1793,1813: gzseek / gztell / gzoffset, *_combine */
+#endif
+#ifndef z_off64_t
+typedef long long z_off64_t;     /* the *64 variants; same width as z_off_t on LP64 */
+#endif
 
 typedef voidpf (*alloc_func)(voidpf opaque, uInt items, uInt size); /* zlib-rs/src/c_api.rs:8 */
 typedef void (*free_func)(voidpf opaque, voidpf address);           /* zlib-rs/src/c_api.rs:9 */
@@ -68,13 +123,13 @@ struct internal_state;
 
 /* zlib-rs/src/c_api.rs:54-71 */
 typedef struct z_stream_s {
-    const Bytef* next_in;
+    z_const Bytef* next_in;
     uInt avail_in;
     uLong total_in;
     Bytef* next_out;
     uInt avail_out;
     uLong total_out;
-    const char* msg;
+    z_const char* msg;
     struct internal_state* state;
     alloc_func zalloc;
     free_func zfree;
@@ -131,6 +186,7 @@ typedef gz_header* gz_headerp;
 #define Z_DEFAULT_STRATEGY 0
 #define Z_BINARY 0
 #define Z_TEXT 1
+#define Z_ASCII Z_TEXT
 #define Z_UNKNOWN 2
 #define Z_DEFLATED 8
 #define Z_NULL 0
@@ -187,8 +243,6 @@ int inflateBackEnd(z_streamp strm);                                             
 /* ---- gz* file API (libz-rs-sys/src/gz.rs): gzip files through the stream ABI above; the reader accepts
  * concatenated members (gz.rs:931-932, 1464-1506) and passes non-gzip files through unchanged ---- */
 #include <stdarg.h>
-typedef void* voidp;
-typedef const void* voidpc;
 struct gzFile_s {            /* public part of the handle, read by zlib.h's gzgetc() macro (gz.rs:27-41) */
     unsigned have;
     unsigned char* next;
@@ -213,13 +267,13 @@ int gzgetc(gzFile file);                                                        
 int gzgetc_(gzFile file);                                                                /* gz.rs:2223 */
 int gzungetc(int c, gzFile file);                                                        /* gz.rs:2247 */
 int gzflush(gzFile file, int flush);                                                     /* gz.rs:1928 */
-long gzseek(gzFile file, long offset, int whence);                                       /* gz.rs:2650 */
-long long gzseek64(gzFile file, long long offset, int whence);                           /* gz.rs:2530 */
+z_off_t gzseek(gzFile file, z_off_t offset, int whence);                                 /* gz.rs:2650 */
+z_off64_t gzseek64(gzFile file, z_off64_t offset, int whence);                           /* gz.rs:2530 */
 int gzrewind(gzFile file);                                                               /* gz.rs:2667 */
-long gztell(gzFile file);                                                                /* gz.rs:2004 */
-long long gztell64(gzFile file);                                                         /* gz.rs:1971 */
-long gzoffset(gzFile file);                                                              /* gz.rs:2064 */
-long long gzoffset64(gzFile file);                                                       /* gz.rs:2024 */
+z_off_t gztell(gzFile file);                                                             /* gz.rs:2004 */
+z_off64_t gztell64(gzFile file);                                                         /* gz.rs:1971 */
+z_off_t gzoffset(gzFile file);                                                           /* gz.rs:2064 */
+z_off64_t gzoffset64(gzFile file);                                                       /* gz.rs:2024 */
 int gzeof(gzFile file);                                                                  /* gz.rs:870 */
 int gzdirect(gzFile file);                                                               /* gz.rs:910 */
 int gzclose(gzFile file);                                                                /* gz.rs:600 */
@@ -241,14 +295,14 @@ int uncompress2_z(Bytef* dest, z_size_t* destLen, const Bytef* source, z_size_t*
 
 uLong adler32(uLong adler, const Bytef* buf, uInt len);                                  /* lib.rs:340 */
 uLong adler32_z(uLong adler, const Bytef* buf, z_size_t len);                            /* lib.rs:307 */
-uLong adler32_combine(uLong adler1, uLong adler2, long len2);                            /* lib.rs:372 */
-uLong adler32_combine64(uLong adler1, uLong adler2, long long len2);                     /* lib.rs:412 */
+uLong adler32_combine(uLong adler1, uLong adler2, z_off_t len2);                         /* lib.rs:372 */
+uLong adler32_combine64(uLong adler1, uLong adler2, z_off64_t len2);                     /* lib.rs:412 */
 uLong crc32(uLong crc, const Bytef* buf, uInt len);                                      /* lib.rs:183 */
 uLong crc32_z(uLong crc, const Bytef* buf, z_size_t len);                                /* lib.rs:150 */
-uLong crc32_combine(uLong crc1, uLong crc2, long len2);                                  /* lib.rs:215 */
-uLong crc32_combine64(uLong crc1, uLong crc2, long long len2);                           /* lib.rs:247 */
-uLong crc32_combine_gen(long len2);                                                      /* lib.rs:268 */
-uLong crc32_combine_gen64(long long len2);                                               /* lib.rs:260 */
+uLong crc32_combine(uLong crc1, uLong crc2, z_off_t len2);                               /* lib.rs:215 */
+uLong crc32_combine64(uLong crc1, uLong crc2, z_off64_t len2);                           /* lib.rs:247 */
+uLong crc32_combine_gen(z_off_t len2);                                                   /* lib.rs:268 */
+uLong crc32_combine_gen64(z_off64_t len2);                                               /* lib.rs:260 */
 uLong crc32_combine_op(uLong crc1, uLong crc2, uLong op);                                /* lib.rs:277 */
 const uint32_t* get_crc_table(void);                                                     /* lib.rs:253 */
 
@@ -257,6 +311,11 @@ const uint32_t* get_crc_table(void);                                            
     deflateInit2_((strm), (level), (method), (windowBits), (memLevel), (strategy), ZLIB_VERSION, (int)sizeof(z_stream))
 #define inflateInit(strm) inflateInit_((strm), ZLIB_VERSION, (int)sizeof(z_stream))
 #define inflateInit2(strm, windowBits) inflateInit2_((strm), (windowBits), ZLIB_VERSION, (int)sizeof(z_stream))
+#define inflateBackInit(strm, windowBits, window) \
+    inflateBackInit_((strm), (windowBits), (window), ZLIB_VERSION, (int)sizeof(z_stream))
+#define zlib_version zlibVersion()
+/* zlib.h's gzgetc() reads the public part of the handle and falls back to the function (libz-rs-sys/include/zlib.h) */
+#define gzgetc(g) ((g)->have ? ((g)->have--, (g)->pos++, *((g)->next)++) : (gzgetc)(g))
 
 #ifdef __cplusplus
 }

@@ -334,3 +334,43 @@ def extract_inflate():
 
 if __name__ == "__main__":
     extract_inflate()
+
+
+# ---------------------------------------------------------------------------------------------
+# ABI facts and real-data fixtures (round 2)
+#   zlib_symbol_versions.json   symbol -> version node of libz-rs-sys/include/zlib.map (what `readelf --dyn-syms`
+#                               of a drop-in libz must show), plus the names the map keeps local
+#   fixtures/*.xz               the three real files the reference's own deflate tests round-trip
+#                               (test-libz-rs-sys/src/deflate.rs:1982-2003): lcet10.txt, paper-100k.pdf,
+#                               fireworks.jpg -- stored xz-compressed (data, not source) with their CRC-32 in
+#                               fixtures/manifest.json
+# ---------------------------------------------------------------------------------------------
+def extract_abi_and_fixtures():
+    import lzma
+    import zlib as _z
+    here = os.path.dirname(os.path.abspath(__file__))
+    text = open(os.path.join(REF, "libz-rs-sys/include/zlib.map"), encoding="utf-8").read()
+    versions, local = {}, []
+    for m in re.finditer(r"(ZLIB_[0-9.]+)\s*\{(.*?)\}", text, re.S):
+        node, body, is_local = m.group(1), m.group(2), False
+        for tok in re.split(r"[;\s]+", body):
+            if tok in ("global:", "local:"):
+                is_local = tok == "local:"
+            elif tok:
+                (local.append(tok) if is_local else versions.__setitem__(tok, node))
+    json.dump({"reference": "libz-rs-sys/include/zlib.map", "versions": versions, "local": local},
+              open(os.path.join(here, "zlib_symbol_versions.json"), "w"), indent=1, sort_keys=True)
+    print("wrote %d versioned symbols" % len(versions))
+    fx = os.path.join(here, "fixtures")
+    os.makedirs(fx, exist_ok=True)
+    manifest = []
+    for name in ("lcet10.txt", "paper-100k.pdf", "fireworks.jpg"):
+        raw = open(os.path.join(REF, "test-libz-rs-sys/src/test-data", name), "rb").read()
+        open(os.path.join(fx, name + ".xz"), "wb").write(lzma.compress(raw, preset=9 | lzma.PRESET_EXTREME))
+        manifest.append({"name": name, "source": "test-libz-rs-sys/src/test-data/" + name, "bytes": len(raw), "crc32": _z.crc32(raw)})
+    json.dump(manifest, open(os.path.join(fx, "manifest.json"), "w"), indent=1)
+    print("wrote fixtures:", [(m["name"], m["bytes"]) for m in manifest])
+
+
+if __name__ == "__main__":
+    extract_abi_and_fixtures()

@@ -17,9 +17,24 @@ def _declared(header):
     return sorted(set(n for n in names if n not in ("alloc_func", "free_func", "sizeof")))
 
 
-def _exports(lib):
+def _exports_versions(lib):
+    """{symbol: version node or None} of the dynamic symbol table"""
     out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
-    return set(l.split()[-1] for l in out.splitlines() if l.strip())
+    res = {}
+    for l in out.splitlines():
+        if not l.strip():
+            continue
+        name = l.split()[-1]
+        if "@" in name:
+            sym, ver = name.split("@", 1)
+            res[sym] = ver.lstrip("@")
+        else:
+            res[name] = None
+    return res
+
+
+def _exports(lib):
+    return set(k for k in _exports_versions(lib) if not k.startswith("ZLIB_"))
 
 
 def test_libraries_export_declared_symbols():
@@ -32,6 +47,28 @@ def test_libraries_export_declared_symbols():
     assert not missing, missing
     # the engine library itself must not define zlib-named symbols (they would interpose libz)
     assert not ({"deflate", "inflate", "crc32", "adler32", "compress", "uncompress"} & core)
+
+
+def test_drop_in_library_exports_exactly_the_zlib_abi_with_its_version_nodes():
+    """libz_mi355.so against the reference's libz-rs-sys/include/zlib.map (extracted to tests/golden/
+    zlib_symbol_versions.json): every versioned entry point carries its node, the pre-1.2.0 entry points carry none,
+    and nothing but the declared entry points is exported (no C++ helpers, no std:: instantiations)."""
+    import json
+    from zlib_rs_amd import _build
+    _build.build()
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "zlib_symbol_versions.json")))
+    got = _exports_versions(_build.ABI_LIB)
+    got = {k: v for k, v in got.items() if not k.startswith("ZLIB_")}     # the version nodes themselves
+    declared = set(_declared("zmi355_zlib.h"))
+    assert set(got) == declared, (sorted(set(got) - declared), sorted(declared - set(got)))
+    for sym, node in golden["versions"].items():
+        assert got.get(sym) == node, (sym, got.get(sym), node)
+    for sym, ver in got.items():
+        if sym not in golden["versions"]:
+            assert ver is None, (sym, ver)
+    for sym in golden["local"]:
+        assert sym.rstrip("*") not in got or sym.endswith("*")
+    assert not [s for s in got if s.startswith("_")]
 
 
 def test_libraries_load_and_fail_loudly_without_gpu():

@@ -155,3 +155,12 @@ def test_streams_on_concurrent_threads():
     zmi_ctypes.load_emu()
     lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
     H.threaded_roundtrips(lib, oracle_lib.load(), threads=4, rounds=3)
+
+
+def test_input_handback_after_a_paused_decode(monkeypatch, tmp_path):
+    monkeypatch.setenv("ZMI_ABI_QUEUE", "4096")
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    H.handback_checks(lib, oracle_lib.load(), tmp_path)
+    monkeypatch.setenv("ZMI_ABI_ABSORB", "1000")     # the caller's input is taken in small pieces
+    H.handback_checks(lib, oracle_lib.load(), tmp_path, size=60000)

@@ -142,6 +142,38 @@ def test_inflate_long_distances_and_runs(eng, o):
         assert outs == blobs
 
 
+def resolve_window_edge_streams(o):
+    """after a long hole-free stretch the resolve pass restarts its ring one window in front of the
+    batch.  The restart used to be derived from the LAST hole of the batch (+3), which with a batch spanning RES_SPAN
+    (2048) and a first hole at p % 1024 in 1021..1023 landed up to 3 bytes above p - 32768: distances 32766..32768
+    then copied bytes that were never staged.  Raw fixed-Huffman streams with exactly that geometry.  Shared with the
+    GPU test.  Returns [(stream, expected)]."""
+    import deflate_craft
+    cases = []
+    for pmod in (1021, 1022, 1023):
+        for dist in (32766, 32767, 32768):
+            lits = o.prng_bytes(100 + pmod + dist, 50000, 1)
+            p = 40 * 1024 + pmod
+            toks = list(lits[:10]) + [(4, 7)]
+            k = 14
+            toks += list(lits[k:p]); k = p
+            toks += [(3, dist)]; k += 3
+            toks += list(lits[k:p + 2048]); k = p + 2048
+            toks += [(5, 32768)]; k += 5
+            toks += list(lits[k:k + 500])
+            cases.append((deflate_craft.fixed_block(toks), deflate_craft.expand(toks)))
+    return cases
+
+
+def test_inflate_resolve_window_edge(eng, o):
+    cases = resolve_window_edge_streams(o)
+    for s, want in cases:
+        assert zlib.decompress(s, -15) == want
+    outs, st = eng.inflate([s for s, _ in cases], [len(w) for _, w in cases], 0)
+    assert st == [0] * len(cases)
+    assert outs == [w for _, w in cases]
+
+
 def test_inflate_unaligned_layout_and_scratch_limit(eng, o):
     blobs = [o.gen_shard(1, 5000), o.gen_shard(4, 3001), b"q" * 777 + o.gen_shard(6, 2000), o.gen_shard(2, 4097)]
     streams = [zlib.compress(b, 6) for b in blobs]

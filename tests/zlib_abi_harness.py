@@ -1231,3 +1231,68 @@ def threaded_roundtrips(lib, o, threads=4, rounds=5):
     for t in ts:
         t.join()
     assert not errors, errors
+
+
+def handback_checks(lib, o, tmpdir, size=150000):
+    """ADVICE r01 (medium x2): bytes behind the end of a stream come back to the caller exactly, also when the decode
+    paused on the way (output queue limit, Z_NEED_DICT), and a gz reader drains a paused member without swallowing the
+    next one.  Needs ZMI_ABI_QUEUE set small by the caller (environment is read per call)."""
+    import gzip
+    import zlib
+    data = o.gen_shard(0, size) + o.gen_shard(3, size // 2)
+    tail = bytes(range(25))
+    co = zlib.compressobj(6, zlib.DEFLATED, 15)
+    comp = b"".join(co.compress(data[i:i + 20000]) + co.flush(zlib.Z_FULL_FLUSH) for i in range(0, len(data), 20000)) + co.flush()
+    # everything offered at once, small output rooms: the end is found many calls after the input was first seen
+    for room in (4096, 50000):
+        rc, out, unused = inflate_stream(lib, comp + tail, 15, chunk_in=1 << 30, chunk_out=room)
+        assert rc == Z_STREAM_END and out == data and unused == len(tail), (room, rc, len(out), unused)
+    # total_in follows what was really consumed
+    strm = ZStream()
+    assert lib.inflateInit2_(C.byref(strm), 15, lib.zlibVersion(), C.sizeof(ZStream)) == Z_OK
+    src = C.create_string_buffer(comp + tail, len(comp) + len(tail))
+    obuf = C.create_string_buffer(1 << 20)
+    strm.next_in, strm.avail_in = C.addressof(src), len(comp) + len(tail)
+    got = bytearray()
+    for _ in range(10000):
+        strm.next_out, strm.avail_out = C.addressof(obuf), 3000
+        rc = lib.inflate(C.byref(strm), Z_NO_FLUSH)
+        got += obuf.raw[:3000 - strm.avail_out]
+        assert strm.next_in == C.addressof(src) + strm.total_in
+        assert strm.total_in + strm.avail_in == len(comp) + len(tail)
+        if rc != Z_OK:
+            break
+    assert rc == Z_STREAM_END and bytes(got) == data and strm.avail_in == len(tail) and strm.total_in == len(comp)
+    lib.inflateEnd(C.byref(strm))
+
+    # Z_NEED_DICT in the middle: the bytes behind the stream still come back
+    zdict = data[:5000]
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, 8, 0, zdict)
+    dcomp = co.compress(data[3000:60000]) + co.flush()
+    strm = ZStream()
+    assert lib.inflateInit2_(C.byref(strm), 15, lib.zlibVersion(), C.sizeof(ZStream)) == Z_OK
+    src = C.create_string_buffer(dcomp + tail, len(dcomp) + len(tail))
+    strm.next_in, strm.avail_in = C.addressof(src), len(dcomp) + len(tail)
+    strm.next_out, strm.avail_out = C.addressof(obuf), 1 << 20
+    assert lib.inflate(C.byref(strm), Z_NO_FLUSH) == 2                      # Z_NEED_DICT
+    assert strm.total_in == 6 and strm.avail_in == len(dcomp) + len(tail) - 6   # header + DICTID, nothing else
+    assert lib.inflateSetDictionary(C.byref(strm), zdict, len(zdict)) == Z_OK
+    got = bytearray()
+    for _ in range(10000):
+        strm.next_out, strm.avail_out = C.addressof(obuf), 1 << 20
+        rc = lib.inflate(C.byref(strm), Z_NO_FLUSH)
+        got += obuf.raw[:(1 << 20) - strm.avail_out]
+        if rc != Z_OK:
+            break
+    assert rc == Z_STREAM_END and bytes(got) == data[3000:60000] and strm.avail_in == len(tail), (rc, strm.avail_in)
+    lib.inflateEnd(C.byref(strm))
+
+    # gz reader: two members, the first expands far beyond the queue limit; small gzread()s
+    _bind_gz(lib)
+    path = os.path.join(str(tmpdir), "two_members.gz")
+    second = o.gen_shard(5, 30000)
+    with open(path, "wb") as fh:
+        fh.write(gzip.compress(bytes(size) + data, 6))
+        fh.write(gzip.compress(second, 6))
+    assert _gz_read_all(lib, path, chunk=1000) == bytes(size) + data + second
+    assert _gz_read_all(lib, path, chunk=1 << 20) == bytes(size) + data + second

@@ -3,7 +3,7 @@
 Only what the deflate/inflate hot path needs lives here:
   csrc/        hand-written HIP kernels for gfx950 + the C ABI (libzmi355.so)
   engine.py    device-resident batch API (torch tensors in HBM, HIP stream from torch)
-  zlibmod.py   host-bytes mirror of the reference's one-shot API (compress / decompress / checksums)
+  dist.py      multi-GPU plumbing: shard ownership, size-table all-gather, slab exchange
 """
 from ._build import build  # noqa: F401
 

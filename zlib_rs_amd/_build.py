@@ -33,7 +33,9 @@ def build(force=False, verbose=False):
     # loading the engine never interposes the system libz of the process
     # -Bsymbolic-functions: calls between the zlib-named entry points (inflateResetKeep -> inflateReset, ...) must stay
     # inside this library even when the process has the system libz loaded in front of it
-    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic-functions", "-o", ABI_LIB] + \
+    # version script: the zlib version nodes (libz-rs-sys/include/zlib.map) and nothing exported but the entry points
+    cmd = [hipcc, "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic-functions",
+           "-Wl,--version-script=" + os.path.join(CSRC, "libz_mi355.map"), "-Wl,-soname,libz_mi355.so", "-o", ABI_LIB] + \
           [os.path.join(CSRC, s) for s in ABI_SOURCES] + ["-L" + HERE, "-lzmi355", "-Wl,-rpath,$ORIGIN"]
     if verbose:
         print(" ".join(cmd))

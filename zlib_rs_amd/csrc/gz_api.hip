@@ -8,6 +8,7 @@
 //
 // The first three members of the handle are public in zlib's ABI (the gzgetc() macro of zlib.h reads them,
 // gz.rs:27-41), so they keep their place and meaning: have, next, pos.
+#define ZLIB_CONST 1   // the library itself treats next_in / msg as pointers to const
 #include "../../include/zmi355_zlib.h"
 #include <errno.h>
 #include <fcntl.h>
@@ -194,17 +195,23 @@ int gz_look(GzState* s) {   // gz.rs:1296-1385: what comes next -- a gzip member
 int gz_decomp(GzState* s) {   // gz.rs:1456-1509: inflate into strm.next_out until it is full or the member ends
     const unsigned had = s->strm.avail_out;
     for (;;) {
-        if (s->strm.avail_in == 0 && gz_avail(s) == -1) return -1;
-        // this library's inflate() takes all input at once and hands the decoded bytes out over the following calls:
-        // no input left does not mean nothing to get.  Only a call that has no input AND yields nothing is the end.
-        const bool starved = s->strm.avail_in == 0;
+        // this library's inflate() may hold decoded bytes queued from input it took earlier: it is asked first, and the
+        // file is read only when it has nothing more to give (room left in the output, all input used).  A refill on
+        // "avail_in == 0" alone pulled a 4 MiB chunk per small gzread() while a member was still draining.
+        const uInt in_before = s->strm.avail_in, out_before = s->strm.avail_out;
         const int rc = inflate(&s->strm, Z_NO_FLUSH);
         if (rc == Z_STREAM_ERROR || rc == Z_NEED_DICT) { gz_error(s, Z_STREAM_ERROR, "internal error: inflate stream corrupt"); return -1; }
         if (rc == Z_MEM_ERROR) { gz_error(s, Z_MEM_ERROR, "out of memory"); return -1; }
         if (rc == Z_DATA_ERROR) { gz_error(s, Z_DATA_ERROR, s->strm.msg ? s->strm.msg : "compressed data error"); return -1; }
         if (rc == Z_STREAM_END) { s->how = LOOK; break; }
-        if (rc == Z_BUF_ERROR && starved) { gz_error(s, Z_BUF_ERROR, "unexpected end of file"); break; }
         if (s->strm.avail_out == 0) break;
+        if (s->strm.avail_in == 0) {   // everything buffered is decoded and handed out: more of the file
+            if (gz_avail(s) == -1) return -1;
+            if (s->strm.avail_in == 0) { gz_error(s, Z_BUF_ERROR, "unexpected end of file"); break; }
+        } else if (in_before == s->strm.avail_in && out_before == s->strm.avail_out) {
+            gz_error(s, Z_STREAM_ERROR, "internal error: inflate made no progress");
+            return -1;
+        }
     }
     s->have = had - s->strm.avail_out;
     s->next = s->strm.next_out - s->have;
@@ -435,6 +442,7 @@ z_size_t gzfread(voidp buf, z_size_t size, z_size_t nitems, gzFile file) {
     return len ? gz_read(s, (unsigned char*)buf, len) / size : 0;
     GZ_CATCH(0)
 }
+#undef gzgetc   // zlib.h's macro form; here the function itself is defined
 int gzgetc(gzFile file) {
     GZ_TRY
     GzState* s = st_of(file);

@@ -829,12 +829,18 @@ static __device__ __forceinline__ uint4 res_fetch(const uint8_t* dst, uint32_t n
 }
 // `pre` holds block [loaded, loaded + RES_BLK) when `have` is set: the load of the next block is always in
 // flight while the holes of the current one are filled
+// `keep` = lowest output byte the batch being staged for may still read (its first hole - 32768)
 static __device__ __forceinline__ void res_stage(uint8_t* ring, const uint8_t* dst, uint32_t n_out, uint32_t& loaded, uint32_t upto,
-                                                 bool aligned16, uint4& pre, bool& have, uint32_t& rb, uint32_t lo) {
+                                                 bool aligned16, uint4& pre, bool& have, uint32_t& rb, uint32_t lo, uint32_t keep) {
     const uint32_t lane = zmi_lane();
     zmi_wave_order();   // ring reads issued so far (write-back of final lines) stay in front of the stores below
     if (upto > loaded + RES_RING - 2048u) {   // a long stretch without holes: only the window matters
-        loaded = (upto - 32768u - 2u * RES_BLK) & ~(RES_BLK - 1u);
+        // restart at the block holding the oldest byte the batch can reference: `upto` is up to RES_SPAN + 3 past the
+        // first hole, so a start derived from it alone could land up to 3 bytes above first hole - 32768 (a distance of
+        // 32766..32768 then read bytes that were never staged).  Ring budget: keep's block start .. upto + RES_BLK
+        // <= 1023 + 32768 + RES_SPAN + 258 + RES_BLK <= RES_RING.
+        const uint32_t a = (upto - 32768u - 2u * RES_BLK) & ~(RES_BLK - 1u), b = keep & ~(RES_BLK - 1u);
+        loaded = a < b ? a : b;
         have = false;
     }
     while (loaded < upto) {
@@ -942,7 +948,8 @@ __global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, c
                 if (upto > wb) res_writeback(ring, dst, n_out, wb, upto, aligned4, rb);
                 if (fin > wb) wb = fin;
             }
-            if (p_last + 3u > loaded) res_stage(ring, dst, n_out, loaded, p_last + 3u, aligned16, pre, have, rb, lo);
+            const uint32_t keep = p_first > 32768u ? p_first - 32768u : 0u;
+            if (p_last + 3u > loaded) res_stage(ring, dst, n_out, loaded, p_last + 3u, aligned16, pre, have, rb, lo, keep);
             uint32_t rec = 0;
             if (active) {
                 const uint32_t a = res_ri(p, rb);
@@ -951,7 +958,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, c
             }
             const uint32_t mlen = (rec >> 15) + 3u, md = (rec & 0x7FFFu) + 1u;
             const uint32_t last_end = p_last + zmi_readlane(mlen, nb - 1u);
-            if (last_end > loaded) res_stage(ring, dst, n_out, loaded, last_end, aligned16, pre, have, rb, lo);
+            if (last_end > loaded) res_stage(ring, dst, n_out, loaded, last_end, aligned16, pre, have, rb, lo, keep);
             const uint32_t s0 = p - md;
             const uint32_t e = s0 + (mlen < md ? mlen : md);   // end of the bytes this hole reads
             uint32_t need = 0;                                  // holes of this batch that must be finished first

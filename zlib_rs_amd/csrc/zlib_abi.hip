@@ -12,6 +12,7 @@
 // libz-rs-sys-cdylib/src/lib.rs:5-6): every export is noexcept and catches std::bad_alloc.
 #include "zmi_kernels.h"
 #include "../../include/zmi355.h"
+#define ZLIB_CONST 1   // the library itself treats next_in / msg as pointers to const
 #include "../../include/zmi355_zlib.h"
 #include <mutex>
 #include <new>
@@ -125,6 +126,17 @@ uint32_t host_adler_combine(uint32_t a1, uint32_t a2, uint64_t len2) {
 // ------------------------------------------------------------------------------------------------
 std::mutex g_mu;
 zmi_ctx* g_ctx = nullptr;
+// the ABI layer's own hipMalloc / hipMemcpy calls run on the context's device and leave the caller's current device alone
+struct AbiDevice {
+    int prev = -1;
+    bool switched = false;
+    AbiDevice() {
+        const int dev = 0;   // abi_ctx() lives on device 0
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) switched = hipSetDevice(dev) == hipSuccess && prev >= 0;
+    }
+    ~AbiDevice() { if (switched) (void)hipSetDevice(prev); }
+};
 zmi_ctx* abi_ctx() {
     if (!g_ctx) {
         zmi_ctx* c = nullptr;
@@ -204,6 +216,7 @@ int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_
         return Z_OK;
     }
     std::lock_guard<std::mutex> lk(g_mu);
+    AbiDevice on_dev;
     zmi_ctx* c = abi_ctx();
     if (!c) return Z_MEM_ERROR;
     const size_t kSegment = segment_bytes();
@@ -272,6 +285,7 @@ int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_
 int gpu_inflate_stream(const uint8_t* in, size_t n, int wrap, std::vector<uint8_t>& out, size_t cap, uint32_t* in_used,
                        int32_t* status, int32_t* detail, const uint8_t* dict = nullptr, size_t dict_len = 0) {
     std::lock_guard<std::mutex> lk(g_mu);
+    AbiDevice on_dev;
     zmi_ctx* c = abi_ctx();
     if (!c) return Z_MEM_ERROR;
     if (n > 0xFFFFFFF0ull || cap > 0xFFFFFFF0ull) return Z_MEM_ERROR;
@@ -337,6 +351,7 @@ enum { IM_HEAD = 0, IM_DICT, IM_BLOCKS, IM_TRAILER, IM_DONE, IM_BAD };
 struct InflateState {
     int kind = KIND_INFLATE;
     int wrap = 1, wbits = 15;
+    int hdr_wbits = 0;             // windowBits 0: the window size the zlib header announces
     int mode = IM_HEAD;
     int form = -1;                 // wrapper found: 0 raw, 1 zlib, 2 gzip (-1: no header seen yet)
     std::vector<uint8_t> in;       // input from the checkpoint on; the next block starts at bit `sbit` of in[0]
@@ -420,19 +435,22 @@ const char* const kErrMsg[10] = {"need dictionary", "stream end", "", "file erro
 bool version_ok(const char* version, int stream_size) {  // lib.rs:2133-2143
     return version && version[0] == '1' && stream_size == (int)sizeof(z_stream);
 }
+// The reference installs its default allocator pair as soon as either callback is missing, so that the state is always
+// freed by the partner of what allocated it (zlib-rs/src/deflate.rs:264-280, inflate.rs:2240-2251; c_api.rs:120-122).
+voidpf default_zalloc(voidpf, uInt items, uInt size) { return malloc((size_t)items * size); }
+void default_zfree(voidpf, voidpf p) { free(p); }
 template <typename T>
 T* alloc_state(z_streamp strm) {
-    void* mem = nullptr;
-    if (strm->zalloc) mem = strm->zalloc(strm->opaque, 1, (uInt)sizeof(T));
-    else mem = malloc(sizeof(T));
+    if (!strm->zalloc || !strm->zfree) { strm->zalloc = default_zalloc; strm->zfree = default_zfree; strm->opaque = nullptr; }
+    void* mem = strm->zalloc(strm->opaque, 1, (uInt)sizeof(T));
     if (!mem) return nullptr;
     return new (mem) T();
 }
 template <typename T>
 void free_state(z_streamp strm, T* st) {
     st->~T();
-    if (strm->zalloc && strm->zfree) strm->zfree(strm->opaque, st);
-    else free(st);
+    if (strm->zfree) strm->zfree(strm->opaque, st);
+    else free(st);   // (a stream whose callbacks were cleared after init: what the default pair would have done)
 }
 DeflateState* dstate(z_streamp strm) {
     if (!strm || !strm->state) return nullptr;
@@ -509,7 +527,9 @@ int compress_buffered(DeflateState* s, bool finish, bool full_flush = false) {
     if (rc == Z_OK && s->wrap == 2) s->crc = gf2_mul(gf2_xpow8(s->in.size()), s->crc) ^ part;
     // window carry-over to the next call: the last 32 KiB of what the stream has seen (deflate.rs:2739-2752: only
     // Z_FULL_FLUSH forgets it)
-    if (full_flush || finish) s->hist.clear();
+    // (Z_FINISH leaves the window as it is -- deflateGetDictionary after the last deflate() still shows it, as
+    // libz-rs-sys-cdylib/example.c test_deflate_get_dict expects; nothing is compressed against it any more)
+    if (full_flush) s->hist.clear();
     else {
         s->hist.insert(s->hist.end(), s->in.begin(), s->in.end());
         if (s->hist.size() > 32768u) s->hist.erase(s->hist.begin(), s->hist.end() - 32768);
@@ -548,11 +568,15 @@ void inf_bad(InflateState* s, const char* msg) {
     s->in.clear();
     s->sbit = 0;
 }
+// The history a restart sees is the window the stream was opened with (1 << windowBits; the header's size for windowBits
+// 0): a distance that reaches further back than window + bytes decoded since the checkpoint is "invalid distance too far
+// back", as the reference reports it for window.have() + bytes written in the call (inflate.rs:839-850,2042-2047).
 void inf_keep_hist(InflateState* s, const uint8_t* p, size_t n) {
-    if (n >= 32768u) s->hist.assign(p + (n - 32768u), p + n);
+    const size_t w = s->wbits >= 8 && s->wbits <= 15 ? (size_t)1 << s->wbits : (s->hdr_wbits ? (size_t)1 << s->hdr_wbits : 32768u);
+    if (n >= w) s->hist.assign(p + (n - w), p + n);
     else {
         s->hist.insert(s->hist.end(), p, p + n);
-        if (s->hist.size() > 32768u) s->hist.erase(s->hist.begin(), s->hist.end() - 32768);
+        if (s->hist.size() > w) s->hist.erase(s->hist.begin(), s->hist.end() - w);
     }
 }
 // decoded bytes waiting for the caller before decoding pauses / input bytes handed to one device decode.
@@ -670,6 +694,7 @@ int inflate_run(z_streamp strm, InflateState* s) {
             if ((s->in[0] & 0x0F) != 8) { inf_bad(s, "unknown compression method"); break; }
             const int len = (s->in[0] >> 4) + 8;
             if (len > 15 || (s->wbits != 0 && len > s->wbits)) { inf_bad(s, "invalid window size"); break; }
+            if (s->wbits == 0) s->hdr_wbits = len;
             s->form = 1;
             s->check = 1;
             if (s->in[1] & 0x20) {   // FDICT: the DICTID follows; wait for inflateSetDictionary (inflate.rs:1036-1062)
@@ -1039,7 +1064,7 @@ int compress(Bytef* dest, uLongf* destLen, const Bytef* source, uLong sourceLen)
 
 // ---------------------------------------------------------------- inflate
 namespace {
-int parse_window_bits(int windowBits, int* wrap, int* wb) {   // inflate.rs:2298-2327
+static int parse_window_bits(int windowBits, int* wrap, int* wb) {   // inflate.rs:2298-2327
     int w = windowBits;
     if (w < 0) { if (w < -15) return Z_STREAM_ERROR; *wrap = ZMI_WRAP_RAW; w = -w; }
     else if (w >= 32) { *wrap = ZMI_WRAP_AUTO; w -= 32; }
@@ -1049,7 +1074,7 @@ int parse_window_bits(int windowBits, int* wrap, int* wb) {   // inflate.rs:2298
     *wb = w;
     return Z_OK;
 }
-void inflate_reset_state(z_streamp strm, InflateState* s) {
+static void inflate_reset_state(z_streamp strm, InflateState* s) {
     const int wrap = s->wrap, wb = s->wbits;
     uint8_t* bw = s->back_window;
     s->~InflateState();
@@ -1093,28 +1118,51 @@ int inflate(z_streamp strm, int flush) {
     if (s->bias) { strm->total_in += (uLong)s->bias; s->bias = 0; }
     const uInt in0 = strm->avail_in, out0 = strm->avail_out;
     uInt taken = 0;
-    if (s->mode != IM_DONE && s->mode != IM_BAD && in0) {
-        s->in.insert(s->in.end(), strm->next_in, strm->next_in + in0);
-        strm->next_in += in0; strm->total_in += in0; strm->avail_in = 0;
-        taken = in0;
-        s->in_sync = false;
-    }
+    // Bytes can only be handed back to the caller in the call that took them (next_in still points behind them).  So no
+    // call may return with bytes of its take buffered that the decoder has not read yet: whenever decoding stops before
+    // the buffered input is used up (Z_NEED_DICT; the pause while much output is queued), the unread tail of this call's
+    // take goes back -- the end of the stream is then always found in the call that delivered the bytes behind it, and
+    // those are returned exactly (the reference consumes only what it decodes, inflate.rs:2376-2457).
+    auto hand_back = [&](size_t keep) {
+        if (s->in.size() <= keep || taken == 0) return;
+        size_t n = s->in.size() - keep;
+        if (n > taken) n = taken;
+        strm->next_in -= n; strm->total_in -= (uLong)n; strm->avail_in += (uInt)n;
+        s->in.resize(s->in.size() - n);
+        taken -= (uInt)n;
+        s->tried = (size_t)-1;
+    };
+    // the caller's input is taken a piece at a time, and only while the decoder can use it: what a pause hands back (and
+    // the next call copies again) stays bounded, however much the caller offers
+    const size_t kAbsorb = abi_limit("ZMI_ABI_ABSORB", (size_t)16 << 20);
     for (;;) {
+        const bool paused = s->mode == IM_BLOCKS && s->out.size() - s->out_pos > queue_limit();
+        const bool wants_input = s->mode != IM_BLOCKS || s->in.empty() || s->tried == s->in.size();
+        if (s->mode != IM_DONE && s->mode != IM_BAD && strm->avail_in && !paused && wants_input) {
+            const uInt n = strm->avail_in < kAbsorb ? strm->avail_in : (uInt)kAbsorb;
+            s->in.insert(s->in.end(), strm->next_in, strm->next_in + n);
+            strm->next_in += n; strm->total_in += n; strm->avail_in -= n;
+            taken += n;
+            s->in_sync = false;
+        }
         const int was = s->mode;
         const int rc = inflate_run(strm, s);
-        if (rc == Z_NEED_DICT) return Z_NEED_DICT;
+        if (rc == Z_NEED_DICT) { hand_back(0); return Z_NEED_DICT; }
         if (rc != Z_OK) { strm->msg = zError(rc); return rc; }
         if (s->mode == IM_DONE && was != IM_DONE && !s->in.empty()) {
-            // bytes behind the end of the stream belong to the caller: hand them back -- as far as they came with this
-            // call (what an earlier call took cannot be returned any more)
-            const size_t unused = s->in.size() < taken ? s->in.size() : taken;
-            strm->next_in -= unused; strm->total_in -= unused; strm->avail_in += (uInt)unused;
+            hand_back(0);   // bytes behind the end of the stream belong to the caller
             s->in.clear();
         }
         inflate_drain(strm, s);
-        // decoding pauses while much output is queued; a caller who still has room gets the rest in this same call
-        if (strm->avail_out == 0 || s->mode != IM_BLOCKS || s->in.empty() || s->tried == s->in.size()) break;
+        if (strm->avail_out == 0 || s->mode == IM_DONE || s->mode == IM_BAD) break;
+        // the caller still has room: decoding that paused on queued output goes on (the queue is empty now), and a
+        // decoder that has used up what is buffered gets the next piece
+        const bool undecoded = s->mode == IM_BLOCKS && !s->in.empty() && s->tried != s->in.size();
+        if (!undecoded && strm->avail_in == 0) break;
     }
+    // paused (output queued beyond the limit, or the caller's buffer is full) with input the decoder has not reached:
+    // `stop` is how far it read (its bit reader runs a few bytes ahead, hence the margin)
+    if (s->mode == IM_BLOCKS && s->tried != s->in.size()) hand_back(s->stop > 64 ? s->stop - 64 : 0);
     const bool drained = s->out_pos >= s->out.size();
     // data_type as the reference reports it (inflate.rs:2440-2448): unused bits of the last byte, +64 in the last
     // block, +128 right behind a block

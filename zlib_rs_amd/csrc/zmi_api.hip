@@ -32,6 +32,22 @@ static int zmi_fail(int code, const char* what, hipError_t e = hipSuccess) {
         if (e_ != hipSuccess) return zmi_fail(ZMI_E_HIP, #call, e_); \
     } while (0)
 
+// Every entry point runs on the context's device and leaves the calling thread's current device as it found it (a
+// process that drives several GPUs -- one torch process with libz_mi355 loaded -- must not have its device switched
+// under it).
+struct zmi_dev_guard {
+    int prev = -1;
+    bool switched = false, ok = true;
+    explicit zmi_dev_guard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) { ok = hipSetDevice(dev) == hipSuccess; switched = ok && prev >= 0; }
+    }
+    ~zmi_dev_guard() { if (switched) (void)hipSetDevice(prev); }
+};
+#define ZMI_ON_DEVICE(c)                                         \
+    zmi_dev_guard dev_guard_((c)->device);                       \
+    if (!dev_guard_.ok) return zmi_fail(ZMI_E_HIP, "hipSetDevice")
+
 struct zmi_buf {
     void* p = nullptr;
     size_t cap = 0;
@@ -80,7 +96,6 @@ extern "C" int zmi_ctx_create(zmi_ctx** out, int device) {
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return zmi_fail(ZMI_E_NODEVICE, "no HIP device (this library has no CPU path)", e);
     if (device < 0 || device >= ndev) return zmi_fail(ZMI_E_ARG, "zmi_ctx_create: device index out of range");
-    ZMI_HIP(hipSetDevice(device));
     zmi_ctx* c = new zmi_ctx();
     c->device = device;
     const char* env = getenv("ZMI_SCRATCH_MB");
@@ -91,6 +106,7 @@ extern "C" int zmi_ctx_create(zmi_ctx** out, int device) {
 
 extern "C" int zmi_ctx_destroy(zmi_ctx* c) {
     if (!c) return ZMI_E_OK;
+    zmi_dev_guard dev_guard_(c->device);
     if (c->match.p) (void)hipFree(c->match.p);
     if (c->sums.p) (void)hipFree(c->sums.p);
     if (c->pieces.p) (void)hipFree(c->pieces.p);
@@ -130,6 +146,8 @@ struct zmi_scope_timer {
         c->timers.push_back(t);
     }
 };
+
+extern "C" int zmi_ctx_device(const zmi_ctx* c) { return c ? c->device : -1; }
 
 extern "C" int zmi_ctx_set_timing(zmi_ctx* c, int on) {
     if (!c) return zmi_fail(ZMI_E_ARG, "null context");
@@ -202,6 +220,7 @@ extern "C" int zmi_checksum_batch_dev(zmi_ctx* c, const void* d_data, const uint
                                       uint32_t n, int kind, uint32_t* d_adler, uint32_t* d_crc, void* stream) {
     if (!c) return zmi_fail(ZMI_E_ARG, "null context");
     if (n == 0) return ZMI_E_OK;
+    ZMI_ON_DEVICE(c);
     {
         zmi_scope_timer tm(c, ZMI_K_CHECKSUM, (hipStream_t)stream);
         zmi_launch_checksum((const uint8_t*)d_data, d_off, d_len, n, (uint32_t)kind, d_adler, d_crc, (hipStream_t)stream);
@@ -214,6 +233,7 @@ extern "C" int zmi_gen_shards_dev(zmi_ctx* c, void* d_out, uint64_t seed, uint32
                                   uint32_t shard_bytes, void* stream) {
     if (!c) return zmi_fail(ZMI_E_ARG, "null context");
     if (shard_bytes % 64u) return zmi_fail(ZMI_E_ARG, "shard_bytes must be a multiple of 64");
+    ZMI_ON_DEVICE(c);
     zmi_launch_gen((uint8_t*)d_out, seed, first_shard, n_shards, shard_bytes, (hipStream_t)stream);
     ZMI_HIP(hipGetLastError());
     return ZMI_E_OK;
@@ -279,7 +299,7 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     if (out_stride > 0xFFFFFFF0ull) return zmi_fail(ZMI_E_ARG, "shards larger than 3.5 GiB are not supported");
     if (n == 0) return ZMI_E_OK;
     hipStream_t stream = (hipStream_t)stream_;
-    ZMI_HIP(hipSetDevice(c->device));
+    ZMI_ON_DEVICE(c);
 
     // wrapper checksums
     int rc = zmi_reserve(c->sums, (size_t)n * 8u);
@@ -413,7 +433,7 @@ static int zmi_inflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     if (wrap < ZMI_WRAP_RAW || wrap > ZMI_WRAP_AUTO) return zmi_fail(ZMI_E_ARG, "wrap must be raw/zlib/gzip/auto");
     if (n == 0) return ZMI_E_OK;
     hipStream_t stream = (hipStream_t)stream_;
-    ZMI_HIP(hipSetDevice(c->device));
+    ZMI_ON_DEVICE(c);
     int rc = zmi_reserve(c->inf_tmp, (size_t)n * 24u);
     if (rc) return rc;
     uint64_t* d_bm_off = (uint64_t*)c->inf_tmp.p;
@@ -516,7 +536,7 @@ static int zmi_deflate_batch_simple(zmi_ctx* c, const uint8_t* in, const uint64_
                                  int32_t* status) {
     if (!c || (!in && n) || !in_off || !in_len || !out || !out_len || !status) return zmi_fail(ZMI_E_ARG, "null argument");
     if (n == 0) return ZMI_E_OK;
-    ZMI_HIP(hipSetDevice(c->device));
+    ZMI_ON_DEVICE(c);
     // pack the shards back to back on the device, 16-byte aligned starts (fast load path)
     std::vector<uint64_t> doff(n);
     uint64_t total = 0;
@@ -596,7 +616,7 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     const char* pl = getenv("ZMI_HOST_PIPELINE");   // 0: the plain copy-in / kernels / copy-out sequence
     if (chunks.size() < 3 || (pl && !atoi(pl)))   // two chunks overlap too little to pay for the whole-slot copies
         return zmi_deflate_batch_simple(c, in, in_off, in_len, n, level, strategy, wrap, out, out_stride, out_len, status);
-    ZMI_HIP(hipSetDevice(c->device));
+    ZMI_ON_DEVICE(c);
     {
         int irc = zmi_host_pipeline_init(c);
         if (irc) return irc;
@@ -677,7 +697,7 @@ static int zmi_inflate_batch_simple(zmi_ctx* c, const uint8_t* in, const uint64_
     if (!c || (!in && n) || !in_off || !in_len || !out_off || !out_cap || !out_len || !status)
         return zmi_fail(ZMI_E_ARG, "null argument");
     if (n == 0) return ZMI_E_OK;
-    ZMI_HIP(hipSetDevice(c->device));
+    ZMI_ON_DEVICE(c);
     std::vector<uint64_t> dioff(n), dooff(n);
     uint64_t tin = 0, tout = 0;
     for (uint32_t i = 0; i < n; ++i) {
@@ -758,7 +778,7 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     const char* pl = getenv("ZMI_HOST_PIPELINE");
     if (chunks.size() < 3 || (pl && !atoi(pl)))
         return zmi_inflate_batch_simple(c, in, in_off, in_len, n, wrap, out, out_off, out_cap, out_len, status);
-    ZMI_HIP(hipSetDevice(c->device));
+    ZMI_ON_DEVICE(c);
     int rc = zmi_host_pipeline_init(c);
     if (rc) return rc;
     uint64_t max_in = 0, max_out = 0;
@@ -858,7 +878,7 @@ extern "C" int zmi_inflate_resume(zmi_ctx* c, const uint8_t* in, uint32_t in_len
     if (!c || (!in && in_len) || (!hist && hist_len) || (!out && out_cap) || !out_len || !status || !detail || !in_used || !resume)
         return zmi_fail(ZMI_E_ARG, "null argument");
     if (in_len > 0xFFFFFF00u || out_cap > 0xFFFF0000u || in_bit > 7u) return zmi_fail(ZMI_E_ARG, "stream too large for one call");
-    ZMI_HIP(hipSetDevice(c->device));
+    ZMI_ON_DEVICE(c);
     if (hist_len > 32768u) { hist += hist_len - 32768u; hist_len = 32768u; }
     const size_t base = ((size_t)hist_len + 1023u) & ~(size_t)1023u;   // the output region stays aligned; the history ends where it starts
     int rc = zmi_reserve(c->st_in, (size_t)in_len + 64u);
