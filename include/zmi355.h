@@ -57,7 +57,7 @@ int zmi_ctx_set_scratch_limit(zmi_ctx* ctx, uint64_t bytes);
 int zmi_ctx_set_inflate_out_limit(zmi_ctx* ctx, uint64_t bytes);
 
 /* per-kernel HIP-event timing for benchmarking: kernels 0 checksum, 1 lz77, 2 encode, 3 inflate (decode),
- * 4 verify, 6 inflate (resolve).  zmi_ctx_get_timing synchronises, returns the sums (ms) / launch counts since the
+ * 4 verify, 6 inflate (resolve), 7 pack / stitch copies.  zmi_ctx_get_timing synchronises, returns the sums (ms) / launch counts since the
  * previous call (arrays of 8) and resets them. */
 int zmi_ctx_set_timing(zmi_ctx* ctx, int on);
 int zmi_ctx_get_timing(zmi_ctx* ctx, double* ms_sums, uint32_t* counts);
@@ -139,6 +139,27 @@ int zmi_checksum_batch_dev(zmi_ctx* ctx, const void* d_data, const uint64_t* d_o
 /* synthetic Silesia-like benchmark shards (csrc/shardgen.h): shard first_shard+i at d_out + i*shard_bytes */
 int zmi_gen_shards_dev(zmi_ctx* ctx, void* d_out, uint64_t seed, uint32_t first_shard, uint32_t n_shards,
                        uint32_t shard_bytes, void* stream);
+
+/* shard first_shard + i*shard_step at d_out + i*shard_bytes: a step of `world` is the round-robin shard ownership of a
+ * multi-GPU job (rank r owns the shards g with g % world == r, BASELINE.json configs[4]) */
+int zmi_gen_shards_strided_dev(zmi_ctx* ctx, void* d_out, uint64_t seed, uint32_t first_shard, uint32_t shard_step,
+                               uint32_t n_shards, uint32_t shard_bytes, void* stream);
+
+/* ---- the stitch (replaces the append loop of the reference's parallel-deflate recipe, zlib-rs/src/deflate.rs:4145-4221
+ * `split_deflate`; multi-member gzip as read by libz-rs-sys/src/gz.rs:1464-1506): the batch leaves its compressed
+ * shards in out_stride-strided slots; these calls turn them into dense, ordered bytes on the device ----
+ * zmi_scan_sizes_dev   d_off[0..n] = exclusive prefix sum of d_len[0..n) (u64; d_off[n] = total)
+ * zmi_copy_ranges_dev  range i: d_len[i] bytes from d_src + (d_src_off ? d_src_off[i] : i*src_stride) to
+ *                      d_dst + d_dst_off[i]; ranges that would end behind dst_cap are skipped (the offsets tell).
+ *                      max_len bounds d_len[] (it only shapes the launch).
+ * zmi_pack_slab_dev    both: the slots of one batch -> one dense slab + its offsets.  One D2H copy / one send per
+ *                      peer then moves the batch; after a slab exchange zmi_copy_ranges_dev scatters a peer's slab into
+ *                      the globally ordered output (d_src_off = the peer's scan, d_dst_off = global offsets). */
+int zmi_scan_sizes_dev(zmi_ctx* ctx, const uint32_t* d_len, uint32_t n, uint64_t* d_off, void* stream);
+int zmi_copy_ranges_dev(zmi_ctx* ctx, const void* d_src, const uint64_t* d_src_off, uint64_t src_stride, const uint32_t* d_len,
+                        uint32_t n, uint32_t max_len, void* d_dst, const uint64_t* d_dst_off, uint64_t dst_cap, void* stream);
+int zmi_pack_slab_dev(zmi_ctx* ctx, const void* d_slots, uint64_t slot_stride, const uint32_t* d_len, uint32_t n,
+                      void* d_slab, uint64_t slab_cap, uint64_t* d_off, void* stream);
 
 /* ---- host-buffer convenience wrappers: copy in, run the batch on the GPU, copy back ---- */
 int zmi_deflate_batch(zmi_ctx* ctx, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n_shards,

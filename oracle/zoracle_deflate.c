@@ -1012,3 +1012,59 @@ double zo_bench_deflate(uint64_t seed, uint32_t first_shard, uint32_t n_shards, 
     if (total_out) *total_out = tot;
     return dt;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Producer of the inflate benchmark's input (BASELINE.json configs[2]: "precompressed 1 MiB gzip blocks", produced by
+ * the CPU reference path and not by the GPU deflater): the synthetic shards first_shard .. first_shard + n_shards - 1
+ * compressed by this restatement of the reference at `level` with wrapper `wrap` (2 = gzip), `nthreads` POSIX threads,
+ * member i at out + i * out_stride, its size in out_len[i].  Returns the seconds the compression took (a second
+ * cpu_baseline sample), < 0 on failure.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    uint64_t seed; uint32_t shard_bytes, first_shard, first, count; int level, wrap; uint8_t* out; size_t out_stride;
+    uint32_t* out_len; int failed; pthread_barrier_t* bar;
+} zo_member_job;
+static void* zo_member_worker(void* arg) {
+    zo_member_job* j = (zo_member_job*)arg;
+    uint8_t* data = (uint8_t*)malloc(j->shard_bytes ? j->shard_bytes : 1);
+    pthread_barrier_wait(j->bar);
+    for (uint32_t i = 0; i < j->count && data; ++i) {
+        const uint32_t k = j->first + i;
+        size_t olen = 0;
+        zo_gen_shard(j->seed, j->first_shard + k, j->shard_bytes, data);
+        const int rc = zo_deflate(data, j->shard_bytes, j->out + (size_t)k * j->out_stride, j->out_stride, j->level, j->wrap, 0, 8, &olen);
+        if (rc != 0 && rc != 1) j->failed = 1;
+        j->out_len[k] = (uint32_t)olen;
+    }
+    if (!data) j->failed = 1;
+    pthread_barrier_wait(j->bar);
+    free(data);
+    return NULL;
+}
+double zo_deflate_shards(uint64_t seed, uint32_t first_shard, uint32_t n_shards, uint32_t shard_bytes, int level, int wrap,
+                         int nthreads, uint8_t* out, size_t out_stride, uint32_t* out_len) {
+    if (nthreads < 1) nthreads = 1;
+    if ((uint32_t)nthreads > n_shards) nthreads = (int)n_shards;
+    if (n_shards == 0) return 0.0;
+    pthread_t* th = (pthread_t*)calloc((size_t)nthreads, sizeof(pthread_t));
+    zo_member_job* jobs = (zo_member_job*)calloc((size_t)nthreads, sizeof(zo_member_job));
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, NULL, (unsigned)nthreads + 1);
+    uint32_t per = n_shards / (uint32_t)nthreads, extra = n_shards % (uint32_t)nthreads, at = 0;
+    for (int t = 0; t < nthreads; ++t) {
+        zo_member_job* j = &jobs[t];
+        j->seed = seed; j->shard_bytes = shard_bytes; j->first_shard = first_shard; j->first = at;
+        j->count = per + ((uint32_t)t < extra ? 1u : 0u); at += j->count;
+        j->level = level; j->wrap = wrap; j->out = out; j->out_stride = out_stride; j->out_len = out_len; j->bar = &bar;
+        pthread_create(&th[t], NULL, zo_member_worker, j);
+    }
+    pthread_barrier_wait(&bar);
+    double t0 = zo_now();
+    pthread_barrier_wait(&bar);
+    double dt = zo_now() - t0;
+    int failed = 0;
+    for (int t = 0; t < nthreads; ++t) { pthread_join(th[t], NULL); failed |= jobs[t].failed; }
+    pthread_barrier_destroy(&bar);
+    free(th); free(jobs);
+    return failed ? -1.0 : dt;
+}

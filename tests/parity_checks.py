@@ -1,0 +1,102 @@
+"""Parity checks shared by the emulator tests (CPU) and the -m gpu tests: the same seeded inputs go through the
+batch entry points (`zmi_inflate_batch*` -- the instantiation the benchmark times) and through the CPU oracle, and
+the per-stream return codes and bytes must be identical.
+
+`inflate_fn(streams, caps, wrap) -> (outputs, statuses)`; statuses in zlib numbering with 0 = complete stream
+(the oracle's zo_inflate returns Z_STREAM_END = 1 for that)."""
+import base64
+import json
+import lzma
+import os
+import zlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _want(o, stream, cap, wrap):
+    rc, out, _, msg = o.inflate(stream, cap, wrap)
+    return (0 if rc == 1 else rc), out, msg
+
+
+def golden_bitstreams_exact(inflate_fn, o):
+    """the reference's hand-made inflate bitstreams (test-libz-rs-sys/src/inflate.rs:734-1030, extracted to
+    tests/golden/inflate_vectors.json): every stream must end with exactly the code the oracle reports -- Z_OK with
+    identical bytes, Z_DATA_ERROR where the reference's test expects it, Z_BUF_ERROR for the deliberately cut ones"""
+    inf = json.load(open(os.path.join(HERE, "golden", "inflate_vectors.json")))
+    streams = [bytes.fromhex(v["input"]) for v in inf["bitstreams"]]
+    n = 0
+    for wrap in (0, 3):
+        idx = [i for i, v in enumerate(inf["bitstreams"]) if v["wrap"] == wrap]
+        caps = [8 * len(streams[i]) + 64 for i in idx]
+        outs, st = inflate_fn([streams[i] for i in idx], caps, wrap)
+        for k, i in enumerate(idx):
+            v = inf["bitstreams"][i]
+            rc, want, msg = _want(o, streams[i], caps[k], wrap)
+            assert int(st[k]) == rc, (v["source"], int(st[k]), rc, msg)
+            if v["expect"] == "data_error":
+                assert rc == -3, (v["source"], rc)
+            if rc == 0:
+                assert outs[k] == want, v["source"]
+            n += 1
+    return n
+
+
+def golden_files_exact(inflate_fn, o):
+    """the reference's binary inflate fixtures (test-libz-rs-sys/src/test-data: window-match-bug.zraw,
+    op-len-edge-case.zraw, text.gz, issue-109.gz, compression-corpus/*.gz)"""
+    inf = json.load(open(os.path.join(HERE, "golden", "inflate_vectors.json")))
+    for wrap in (0, 2):
+        files = [f for f in inf["files"] if f["wrap"] == wrap]
+        raws = [base64.b64decode(f["data_b64"]) for f in files]
+        outs, st = inflate_fn(raws, [f["out_len"] for f in files], wrap)
+        for f, out, s, raw in zip(files, outs, st, raws):
+            assert int(s) == 0, (f["source"], int(s))
+            assert len(out) == f["out_len"] and zlib.crc32(out) == f["out_crc32"] and zlib.adler32(out) == f["out_adler32"], f["source"]
+            assert out == o.inflate(raw, f["out_len"], wrap)[1]
+        # one byte of room too few / input cut short: the oracle's code, whatever it is
+        outs, st = inflate_fn(raws, [max(0, f["out_len"] - 1) for f in files], wrap)
+        for f, s, raw in zip(files, st, raws):
+            assert int(s) == _want(o, raw, max(0, f["out_len"] - 1), wrap)[0], f["source"]
+        cut = [r[:len(r) * 2 // 3] for r in raws]
+        outs, st = inflate_fn(cut, [f["out_len"] for f in files], wrap)
+        for f, s, raw in zip(files, st, cut):
+            assert int(s) == _want(o, raw, f["out_len"], wrap)[0], f["source"]
+    return len(inf["files"])
+
+
+def corrupt_streams_exact(inflate_fn, o, data):
+    """bit flips, truncations, wrong trailers: the status of every stream equals the oracle's for that exact stream
+    (replaces the `in (-3, -5)` of round 1)"""
+    good = zlib.compress(data, 6)
+    streams, caps = [good], [len(data)]
+    for at in (2, 5, 40, 200, 777, len(good) // 2, len(good) - 6, len(good) - 1):
+        for mask in (0x01, 0x5A, 0x80):
+            b = bytearray(good)
+            b[at] ^= mask
+            streams.append(bytes(b)); caps.append(len(data))
+    for cut in (0, 1, 2, 3, 10, 1000, len(good) - 5, len(good) - 4, len(good) - 1):
+        streams.append(good[:cut]); caps.append(len(data))
+    streams += [good, good, b"\x78\x9c\x07", b"\x79\x9c\x03\x00", b"\x78\x9c\x03\x00\x00\x00\x00\x01", b"\x78\x9c\x03\x00\x00\x00\x00\x00"]
+    caps += [100, 0, 100, 100, 100, 100]
+    outs, st = inflate_fn(streams, caps, 1)
+    for i, (s_, c) in enumerate(zip(streams, caps)):
+        rc, want, msg = _want(o, s_, c, 1)
+        assert int(st[i]) == rc, (i, int(st[i]), rc, msg)
+        if rc == 0:
+            assert outs[i] == want
+    return len(streams)
+
+
+def real_fixtures():
+    """[(name, bytes)] of lcet10.txt, paper-100k.pdf, fireworks.jpg (test-libz-rs-sys/src/deflate.rs:1982-2003)"""
+    fx = os.path.join(HERE, "golden", "fixtures")
+    out = []
+    for m in json.load(open(os.path.join(fx, "manifest.json"))):
+        raw = lzma.decompress(open(os.path.join(fx, m["name"] + ".xz"), "rb").read())
+        assert len(raw) == m["bytes"] and zlib.crc32(raw) == m["crc32"], m["name"]
+        out.append((m["name"], raw))
+    return out
+
+
+def tile(raw, size=1 << 20):
+    return (raw * (size // len(raw) + 1))[:size]

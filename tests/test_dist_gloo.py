@@ -32,6 +32,53 @@ def _worker(rank, world, port, n_total, q):
     assert table.shape == (world, len(mine))
     assert int(table[rank].sum()) == sum(len(m) for m in members)
     ordered = zd.gather_members_to_root(members, 0)
+    # ---- the slab exchange itself (the code that runs over RCCL on the GPUs), on CPU tensors: dense slab per rank,
+    # direct grouped send/recv in several rounds, all-gather and gather-to-root; the scatter by global offsets is done
+    # here in numpy (on the GPU it is csrc/pack.hip, tested in test_emu_kernels.py / test_gpu_parity.py)
+    import numpy as np
+    slab = torch.from_numpy(np.frombuffer(b"".join(members), dtype=np.uint8).copy())
+    slab_bytes = [int(x) for x in table.to(torch.int64).sum(1)]
+    so = zd.slab_offsets(table)
+    assert int(so[rank, -1]) == slab.numel() == slab_bytes[rank]
+    for mode, chunk in (("allgather", 1 << 30), ("allgather", 1000), ("gather", 4096)):
+        slabs = zd.exchange_slabs(slab, slab_bytes, mode=mode, root=0, chunk_bytes=chunk)
+        if mode == "gather" and rank != 0:
+            assert slabs is None
+            continue
+        stitched = np.zeros(total, dtype=np.uint8)
+        for r in range(world):
+            assert slabs[r].numel() == slab_bytes[r]
+            sr = slabs[r].numpy()
+            for j in range(table.shape[1]):
+                a, n = int(so[r, j]), int(table[r, j])
+                stitched[int(offs[r, j]):int(offs[r, j]) + n] = sr[a:a + n]
+        want = b"".join(o.gen_shard(g, 1 << 13) for g in range(n_total))
+        assert gzip.decompress(stitched.tobytes()) == want, mode      # every rank holds the whole file after the all-gather
+    # the bounded-memory form (what bench.py runs at N > 1): chunks arrive in reused staging and are consumed at once
+    for mode in ("allgather", "gather"):
+        stitched = np.zeros(total, dtype=np.uint8)
+        mine_so = so[rank]
+        for j in range(table.shape[1]):          # own shards do not travel
+            a, n = int(mine_so[j]), int(table[rank, j])
+            stitched[int(offs[rank, j]):int(offs[rank, j]) + n] = slab.numpy()[a:a + n]
+        peer_bytes = {}
+
+        def consume(peer, lo, view, peer_bytes=peer_bytes):
+            peer_bytes.setdefault(peer, bytearray())
+            assert len(peer_bytes[peer]) == lo
+            peer_bytes[peer] += view.numpy().tobytes()
+
+        got = zd.exchange_slabs_streaming(slab, slab_bytes, chunk_bytes=777, consume=consume, mode=mode, root=0)
+        if mode == "gather" and rank != 0:
+            assert got == 0
+            continue
+        assert got == sum(slab_bytes) - slab_bytes[rank]
+        for r, bts in peer_bytes.items():
+            sr = np.frombuffer(bytes(bts), dtype=np.uint8)
+            for j in range(table.shape[1]):
+                a, n = int(so[r, j]), int(table[r, j])
+                stitched[int(offs[r, j]):int(offs[r, j]) + n] = sr[a:a + n]
+        assert gzip.decompress(stitched.tobytes()) == b"".join(o.gen_shard(g, 1 << 13) for g in range(n_total)), mode
     tmax = zd.max_over_ranks(0.1 * (rank + 1), torch.device("cpu"))
     assert abs(tmax - 0.1 * world) < 1e-9
     if rank == 0:

@@ -90,19 +90,14 @@ def test_inflate_kernel_matches_oracle(eng, o):
 
 
 def test_inflate_kernel_golden_bitstreams(eng, o):
-    inf = json.load(open(os.path.join(HERE, "golden", "inflate_vectors.json")))
-    streams = [bytes.fromhex(v["input"]) for v in inf["bitstreams"]]
-    for wrap in (0, 3):
-        idx = [i for i, v in enumerate(inf["bitstreams"]) if v["wrap"] == wrap]
-        outs, st = eng.inflate([streams[i] for i in idx], [8 * len(streams[i]) + 64 for i in idx], wrap)
-        for k, i in enumerate(idx):
-            rc, want, _, msg = o.inflate(streams[i], 8 * len(streams[i]) + 64, wrap)
-            if inf["bitstreams"][i]["expect"] == "data_error":
-                assert st[k] == -3, (inf["bitstreams"][i]["source"], st[k])
-            else:
-                assert st[k] in (0, -5)
-                if st[k] == 0:
-                    assert outs[k] == want
+    import parity_checks
+    assert parity_checks.golden_bitstreams_exact(eng.inflate, o) >= 20
+    assert parity_checks.golden_files_exact(eng.inflate, o) >= 10
+
+
+def test_inflate_kernel_corrupt_streams_report_the_oracles_code(eng, o):
+    import parity_checks
+    parity_checks.corrupt_streams_exact(eng.inflate, o, o.gen_shard(2, 1 << 13))
 
 
 def test_inflate_kernel_errors(eng, o):
@@ -300,3 +295,16 @@ def test_batch_api_argument_errors(eng):
     for kw in (dict(ctx=None), dict(wrap=4), dict(wrap=-1)):
         assert icall(**kw) == E_ARG, kw
     assert icall(n=0) == 0
+
+
+def test_pack_slab_kernel(eng, o):
+    """csrc/pack.hip: strided slots -> dense slab, every source / destination alignment, empty and multi-tile ranges"""
+    rng_sizes = [0, 1, 2, 3, 4, 5, 15, 16, 17, 31, 33, 100, 4095, 4096, 4097, 8191, 8200, 12345, 0, 7]
+    members = [o.prng_bytes(40 + i, n, 1) if n else b"" for i, n in enumerate(rng_sizes)]
+    for stride, sb, db in ((12352, 0, 0), (12353, 3, 1), (12355, 13, 2), (12366, 16, 3)):
+        slab, off = eng.pack_slab(members, stride, slot_base=sb, slab_base=db)
+        assert slab == b"".join(members)
+        assert off == [sum(rng_sizes[:i]) for i in range(len(rng_sizes) + 1)]
+    few = [o.prng_bytes(9, 70001, 1), o.prng_bytes(8, 65536, 1)]          # few large ranges: several workgroups per range
+    slab, off = eng.pack_slab(few, 70016)
+    assert slab == b"".join(few) and off == [0, 70001, 70001 + 65536]

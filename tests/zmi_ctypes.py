@@ -26,6 +26,9 @@ def _bind(lib):
     vp = C.c_void_p
     lib.zmi_inflate_batch_dev.argtypes = [vp, vp, vp, vp, C.c_uint32, C.c_int, vp, vp, vp, vp, vp, vp]
     lib.zmi_ctx_set_inflate_out_limit.argtypes = [vp, C.c_uint64]
+    lib.zmi_scan_sizes_dev.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    lib.zmi_copy_ranges_dev.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, vp]
+    lib.zmi_pack_slab_dev.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp, C.c_uint64, vp, vp]
     lib.zmi_inflate_resume.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, u32p, i32p, i32p, u32p, u32p]
     return lib
 
@@ -124,6 +127,24 @@ class Engine:
         res = [bytes(out[int(ooff[i]):int(ooff[i]) + min(int(olen[i]), int(ocap[i]))]) for i in range(n)]
         guard = [bytes(out[int(ooff[i]) + int(ocap[i]):int(ooff[i]) + int(ocap[i]) + 1]) for i in range(n)]
         return res, [int(x) for x in st], guard
+
+    def pack_slab(self, members, stride, slot_base=0, slab_base=0):
+        """EMULATOR ONLY: members laid out in stride-d slots (first slot at byte slot_base of its buffer) ->
+        (slab bytes, offsets list of n + 1) through zmi_pack_slab_dev; the slab starts at byte slab_base of its buffer"""
+        n = len(members)
+        slots = np.full(slot_base + n * stride + 64, 0xA5, dtype=np.uint8)
+        for i, m in enumerate(members):
+            slots[slot_base + i * stride:slot_base + i * stride + len(m)] = np.frombuffer(m, dtype=np.uint8)
+        lens = np.array([len(m) for m in members], dtype=np.uint32)
+        total = int(lens.sum())
+        slab = np.full(slab_base + total + 64, 0xEE, dtype=np.uint8)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        rc = self.lib.zmi_pack_slab_dev(self.ctx, slots.ctypes.data + slot_base, stride, lens.ctypes.data, n,
+                                        slab.ctypes.data + slab_base, total, off.ctypes.data, None)
+        if rc != 0:
+            raise RuntimeError("zmi_pack_slab_dev failed: %d %s" % (rc, self.lib.zmi_last_error().decode()))
+        assert bytes(slab[:slab_base]) == b"\xee" * slab_base and bytes(slab[slab_base + total:]) == b"\xee" * 64   # nothing outside
+        return bytes(slab[slab_base:slab_base + total]), [int(x) for x in off]
 
     def inflate_resume(self, data, in_bit=0, hist=b"", cap=1 << 16):
         """one call of the resumable raw-deflate decode (zmi_inflate_resume) ->

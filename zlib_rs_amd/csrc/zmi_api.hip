@@ -57,7 +57,7 @@ struct zmi_timer {
     hipEvent_t a, b;
     int kernel;
 };
-enum { ZMI_K_CHECKSUM = 0, ZMI_K_LZ77 = 1, ZMI_K_ENCODE = 2, ZMI_K_INFLATE = 3, ZMI_K_VERIFY = 4, ZMI_K_GEN = 5, ZMI_K_RESOLVE = 6 };
+enum { ZMI_K_CHECKSUM = 0, ZMI_K_LZ77 = 1, ZMI_K_ENCODE = 2, ZMI_K_INFLATE = 3, ZMI_K_VERIFY = 4, ZMI_K_GEN = 5, ZMI_K_RESOLVE = 6, ZMI_K_PACK = 7 };
 
 struct zmi_ctx {
     bool timing = false;
@@ -237,6 +237,46 @@ extern "C" int zmi_gen_shards_dev(zmi_ctx* c, void* d_out, uint64_t seed, uint32
     zmi_launch_gen((uint8_t*)d_out, seed, first_shard, n_shards, shard_bytes, (hipStream_t)stream);
     ZMI_HIP(hipGetLastError());
     return ZMI_E_OK;
+}
+
+extern "C" int zmi_gen_shards_strided_dev(zmi_ctx* c, void* d_out, uint64_t seed, uint32_t first_shard, uint32_t shard_step,
+                                          uint32_t n_shards, uint32_t shard_bytes, void* stream) {
+    if (!c) return zmi_fail(ZMI_E_ARG, "null context");
+    if (shard_bytes % 64u) return zmi_fail(ZMI_E_ARG, "shard_bytes must be a multiple of 64");
+    ZMI_ON_DEVICE(c);
+    zmi_launch_gen_strided((uint8_t*)d_out, seed, first_shard, shard_step, n_shards, shard_bytes, (hipStream_t)stream);
+    ZMI_HIP(hipGetLastError());
+    return ZMI_E_OK;
+}
+
+// ---- the stitch: strided slots -> dense slab, slab -> globally ordered output (pack.hip) ----
+extern "C" int zmi_scan_sizes_dev(zmi_ctx* c, const uint32_t* d_len, uint32_t n, uint64_t* d_off, void* stream) {
+    if (!c || !d_off || (!d_len && n)) return zmi_fail(ZMI_E_ARG, "null argument");
+    ZMI_ON_DEVICE(c);
+    zmi_launch_scan_sizes(d_len, n, d_off, (hipStream_t)stream);
+    ZMI_HIP(hipGetLastError());
+    return ZMI_E_OK;
+}
+extern "C" int zmi_copy_ranges_dev(zmi_ctx* c, const void* d_src, const uint64_t* d_src_off, uint64_t src_stride,
+                                   const uint32_t* d_len, uint32_t n, uint32_t max_len, void* d_dst, const uint64_t* d_dst_off,
+                                   uint64_t dst_cap, void* stream) {
+    if (!c || !d_src || !d_len || !d_dst || !d_dst_off) return zmi_fail(ZMI_E_ARG, "null argument");
+    if (n == 0) return ZMI_E_OK;
+    ZMI_ON_DEVICE(c);
+    {
+        zmi_scope_timer tm(c, ZMI_K_PACK, (hipStream_t)stream);
+        zmi_launch_copy_ranges((const uint8_t*)d_src, d_src_off, src_stride, d_len, n, (uint8_t*)d_dst, d_dst_off, dst_cap, max_len,
+                               (hipStream_t)stream);
+    }
+    ZMI_HIP(hipGetLastError());
+    return ZMI_E_OK;
+}
+extern "C" int zmi_pack_slab_dev(zmi_ctx* c, const void* d_slots, uint64_t slot_stride, const uint32_t* d_len, uint32_t n,
+                                 void* d_slab, uint64_t slab_cap, uint64_t* d_off, void* stream) {
+    int rc = zmi_scan_sizes_dev(c, d_len, n, d_off, stream);
+    if (rc) return rc;
+    const uint32_t max_len = slot_stride > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)slot_stride;
+    return zmi_copy_ranges_dev(c, d_slots, nullptr, slot_stride, d_len, n, max_len, d_slab, d_off, slab_cap, stream);
 }
 
 static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n,

@@ -41,16 +41,46 @@ class Engine:
         return int(self.L.zmi_deflate_bound(int(n), int(wrap)))
 
     # ---- synthetic benchmark shards (csrc/shardgen.h) ----
-    def gen_shards(self, n_shards, shard_bytes=1 << 20, first_shard=0, seed=GEN_SEED, out=None):
+    def gen_shards(self, n_shards, shard_bytes=1 << 20, first_shard=0, seed=GEN_SEED, out=None, shard_step=1):
+        """shard first_shard + i*shard_step at out[i*shard_bytes:]; shard_step = world size gives a rank its round-robin
+        share of a multi-GPU job (dist.shards_of_rank)"""
         if out is None:
             out = torch.empty(n_shards * shard_bytes, dtype=torch.uint8, device=self.device)
         # the generator kernel indexes lines with 32-bit block ids: chunk very large batches
         step = 16384
         for s0 in range(0, n_shards, step):
             cnt = min(step, n_shards - s0)
-            _lib.check(self.L.zmi_gen_shards_dev(self._ctx, out.data_ptr() + s0 * shard_bytes, seed, first_shard + s0, cnt,
-                                                 shard_bytes, _stream_ptr()), "zmi_gen_shards_dev")
+            _lib.check(self.L.zmi_gen_shards_strided_dev(self._ctx, out.data_ptr() + s0 * shard_bytes, seed,
+                                                         first_shard + s0 * shard_step, shard_step, cnt, shard_bytes,
+                                                         _stream_ptr()), "zmi_gen_shards_strided_dev")
         return out
+
+    # ---- the stitch: strided slots -> dense slab -> globally ordered output (csrc/pack.hip) ----
+    def scan_sizes(self, lengths, out=None):
+        """exclusive prefix sum of the int32 sizes -> int64 offsets, n + 1 entries (last = total)"""
+        n = int(lengths.numel())
+        if out is None:
+            out = torch.empty(n + 1, dtype=torch.int64, device=self.device)
+        _lib.check(self.L.zmi_scan_sizes_dev(self._ctx, lengths.data_ptr(), n, out.data_ptr(), _stream_ptr()), "zmi_scan_sizes_dev")
+        return out
+
+    def pack_slab(self, slots, lengths, slab=None, offsets=None):
+        """slots [n, stride] uint8 with lengths[i] valid bytes each -> (slab uint8, offsets int64[n + 1]).  Without a
+        preallocated slab this synchronises once to size it."""
+        n = int(lengths.numel())
+        if offsets is None:
+            offsets = self.scan_sizes(lengths)
+        if slab is None:
+            slab = torch.empty(int(offsets[n].item()) + 16, dtype=torch.uint8, device=self.device)
+        self.copy_ranges(slots, None, slots.stride(0), lengths, slots.stride(0), slab, offsets)
+        return slab, offsets
+
+    def copy_ranges(self, src, src_off, src_stride, lengths, max_len, dst, dst_off):
+        n = int(lengths.numel())
+        _lib.check(self.L.zmi_copy_ranges_dev(self._ctx, src.data_ptr(), src_off.data_ptr() if src_off is not None else None,
+                                              int(src_stride), lengths.data_ptr(), n, int(min(max_len, 0xFFFFFFFF)), dst.data_ptr(),
+                                              dst_off.data_ptr(), int(dst.numel()), _stream_ptr()), "zmi_copy_ranges_dev")
+        return dst
 
     # ---- deflate ----
     def deflate_batch(self, data, offsets, lengths, max_len, level=6, strategy=0, wrap=WRAP_ZLIB, out=None, out_len=None,
