@@ -71,6 +71,9 @@ struct EncShared {
 #define M_HDIST 5
 #define M_HCLEN 6
 #define M_DYNHDR 7
+#define M_FAR4 8    // farthest distance at which a match of 4 / 5 / 6 bytes is still cheaper than its literals, judged by the
+#define M_FAR5 9    // code lengths of the block emitted last (enc_far_limits)
+#define M_FAR6 10
 
 // ---- symbol mapping (RFC 1951 3.2.5), computed instead of table-driven ----
 // length 3..258 -> (code index 0..28, extra bit count, extra value)
@@ -432,6 +435,51 @@ static __device__ void enc_header_plan_w(EncShared* S) {
     zmi_wave_sync();
 }
 
+// all lanes: how far back may a 4 / 5 / 6 byte match lie before its length + distance codes cost more bits than the
+// literals it replaces?  Classic zlib has one fixed answer (TOO_FAR = 4096 for 3-byte matches); the reference has none
+// outside Z_FILTERED (zlib-rs/src/deflate/algorithm/slow.rs:69-74).  Here the answer follows the data: after every
+// sub-block the symbol counts gathered so far (lf / df: the open block) give an entropy estimate of the average literal
+// cost and of the price of every length / distance code, and the parse of the next sub-block uses it.  Text (literals
+// ~5 bits) keeps 4-byte matches out to a few KiB, record data with cheap literals drops them beyond a few hundred
+// bytes.  (Estimated from counts, not from the Huffman code lengths of the last block: text grows one block per piece,
+// so a limit that waited for a finished block would never be used.)
+static __device__ __noinline__ void enc_far_limits(EncShared* S, const uint32_t* lf, const uint32_t* df) {
+    const uint32_t lane = zmi_lane();
+    uint32_t nl = 0, nlit = 0;
+    float hl = 0.f;   // sum f log2 f over the literals
+    for (uint32_t i = lane; i < 286u; i += 64u) {
+        const uint32_t f = lf[i];
+        nl += f;
+        if (i < 256u && f) { nlit += f; hl += (float)f * __log2f((float)f); }
+    }
+    nl = zmi_wave_sum(nl);
+    nlit = zmi_wave_sum(nlit);
+    const uint32_t hl16 = zmi_wave_sum((uint32_t)(hl * 16.f));
+    uint32_t dfl = lane < 30u ? df[lane] : 0u;
+    const uint32_t nd = zmi_wave_sum(dfl);
+    if (nlit < 256u || nd < 64u) return;   // too little to judge by: keep the limits in force
+    const float lgN = __log2f((float)nl);
+    // average literal cost in bits: log2 N - (sum f log2 f) / nlit
+    const float lit = lgN - (float)hl16 * (1.f / 16.f) / (float)nlit;
+    // price of every distance code: -log2 of its share (a code not seen yet: one occurrence) + its extra bits
+    const float dcost = __log2f((float)nd) - __log2f((float)(dfl ? dfl : 1u)) + (float)enc_dext(lane < 30u ? lane : 0u);
+#pragma unroll
+    for (uint32_t L = 4u; L <= 6u; ++L) {
+        const uint32_t fl = lf[257u + (L - 3u)];          // lengths 4, 5, 6 are codes 258, 259, 260: no extra bits
+        const float lcost = lgN - __log2f((float)(fl ? fl : 1u));
+        const bool ok = lane < 30u && lcost + dcost <= (float)L * lit;
+        const uint64_t m = __ballot(ok);
+        // the farthest affordable code: its range ends where the next code's base starts
+        uint32_t far = 1u;
+        if (m) {
+            const uint32_t top = 63u - (uint32_t)__clzll((unsigned long long)m);
+            far = top >= 29u ? 32768u : (top < 3u ? top + 1u : ((2u + ((top + 1u) & 1u)) << (((top + 1u) >> 1) - 1u)));
+        }
+        if (lane == 0) S->misc[M_FAR4 + (L - 4u)] = far;
+    }
+    zmi_wave_sync();
+}
+
 // all lanes: emit one deflate block for tokens [tok, tok+ntok) / raw bytes [bstart, bend)
 // (out of line: called from two places; the writer state and the parameters travel by value so that they stay in
 // registers on both sides of the call)
@@ -707,12 +755,21 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
     // the match words are fetched two segments ahead: the word of the NEXT segment is needed right away (its first
     // position decides the lazy rule of this segment's last one), so a load issued in the same iteration would put
     // one HBM round trip on every segment
+    // short matches that cost more than their literals are dropped before the parse looks at them (enc_far_limits)
+    if (lane == 0) { S->misc[M_FAR4] = prm.far4; S->misc[M_FAR5] = prm.far5; S->misc[M_FAR6] = 32768u; }
+    zmi_wave_sync();
+    uint32_t far4 = prm.far4, far5 = prm.far5, far6 = 32768u;
     uint32_t m_cur = (pstart + lane < pend) ? tokbuf[pstart + lane] : 0u;
     uint32_t m_next = (pstart + 64u + lane < pend) ? tokbuf[pstart + 64u + lane] : 0u;
     for (uint32_t seg = seg0; seg < nseg; ++seg) {
         const uint32_t pos = seg * 64u + lane;
         const uint32_t npos2 = pos + 128u;
         const uint32_t m_next2 = (npos2 < pend) ? tokbuf[npos2] : 0u;
+        {
+            const uint32_t l0 = (m_cur >> 8) & 0x1FFu, d0 = (m_cur >> 17) + 1u;
+            const uint32_t lim = l0 == 4u ? far4 : (l0 == 5u ? far5 : far6);
+            if (l0 >= 4u && l0 <= 6u && d0 > lim) m_cur &= 0xFFu;
+        }
         uint32_t first_next = (uint32_t)__shfl((int)m_next, 0);
         uint32_t m1 = __shfl_down(m_cur, 1u);
         if (lane == 63u) m1 = first_next;
@@ -794,6 +851,10 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
             nH = ntok;
             bendH = bmid;
             zmi_wave_sync();
+            if (!last_seg) {
+                enc_far_limits(S, S->lfreq, S->dfreq);   // the open block's statistics price the next sub-block's short matches
+                far4 = zmi_uniform(S->misc[M_FAR4]); far5 = zmi_uniform(S->misc[M_FAR5]); far6 = zmi_uniform(S->misc[M_FAR6]);
+            }
             if (last_seg || bendH - bstart >= prm.block_span) {
                 const uint32_t is_final = (last_seg && is_last) ? 1u : 0u;  // is_last implies last piece
                 __threadfence_block();

@@ -10,8 +10,8 @@
 //       win   32 KiB ring of input bytes (+32 mirrored bytes so an unaligned 16-byte read may straddle the wrap)
 //       prev  32 Ki x u16 ring: DISTANCE to the previous position with the same hash (0 = end of chain) --
 //             deltas instead of positions remove the reference's slide_hash pass (deflate/slide_hash.rs)
-//       head  8 Ki x u32: last position+1 per bucket of the 6-byte hash (the chain)
-//       head4 4 Ki x u32: last position+1 per bucket of the 4-byte hash (chain-less: one probe per position),
+//       head  16 Ki x u16: last position+1 (mod 2^16) per bucket of the 6-byte hash (the chain)
+//       head4 8 Ki x u16: last position+1 (mod 2^16) per bucket of the 4-byte hash (chain-less: one probe per position),
 //       c4    ring with the answer of that probe for the positions not searched yet
 //   * NO workgroup barrier in the steady state.  Wave 0 (levels 1-4: waves 0 and 1, alternating tiles) is the
 //     PRODUCER: it streams the shard from HBM (one coalesced 16 B/lane load per 1 KiB, issued a tile ahead),
@@ -40,14 +40,22 @@
 #define LZ_NW 16u
 #define LZ_WSIZE 32768u
 #define LZ_WMASK 32767u
-#define LZ_HBITS 13
+// Hash heads are 16-bit (position + 1 modulo 2^16; a distance beyond max_dist means "empty or stale"): twice the buckets
+// in the same LDS.  Buckets are what the search quality hangs on: a 32 KiB text window has ~20 K distinct 6-grams, with
+// 8 Ki buckets more than half of all chain links led to a different string (measured: 41 % of the chain candidates of
+// English text were real) and every such candidate costs a searcher a full step.  16 Ki + 8 Ki buckets are worth about
+// 1.5 chain steps (lcet10.txt, budget 4: 2.791 -> 2.827; budget 3 then equals the old budget 4).  The price: no 16-bit
+// LDS atomics, so an insert is a plain read + write; the 64 positions of one step that fall into the same bucket all
+// see the bucket's previous occupant (they lose each other as predecessors -- only distances below 64 are affected, a
+// few bits per match) and one of them becomes the new head.
+#define LZ_HBITS 14
 #define LZ_HSIZE (1u << LZ_HBITS)
 #define LZ_MIRROR 32u
 #define LZ_CTL 128u
-#define LZ_H4BITS 12
+#define LZ_H4BITS 13
 #define LZ_H4SIZE (1u << LZ_H4BITS)
 #define LZ_C4RING 4096u   // positions; >= 4 tiles, the producer never runs further ahead of the oldest search
-#define LZ_SMEM (LZ_WSIZE + LZ_MIRROR + 2u * LZ_WSIZE + 4u * LZ_HSIZE + 4u * LZ_H4SIZE + 2u * LZ_C4RING + LZ_CTL)
+#define LZ_SMEM (LZ_WSIZE + LZ_MIRROR + 2u * LZ_WSIZE + 2u * LZ_HSIZE + 2u * LZ_H4SIZE + 2u * LZ_C4RING + LZ_CTL)
 
 struct LzCtl {
     uint32_t ready;  // positions < ready are searchable (chain built, look-ahead bytes loaded)
@@ -104,8 +112,30 @@ static __device__ __forceinline__ void lz_store_chunk(uint8_t* win, uint32_t pos
 // H6 = true : the chain is keyed by a 6-byte hash -- far sparser, every link is a >= 6-byte match --
 //             and a second, chain-less table remembers the most recent position of every 4-byte
 //             hash; its answer for position p is parked in a small ring (c4) until p is searched.
+// The positions of one step that share a bucket do not see each other through the table (plain read, then write): the
+// nearest one within LZ_SIB lanes below is found with lane shuffles instead -- runs and short periods (zeros, "abab",
+// 3- and 4-byte records) keep their distance-1..4 predecessors, which is where such data gets its cheapest matches.
+#ifndef LZ_SIB
+#define LZ_SIB 4
+#endif
+static __device__ __forceinline__ void lz_siblings(uint32_t h, uint32_t h4v, uint32_t p, uint32_t& old, uint32_t& old4, bool with4) {
+    const uint32_t lane = zmi_lane();
+    uint32_t sib = 0, sib4 = 0;
+#pragma unroll
+    for (uint32_t k = LZ_SIB; k >= 1u; --k) {
+        const uint32_t o = (uint32_t)__shfl_up((int)h, k);
+        if (lane >= k && o == h) sib = k;
+        if (with4) {
+            const uint32_t o4 = (uint32_t)__shfl_up((int)h4v, k);
+            if (lane >= k && o4 == h4v) sib4 = k;
+        }
+    }
+    if (sib) old = (p + 1u - sib) & 0xFFFFu;
+    if (sib4) old4 = (p + 1u - sib4) & 0xFFFFu;
+}
+
 template <bool H6>
-static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_t* prev, uint32_t* head, uint32_t* head4,
+static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_t* prev, uint16_t* head, uint16_t* head4,
                                                      uint16_t* c4, uint32_t tile, uint32_t n, uint32_t max_dist, LzCtl* ctl,
                                                      uint32_t producers) {
     const uint32_t lane = zmi_lane();
@@ -137,18 +167,35 @@ static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_
         // every position of the tile has its 6 bytes: no per-lane bounds checks (all tiles but the last)
 #pragma unroll
         for (uint32_t s = 0; s < LZ_SUB; ++s) {
-            uint32_t p = tile * LZ_T + s * 64u + lane;
-            hv[s] = atomicMax(&head[hv[s]], p + 1u);
-            if (H6) h4[s] = atomicMax(&head4[h4[s]], p + 1u);
+            const uint32_t p = tile * LZ_T + s * 64u + lane;
+            uint32_t old = head[hv[s]], old4 = H6 ? head4[h4[s]] : 0u;
+            zmi_wave_order();   // all 64 reads of the step, then its writes (one instruction each on the hardware)
+            head[hv[s]] = (uint16_t)(p + 1u);
+            if (H6) head4[h4[s]] = (uint16_t)(p + 1u);
+            lz_siblings(hv[s], h4[s], p, old, old4, H6);
+            hv[s] = old;
+            h4[s] = old4;
             zmi_wave_sync();  // steps are position-ordered (no-op on hardware: one wave, in-order LDS)
         }
     } else {
 #pragma unroll
         for (uint32_t s = 0; s < LZ_SUB; ++s) {
-            uint32_t p = tile * LZ_T + s * 64u + lane;
-            uint32_t old = 0, old4 = 0;
-            if (p + (H6 ? 6u : 4u) <= n) old = atomicMax(&head[hv[s]], p + 1u);
-            if (H6 && p + 4u <= n) old4 = atomicMax(&head4[h4[s]], p + 1u);
+            const uint32_t p = tile * LZ_T + s * 64u + lane;
+            const bool in6 = p + (H6 ? 6u : 4u) <= n, in4 = H6 && p + 4u <= n;
+            uint32_t old = in6 ? head[hv[s]] : 0u, old4 = in4 ? head4[h4[s]] : 0u;
+            zmi_wave_order();
+            if (in6) head[hv[s]] = (uint16_t)(p + 1u);
+            if (in4) head4[h4[s]] = (uint16_t)(p + 1u);
+            {
+                // positions without their 6 (4) bytes take no part: give them hash values no other lane has
+                uint32_t o = old, o4 = old4;
+                lz_siblings(in6 ? hv[s] : 0x80000000u + lane, in4 ? h4[s] : 0x80000000u + lane, p, o, o4, H6);
+                old == o ? (void)0 : (void)0;
+                hv[s] = in6 ? o : 0u;
+                h4[s] = in4 ? o4 : 0u;
+                zmi_wave_sync();
+                continue;
+            }
             hv[s] = old;
             h4[s] = old4;
             zmi_wave_sync();
@@ -159,18 +206,15 @@ static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_
 #pragma unroll
     for (uint32_t s = 0; s < LZ_SUB; ++s) {
         uint32_t p = tile * LZ_T + s * 64u + lane;
-        uint32_t old = hv[s], delta = 0;
-        if (old != 0u && old <= p) {
-            uint32_t d = p + 1u - old;
-            if (d <= max_dist) delta = d;
-        }
+        // head values are positions + 1 modulo 2^16: the distance decides whether the entry is alive
+        const uint32_t old = hv[s];
+        uint32_t d = (p + 1u - old) & 0xFFFFu;
+        const uint32_t delta = (old != 0u && d != 0u && d <= max_dist && d <= p) ? d : 0u;
         prev[p & LZ_WMASK] = (uint16_t)delta;
         if (H6) {
-            uint32_t o4 = h4[s], d4 = 0;
-            if (o4 != 0u && o4 <= p) {
-                uint32_t d = p + 1u - o4;
-                if (d <= max_dist) d4 = d;
-            }
+            const uint32_t o4 = h4[s];
+            d = (p + 1u - o4) & 0xFFFFu;
+            const uint32_t d4 = (o4 != 0u && d != 0u && d <= max_dist && d <= p) ? d : 0u;
             c4[p & (LZ_C4RING - 1u)] = (uint16_t)d4;
         }
     }
@@ -184,8 +228,8 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
     ZMI_DYN_SMEM(smem);
     uint8_t* win = smem;
     uint16_t* prev = (uint16_t*)(smem + LZ_WSIZE + LZ_MIRROR);
-    uint32_t* head = (uint32_t*)(smem + LZ_WSIZE + LZ_MIRROR + 2u * LZ_WSIZE);
-    uint32_t* head4 = head + LZ_HSIZE;
+    uint16_t* head = (uint16_t*)(smem + LZ_WSIZE + LZ_MIRROR + 2u * LZ_WSIZE);
+    uint16_t* head4 = head + LZ_HSIZE;
     uint16_t* c4 = (uint16_t*)(head4 + LZ_H4SIZE);
     LzCtl* ctl = (LzCtl*)(c4 + LZ_C4RING);
 
@@ -214,8 +258,7 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
     const uint32_t ntiles = (n + LZ_T - 1u) / LZ_T;
     if (ntiles == 0) return;
 
-    for (uint32_t i = t; i < LZ_HSIZE; i += 1024u) head[i] = 0u;
-    for (uint32_t i = t; i < LZ_H4SIZE; i += 1024u) head4[i] = 0u;
+    for (uint32_t i = t; i < (LZ_HSIZE + LZ_H4SIZE) / 2u; i += 1024u) ((uint32_t*)head)[i] = 0u;   // head4 follows head
     if (t == 0) { ctl->ready = 0u; ctl->next = hist; ctl->atok = 0u; ctl->stored[0] = 0u; ctl->stored[1] = 0u; }
     if (t < LZ_NW) ctl->wmin[t] = 0xFFFFFFFFu;
     __syncthreads();
@@ -309,19 +352,33 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
             res = mylo & 0xFFu;
             uint32_t maxlen = n - p;
             if (maxlen > 258u) maxlen = 258u;
-            uint32_t delta = prev[p & LZ_WMASK];
-            // H6: the first candidate is the most recent 4-byte match (no chain of its own); the walk
-            // then continues along the 6-byte chain starting at this position's own link
-            uint32_t first_dn = 0;
-            bool probe = false;
+            const uint32_t delta = prev[p & LZ_WMASK];
+            uint32_t blen = 3u, bdist = 0u, tail = 0u;
+            // H6: the most recent 4-byte match (no chain of its own) is looked at first, outside the chain loop and with an
+            // 8-byte compare only: what it is for are the 4- and 5-byte matches the 6-byte chain cannot see; a longer match
+            // is in the chain as well.  (Peeling a full-size step out of the loop was slower -- lanes without a probe idle
+            // through it -- but this one is a third of a chain step and takes the probe bookkeeping out of every step.)
             if (H6) {
                 const uint32_t d4 = c4[p & (LZ_C4RING - 1u)];
-                if (d4 != 0u && d4 != delta) { first_dn = delta; delta = d4; probe = true; }
+                if (d4 != 0u && d4 != delta && maxlen >= 4u) {
+                    uint32_t a, b;
+                    lz_ring64(win, p - d4, a, b);
+                    const uint32_t c0 = zmi_ffbl(a ^ mylo), c1 = zmi_ffbl(b ^ myhi) | 32u;
+                    uint32_t l = (c0 < c1 ? c0 : c1) >> 3;
+                    l = l > 8u ? 8u : l;
+                    l = l > maxlen ? maxlen : l;
+                    if (l >= 4u) { blen = l; bdist = d4; }
+                }
             }
-            if (maxlen >= 4u && delta != 0u) {
+            // candidates per position: max_chain counts the probe
+            uint32_t chain = H6 ? (prm.max_chain > 1u ? prm.max_chain - 1u : prm.max_chain) : prm.max_chain;
+            if (maxlen >= 4u && delta != 0u && prm.max_chain != 0u) {
                 uint32_t cand = p - delta;
-                uint32_t blen = 3u, bdist = 0u, tail = 0u;
-                uint32_t chain = prm.max_chain;
+                // a match this long ends the walk: nice_len, the end of the input -- and, for the short budgets, good_len
+                // (the reference quarters the remaining chain there, longest_match.rs:60-66: of a budget of 3 nothing is left)
+                const bool deep = prm.max_chain > 8u;
+                uint32_t stoplen = prm.nice_len < maxlen ? prm.nice_len : maxlen;
+                if (!deep && prm.good_len < stoplen) stoplen = prm.good_len;
                 // The loop body is straight-line for the common case: a candidate is decided by its
                 // first 16 bytes (five aligned dwords, one LDS round trip together with the prev
                 // link).  Only matches of 16+ bytes enter the divergent extension loop, so the wave
@@ -330,9 +387,7 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                 for (;;) {
                     const uint32_t r = cand & LZ_WMASK;
                     const uint32_t* w = (const uint32_t*)(win + (r & ~3u));
-                    uint32_t dn = prev[r];
-                    const bool is_probe = H6 && probe;
-                    if (is_probe) { dn = first_dn; probe = false; }
+                    const uint32_t dn = prev[r];
                     const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
                     const uint32_t sh = r & 3u;
                     // first differing byte of the 16: v_ffbl gives -1 for an all-equal dword, so OR-ing in the dword's
@@ -369,17 +424,14 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                     blen = better ? l : blen;
                     bdist = better ? p - cand : bdist;
                     if (better && l >= 16u) tail = lz_ring32(win, p + l - 3u);
-                    if (better && l >= prm.good_len) chain >>= 1;  // a good match halves the remaining budget
-                    const bool stop = better && (l >= prm.nice_len || l >= maxlen);
-                    cand = is_probe ? p - dn : cand - dn;  // after the 4-byte probe the walk starts at p's own 6-byte link
+                    if (deep && better && l >= prm.good_len) chain >>= 1;  // deep walks: a good match halves the remaining budget
+                    cand -= dn;
                     chain -= 1u;   // may wrap below zero after the halving: compared as signed
-                    if (stop || dn == 0u || (int32_t)chain <= 0 || p - cand > prm.max_dist) break;
+                    if ((better && l >= stoplen) || dn == 0u || (int32_t)chain <= 0 || p - cand > prm.max_dist) break;
                 }
-                // the shortest matches are not worth a far distance: their length + distance codes cost more
-                // bits than the literals they replace
-                const bool too_far = (blen == 4u && bdist > prm.far4) || (blen == 5u && bdist > prm.far5);
-                if (blen >= 4u && !too_far) res |= (blen << 8) | ((bdist - 1u) << 17);
             }
+            // (whether a short match far back is worth its codes is the encoder's call: it knows the prices, enc_far_limits)
+            if (blen >= 4u) res |= (blen << 8) | ((bdist - 1u) << 17);
             mout[p] = res;
         }
       }

@@ -200,18 +200,19 @@ struct zmi_level_cfg {
     uint32_t chain, nice, good, lazy, tok;
 };
 // chain = candidates examined per position (the 4-byte probe counts as one); tok = tokens per sub-block of the
-// encoder's adaptive block splitting.  A chain step costs ~9 % of the level-6 run time and buys ~0.2 % ratio; the
-// block splitting buys 2.2 % for ~10 %, dropping far 4/5-byte matches 0.3 % for nothing -- so the table spends its
-// time there first.  Level 6 (chain 4): ratio 2.247 on the benchmark shards, the reference's level 6 gives 2.233.
+// encoder's adaptive block splitting.  Round 2 moved the curve: 16-bit hash heads (twice the buckets: fewer candidates
+// that are hash collisions), the probe as a slim 8-byte compare outside the chain loop, limits for short far matches
+// that follow the data (encode.hip enc_far_limits), 128 KiB pieces.  Level 6 = budget 5: lcet10.txt 2.79 -> 2.85 (the
+// reference's level 6: 2.91), benchmark shards 2.247 -> see DESIGN.md section 9.
 static const zmi_level_cfg kLevels[10] = {
     {0, 0, 0, 0, 4096},          // 0: stored
     {2, 16, 8, 0, 8192},         // 1
     {3, 32, 8, 0, 8192},         // 2
     {3, 32, 8, 4, 4096},         // 3
     {3, 64, 16, 8, 4096},        // 4
-    {3, 128, 32, 16, 4096},      // 5
-    {4, 128, 32, 16, 4096},      // 6
-    {6, 128, 32, 32, 4096},      // 7
+    {4, 128, 32, 16, 4096},      // 5
+    {5, 128, 32, 16, 4096},      // 6
+    {7, 128, 32, 32, 4096},      // 7
     {16, 258, 64, 128, 4096},    // 8
     {128, 258, 128, 258, 2048},  // 9
 };
@@ -371,7 +372,7 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     ep.max_lazy = L.lazy;
     ep.wrap = (uint32_t)wrap;
     ep.level = (uint32_t)level;
-    ep.block_span = 65536u;
+    ep.block_span = 131072u;   // one encoder wave per 128 KiB piece: 8 per 1 MiB shard (every piece end costs a sync marker and a block header)
     ep.strategy = (uint32_t)strategy;
     ep.chain_mode = chain_mode;
     ep.last_shard = n - 1u;
@@ -391,12 +392,16 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     lp.carry = chain_mode != 0u ? 1u : 0u;   // segments of one stream: a segment sees the window in front of it
     lp.dict_len = chain_mode != 0u ? dict_len : 0u;
     if (const char* cv = getenv("ZMI_CARRY")) lp.carry = (chain_mode != 0u && atoi(cv)) ? 1u : 0u;
-    lp.producers = L.chain <= 4u ? 2u : 1u;   // short chains: 14 searcher waves outrun one producer wave
+    lp.producers = L.chain <= 5u ? 2u : 1u;   // short chains: 14 searcher waves outrun one producer wave
     if (const char* pv = getenv("ZMI_PRODUCERS")) lp.producers = atoi(pv) > 1 ? 2u : 1u;
-    lp.far4 = 1024u;
-    lp.far5 = 8192u;
-    if (const char* f4 = getenv("ZMI_FAR4")) lp.far4 = (uint32_t)atoi(f4);
-    if (const char* f5 = getenv("ZMI_FAR5")) lp.far5 = (uint32_t)atoi(f5);
+    // short far matches are judged by the encoder, block by block, from the codes it just used (enc_far_limits); the
+    // search reports every match of 4+ bytes
+    lp.far4 = 32768u;
+    lp.far5 = 32768u;
+    ep.far4 = 2048u;    // the first block of a piece, before any code exists
+    ep.far5 = 16384u;
+    if (const char* f4 = getenv("ZMI_FAR4")) ep.far4 = (uint32_t)atoi(f4);
+    if (const char* f5 = getenv("ZMI_FAR5")) ep.far5 = (uint32_t)atoi(f5);
     ep.block_tokens = L.tok;
     ep.split_hdr_bits = 640u;
     if (const char* hb = getenv("ZMI_SPLIT_HDR")) ep.split_hdr_bits = (uint32_t)atoi(hb);

@@ -35,6 +35,8 @@ struct zmi_enc_params {
                            // a new one (the reference cuts at 16383 symbols, deflate.rs:321)
     uint32_t split_hdr_bits; // what a block of its own must save: the cost of another dynamic header
     uint32_t strategy;    // 0 default, 4 = Z_FIXED (static trees only)
+    uint32_t far4, far5;  // first block of a piece: a 4- (5-) byte match further back than this is dropped; later blocks derive
+                          // their limits from the codes of the block before (enc_far_limits)
     uint32_t chain_mode;  // 0: every shard is its own stream; 1: the shards of the batch are consecutive
                           // segments of ONE raw deflate stream, only shard `last_shard` ends it (BFINAL);
                           // 2: as 1 but nothing ends the stream (Z_SYNC_FLUSH / Z_FULL_FLUSH output)
