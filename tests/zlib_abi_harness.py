@@ -795,8 +795,8 @@ def gz_checks(lib, tmpdir, data, syslib=None):
     with open(p("bad.gz"), "wb") as fh:
         fh.write(blob[:100] + bytes(200) + blob[300:])
     f = lib.gzopen(p("bad.gz").encode(), b"r")
-    n = lib.gzread(f, big, len(expect))
-    msg = lib.gzerror(f, C.byref(err))
+    n = lib.gzread(f, big, len(expect) + 10)                  # past the end: zeros in the middle of Huffman-coded data may decode
+    msg = lib.gzerror(f, C.byref(err))                        # to valid (wrong) symbols -- the trailer's CRC then catches them
     assert n == -1 or err.value == Z_DATA_ERROR, (n, err.value, msg)
     assert lib.gzclose(f) == Z_OK
 

@@ -39,19 +39,27 @@
 #define ENC_NBL 19u
 #define ENC_STG 128u
 
+// 6.7 KiB per wave: 23 single-wave workgroups fit a CU's 160 KiB (the 9.2 KiB of round 1 held it at 17; the kernel waits on
+// memory half of its cycles, so resident waves are what hides that).  The code tables of the emission pass share their
+// space with the tree builder's scratch: the builder is done (and the header written) before the codes are generated.
 struct EncShared {
     uint32_t lfreq[ENC_NL];   // symbol counts of the open block
     uint32_t dfreq[ENC_ND];
     uint32_t lfreq2[ENC_NL];  // ... and of the sub-block being tokenised (joins the block or starts the next one)
     uint32_t dfreq2[ENC_ND];
-    uint32_t lcode[ENC_NL];  // bit-reversed code | len << 16
-    uint32_t dcode[ENC_ND];
+    union {
+        struct {              // tree construction (enc_rank_sort, enc_huff_lengths_w)
+            uint16_t order[ENC_NL];
+            uint16_t lpar[ENC_NL];
+            uint16_t ipar[ENC_NL];
+            uint16_t idep[ENC_NL];
+        };
+        struct {              // emission (after the header): bit-reversed code | len << 16
+            uint32_t lcode[ENC_NL];
+            uint32_t dcode[ENC_ND];
+        };
+    };
     uint32_t stg[ENC_STG];
-    uint32_t nfreq[ENC_NL];
-    uint16_t order[ENC_NL];
-    uint16_t lpar[ENC_NL];
-    uint16_t ipar[ENC_NL];
-    uint16_t idep[ENC_NL];
     uint8_t llen[ENC_NL];
     uint8_t dlen[ENC_ND];
     uint8_t bllen[32];
@@ -675,8 +683,14 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
     __shared__ EncShared Sh;
     EncShared* S = &Sh;
     const uint32_t lane = zmi_lane();
-    const uint32_t local = blockIdx.x / pieces;   // shard index inside this launch group
-    const uint32_t piece = blockIdx.x % pieces;
+    // Workgroup -> (shard, piece): consecutive workgroups take consecutive SHARDS of one piece index, in the rotated
+    // order of zmi_xcd_spread.  The dispatcher deals workgroups round-robin over 8 XCDs x 4 shader engines; with
+    // "pieces of a shard are neighbours" and 8 pieces per shard every shader engine saw two of the benchmark's eight data
+    // classes only, and the launch ran at the pace of the engine that had drawn the literal-heavy class (its pieces take
+    // three times as long as text): 230 ms per 16 Ki shards against 146 ms for the classes one by one.
+    const uint32_t n_local = gridDim.x / pieces;
+    const uint32_t local = zmi_xcd_spread(blockIdx.x % n_local, n_local);   // shard index inside this launch group
+    const uint32_t piece = blockIdx.x / n_local;
     const uint32_t s = first_shard + local;
     const uint8_t* src = data + off[s];
     const uint32_t n = len[s];

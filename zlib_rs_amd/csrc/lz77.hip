@@ -113,36 +113,41 @@ static __device__ __forceinline__ void lz_store_chunk(uint8_t* win, uint32_t pos
 //             and a second, chain-less table remembers the most recent position of every 4-byte
 //             hash; its answer for position p is parked in a small ring (c4) until p is searched.
 // The positions of one step that share a bucket do not see each other through the table (plain read, then write): the
-// nearest one within LZ_SIB lanes below is found with lane shuffles instead -- runs and short periods (zeros, "abab",
-// 3- and 4-byte records) keep their distance-1..4 predecessors, which is where such data gets its cheapest matches.
-#ifndef LZ_SIB
-#define LZ_SIB 4
-#endif
-static __device__ __forceinline__ void lz_siblings(uint32_t h, uint32_t h4v, uint32_t p, uint32_t& old, uint32_t& old4, bool with4) {
+// nearest one within two lanes below is found with DPP lane shifts instead -- runs and short periods (zeros, "abab")
+// keep their distance-1 / -2 predecessors, which is where such data gets its cheapest matches.
+// per step and lane ONE register: bucket of the 6-byte hash (14 bits) | bucket of the 4-byte hash (13 bits) << 14 |
+// sibling distance of the 6-byte hash (2 bits) << 27 | of the 4-byte hash << 29 (the kernel sits at the 128-VGPR limit
+// of a 1024-thread workgroup: two arrays of 16 spilled)
+static __device__ __forceinline__ uint32_t lz_pack_step(uint32_t h, uint32_t h4v, bool ok6, bool ok4) {
     const uint32_t lane = zmi_lane();
-    uint32_t sib = 0, sib4 = 0;
-#pragma unroll
-    for (uint32_t k = LZ_SIB; k >= 1u; --k) {
-        const uint32_t o = (uint32_t)__shfl_up((int)h, k);
-        if (lane >= k && o == h) sib = k;
-        if (with4) {
-            const uint32_t o4 = (uint32_t)__shfl_up((int)h4v, k);
-            if (lane >= k && o4 == h4v) sib4 = k;
-        }
-    }
-    if (sib) old = (p + 1u - sib) & 0xFFFFu;
-    if (sib4) old4 = (p + 1u - sib4) & 0xFFFFu;
+    // both buckets in one key: 6-byte hash in bits 0-13, 4-byte hash in bits 14-26.  Positions without their 6 (4) bytes
+    // (only in the last tile of a shard) take no part: their field holds a value no bucket has
+    const uint32_t key = (ok6 ? h : LZ_HSIZE + (lane & 3u)) | ((ok4 ? h4v : LZ_H4SIZE + (lane & 3u)) << 15);
+    const uint32_t x1 = zmi_lane_up1(key, ~key) ^ key;                 // lane 0 has no lane below: every field differs
+    const uint32_t u2 = zmi_lane_up1(zmi_lane_up1(key, ~key), ~key);
+    const uint32_t x2 = u2 ^ key;
+    // field equal <=> its bits of the XOR are zero
+    const uint32_t e1 = (x1 & 0x7FFFu) == 0u, e2 = (x2 & 0x7FFFu) == 0u, f1 = (x1 >> 15) == 0u, f2 = (x2 >> 15) == 0u;
+    const uint32_t sib = e1 ? 1u : (e2 ? 2u : 0u), sib4 = f1 ? 1u : (f2 ? 2u : 0u);
+    return h | (h4v << LZ_HBITS) | (sib << 27) | (sib4 << 29);
 }
 
-template <bool H6>
-static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_t* prev, uint16_t* head, uint16_t* head4,
-                                                     uint16_t* c4, uint32_t tile, uint32_t n, uint32_t max_dist, LzCtl* ctl,
-                                                     uint32_t producers) {
+// insert the 1024 positions of one tile into the hash structures in position order (one wave, 16
+// steps of 64; the three phases let the LDS reads, the table updates and the stores of all steps pipeline).
+// H6 = false: one chain keyed by a 4-byte hash (the reference's structure, hash_calc.rs:30-59).
+// H6 = true : the chain is keyed by a 6-byte hash -- far sparser, every link is a >= 6-byte match --
+//             and a second, chain-less table remembers the most recent position of every 4-byte
+//             hash; its answer for position p is parked in a small ring (c4) until p is searched.
+template <bool H6, bool full>   // full: every position of the tile has its 6 bytes (all tiles but the last): no bounds checks
+static __device__ __forceinline__ void lz_build_tile_t(const uint8_t* win, uint16_t* prev, uint16_t* head, uint16_t* head4,
+                                                       uint16_t* c4, uint32_t tile, uint32_t n, uint32_t max_dist, LzCtl* ctl,
+                                                       uint32_t producers) {
     const uint32_t lane = zmi_lane();
-    uint32_t hv[LZ_SUB], h4[LZ_SUB];
+    uint32_t st[LZ_SUB];
 #pragma unroll
     for (uint32_t s = 0; s < LZ_SUB; ++s) {
-        uint32_t p = tile * LZ_T + s * 64u + lane;
+        const uint32_t p = tile * LZ_T + s * 64u + lane;
+        uint32_t h, h4v = 0;
         if (H6) {
             uint32_t lo, hi;
             lz_ring64(win, p, lo, hi);
@@ -151,73 +156,61 @@ static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_
             // separately and summed; the top bits of the sum depend on every input bit
             const uint32_t a = lo & 0xFFFFFFu, b = (lo >> 24) | ((hi & 0xFFFFu) << 8);
             const uint32_t ma = __umul24(a, 0x9E3779u);
-            hv[s] = (ma + __umul24(b, 0x85EBCBu)) >> (32 - LZ_HBITS);
-            h4[s] = (ma + __umul24(lo >> 24, 0xC2B2AFu)) >> (32 - LZ_H4BITS);
+            h = (ma + __umul24(b, 0x85EBCBu)) >> (32 - LZ_HBITS);
+            h4v = (ma + __umul24(lo >> 24, 0xC2B2AFu)) >> (32 - LZ_H4BITS);
         } else {
-            uint32_t v = lz_ring32(win, p);
-            hv[s] = (v * 2654435761u) >> (32 - LZ_HBITS);  // multiplier as hash_calc.rs:30-33
-            h4[s] = 0;
+            const uint32_t v = lz_ring32(win, p);
+            h = (v * 2654435761u) >> (32 - LZ_HBITS);  // multiplier as hash_calc.rs:30-33
         }
+        st[s] = lz_pack_step(h, h4v, full || p + (H6 ? 6u : 4u) <= n, H6 && (full || p + 4u <= n));
+        if ((s & 3u) == 3u) zmi_sched_fence();   // four steps' loads and shuffles in flight at a time, not sixteen
     }
     // two producers hash alternate tiles concurrently; the inserts themselves must happen in position order
     if (producers > 1u) {
         while (lz_ld_acq(&ctl->atok) != tile) lz_pause();
     }
-    if ((tile + 1u) * LZ_T + 6u <= n) {
-        // every position of the tile has its 6 bytes: no per-lane bounds checks (all tiles but the last)
+    // table update: read the bucket's occupant, write this position.  The LDS runs a wave's instructions in order, so
+    // the 64 reads of a step see the writes of the step before without any wait in between
 #pragma unroll
-        for (uint32_t s = 0; s < LZ_SUB; ++s) {
-            const uint32_t p = tile * LZ_T + s * 64u + lane;
-            uint32_t old = head[hv[s]], old4 = H6 ? head4[h4[s]] : 0u;
-            zmi_wave_order();   // all 64 reads of the step, then its writes (one instruction each on the hardware)
-            head[hv[s]] = (uint16_t)(p + 1u);
-            if (H6) head4[h4[s]] = (uint16_t)(p + 1u);
-            lz_siblings(hv[s], h4[s], p, old, old4, H6);
-            hv[s] = old;
-            h4[s] = old4;
-            zmi_wave_sync();  // steps are position-ordered (no-op on hardware: one wave, in-order LDS)
-        }
-    } else {
-#pragma unroll
-        for (uint32_t s = 0; s < LZ_SUB; ++s) {
-            const uint32_t p = tile * LZ_T + s * 64u + lane;
-            const bool in6 = p + (H6 ? 6u : 4u) <= n, in4 = H6 && p + 4u <= n;
-            uint32_t old = in6 ? head[hv[s]] : 0u, old4 = in4 ? head4[h4[s]] : 0u;
-            zmi_wave_order();
-            if (in6) head[hv[s]] = (uint16_t)(p + 1u);
-            if (in4) head4[h4[s]] = (uint16_t)(p + 1u);
-            {
-                // positions without their 6 (4) bytes take no part: give them hash values no other lane has
-                uint32_t o = old, o4 = old4;
-                lz_siblings(in6 ? hv[s] : 0x80000000u + lane, in4 ? h4[s] : 0x80000000u + lane, p, o, o4, H6);
-                old == o ? (void)0 : (void)0;
-                hv[s] = in6 ? o : 0u;
-                h4[s] = in4 ? o4 : 0u;
-                zmi_wave_sync();
-                continue;
-            }
-            hv[s] = old;
-            h4[s] = old4;
-            zmi_wave_sync();
-        }
+    for (uint32_t s = 0; s < LZ_SUB; ++s) {
+        const uint32_t p = tile * LZ_T + s * 64u + lane;
+        const uint32_t h = st[s] & (LZ_HSIZE - 1u), h4v = (st[s] >> LZ_HBITS) & (LZ_H4SIZE - 1u);
+        const uint32_t sib = (st[s] >> 27) & 3u, sib4 = st[s] >> 29;
+        const bool in6 = full || p + (H6 ? 6u : 4u) <= n, in4 = H6 && (full || p + 4u <= n);
+        uint32_t old = in6 ? head[h] : 0u, old4 = in4 ? head4[h4v] : 0u;
+        zmi_wave_order();   // all 64 reads of the step, then its writes (one instruction each on the hardware)
+        if (in6) head[h] = (uint16_t)(p + 1u);
+        if (in4) head4[h4v] = (uint16_t)(p + 1u);
+        if (sib) old = (p + 1u - sib) & 0xFFFFu;       // a sibling of the same step is the nearer predecessor
+        if (sib4) old4 = (p + 1u - sib4) & 0xFFFFu;
+        st[s] = old | (old4 << 16);
+        zmi_wave_order();  // steps are position-ordered
     }
-    // the LDS executes a wave's operations in order: once this store is visible the atomics above have been applied
+    // once this store is visible the table updates above have been applied (in-order LDS)
     if (producers > 1u && lane == 0) lz_st_rel(&ctl->atok, tile + 1u);
 #pragma unroll
     for (uint32_t s = 0; s < LZ_SUB; ++s) {
         uint32_t p = tile * LZ_T + s * 64u + lane;
         // head values are positions + 1 modulo 2^16: the distance decides whether the entry is alive
-        const uint32_t old = hv[s];
+        const uint32_t old = st[s] & 0xFFFFu;
         uint32_t d = (p + 1u - old) & 0xFFFFu;
         const uint32_t delta = (old != 0u && d != 0u && d <= max_dist && d <= p) ? d : 0u;
         prev[p & LZ_WMASK] = (uint16_t)delta;
         if (H6) {
-            const uint32_t o4 = h4[s];
+            const uint32_t o4 = st[s] >> 16;
             d = (p + 1u - o4) & 0xFFFFu;
             const uint32_t d4 = (o4 != 0u && d != 0u && d <= max_dist && d <= p) ? d : 0u;
             c4[p & (LZ_C4RING - 1u)] = (uint16_t)d4;
         }
     }
+}
+
+template <bool H6>
+static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_t* prev, uint16_t* head, uint16_t* head4,
+                                                     uint16_t* c4, uint32_t tile, uint32_t n, uint32_t max_dist, LzCtl* ctl,
+                                                     uint32_t producers) {
+    if ((tile + 1u) * LZ_T + 6u <= n) lz_build_tile_t<H6, true>(win, prev, head, head4, c4, tile, n, max_dist, ctl, producers);
+    else lz_build_tile_t<H6, false>(win, prev, head, head4, c4, tile, n, max_dist, ctl, producers);
 }
 
 template <bool H6>

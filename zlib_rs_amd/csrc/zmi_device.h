@@ -34,6 +34,27 @@ static __device__ __forceinline__ void zmi_wave_sync() {
 }
 #endif
 
+// nothing moves across this point when the compiler schedules instructions (bounds how many loads of an unrolled loop it
+// keeps in flight -- and in registers -- at once)
+#ifdef ZMI_EMU
+static inline void zmi_sched_fence() {}
+#else
+static __device__ __forceinline__ void zmi_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+#endif
+
+// the value of the lane below (lane 0: `fill`).  DPP wave_shr:1 -- one VALU move, no LDS crossbar round trip and no
+// result register parked until it arrives (four ds_bpermute per step spilled the hash builder of lz77.hip to scratch)
+#ifdef ZMI_EMU
+static inline uint32_t zmi_lane_up1(uint32_t v, uint32_t fill) {
+    const uint32_t r = (uint32_t)__shfl_up((int)v, 1u);
+    return (threadIdx.x & 63u) == 0u ? fill : r;
+}
+#else
+static __device__ __forceinline__ uint32_t zmi_lane_up1(uint32_t v, uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);
+}
+#endif
+
 // tell the compiler a value is the same in every lane (it then lives in an SGPR and branches on it are scalar)
 #ifdef ZMI_EMU
 static inline uint32_t zmi_uniform(uint32_t v) { return v; }
