@@ -56,6 +56,10 @@ int zmi_ctx_set_scratch_limit(zmi_ctx* ctx, uint64_t bytes);
  * limit, i.e. 8 GiB of output -> 1 GiB of bitmap).  Streams beyond it report Z_MEM_ERROR (-4). */
 int zmi_ctx_set_inflate_out_limit(zmi_ctx* ctx, uint64_t bytes);
 
+/* hipStream_t the single-stream host wrappers of this context (zmi_inflate_resume) copy and launch on, and the only thing
+ * they wait for; default: the null stream.  One context per thread, each with its own stream, run concurrently. */
+int zmi_ctx_set_stream(zmi_ctx* ctx, void* stream);
+
 /* per-kernel HIP-event timing for benchmarking: kernels 0 checksum, 1 lz77, 2 encode, 3 inflate (decode),
  * 4 verify, 6 inflate (resolve), 7 pack / stitch copies.  zmi_ctx_get_timing synchronises, returns the sums (ms) / launch counts since the
  * previous call (arrays of 8) and resets them. */

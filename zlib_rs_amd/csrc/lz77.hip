@@ -163,7 +163,7 @@ static __device__ __forceinline__ void lz_build_tile_t(const uint8_t* win, uint1
             h = (v * 2654435761u) >> (32 - LZ_HBITS);  // multiplier as hash_calc.rs:30-33
         }
         st[s] = lz_pack_step(h, h4v, full || p + (H6 ? 6u : 4u) <= n, H6 && (full || p + 4u <= n));
-        if ((s & 3u) == 3u) zmi_sched_fence();   // four steps' loads and shuffles in flight at a time, not sixteen
+        if ((s & 7u) == 7u) zmi_sched_fence();   // eight steps' loads in flight at a time, not sixteen (registers)
     }
     // two producers hash alternate tiles concurrently; the inserts themselves must happen in position order
     if (producers > 1u) {
@@ -372,6 +372,7 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                 const bool deep = prm.max_chain > 8u;
                 uint32_t stoplen = prm.nice_len < maxlen ? prm.nice_len : maxlen;
                 if (!deep && prm.good_len < stoplen) stoplen = prm.good_len;
+                const uint32_t goodlen = deep ? prm.good_len : 259u;
                 // The loop body is straight-line for the common case: a candidate is decided by its
                 // first 16 bytes (five aligned dwords, one LDS round trip together with the prev
                 // link).  Only matches of 16+ bytes enter the divergent extension loop, so the wave
@@ -417,10 +418,13 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                     blen = better ? l : blen;
                     bdist = better ? p - cand : bdist;
                     if (better && l >= 16u) tail = lz_ring32(win, p + l - 3u);
-                    if (deep && better && l >= prm.good_len) chain >>= 1;  // deep walks: a good match halves the remaining budget
+                    // deep walks: a good match halves the remaining budget (goodlen = 259 for the short budgets: never)
+                    chain >>= (uint32_t)(better & (l >= goodlen));
                     cand -= dn;
                     chain -= 1u;   // may wrap below zero after the halving: compared as signed
-                    if ((better && l >= stoplen) || dn == 0u || (int32_t)chain <= 0 || p - cand > prm.max_dist) break;
+                    // (bitwise, not short-circuit: four compares and three ORs; as `||` the compiler built a branch per term)
+                    const bool stop = (better & (l >= stoplen)) | (dn == 0u) | ((int32_t)chain <= 0) | (p - cand > prm.max_dist);
+                    if (stop) break;
                 }
             }
             // (whether a short match far back is worth its codes is the encoder's call: it knows the prices, enc_far_limits)

@@ -14,6 +14,7 @@
 #include "../../include/zmi355.h"
 #define ZLIB_CONST 1   // the library itself treats next_in / msg as pointers to const
 #include "../../include/zmi355_zlib.h"
+#include <condition_variable>
 #include <mutex>
 #include <new>
 #include <stdlib.h>
@@ -121,36 +122,76 @@ uint32_t host_adler_combine(uint32_t a1, uint32_t a2, uint64_t len2) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// shared device context of the ABI layer (lazily created, serialised by a mutex: streams may be
-// used from different threads, one thread per stream, zlib-rs/src/deflate.rs:53-54)
+// Device side of the ABI layer: a small pool of engine contexts, each with its own non-blocking HIP stream.
+// A call leases one for its duration, copies / launches / waits on that stream only, and gives it back.  Streams of
+// different threads therefore run side by side on the GPU (zlib's contract: one thread per stream, streams freely in
+// parallel, zlib-rs/src/deflate.rs:53-54); round 1 held one process-wide mutex across copy -> kernels ->
+// hipDeviceSynchronize -> copies, which serialised every caller and stalled the whole device per call.  The only locks
+// left guard the pool bookkeeping, for a few instructions.
 // ------------------------------------------------------------------------------------------------
-std::mutex g_mu;
-zmi_ctx* g_ctx = nullptr;
-// the ABI layer's own hipMalloc / hipMemcpy calls run on the context's device and leave the caller's current device alone
+extern "C" int zmi_ctx_set_stream(zmi_ctx* c, void* stream);
+// the ABI layer's own hipMalloc / hipMemcpy calls run on the contexts' device and leave the caller's current device alone
 struct AbiDevice {
     int prev = -1;
     bool switched = false;
     AbiDevice() {
-        const int dev = 0;   // abi_ctx() lives on device 0
+        const int dev = 0;   // the ABI layer's contexts live on device 0
         if (hipGetDevice(&prev) != hipSuccess) prev = -1;
         if (prev != dev) switched = hipSetDevice(dev) == hipSuccess && prev >= 0;
     }
     ~AbiDevice() { if (switched) (void)hipSetDevice(prev); }
 };
-zmi_ctx* abi_ctx() {
-    if (!g_ctx) {
-        zmi_ctx* c = nullptr;
-        if (zmi_ctx_create(&c, 0) != 0) return nullptr;
-        g_ctx = c;
+struct AbiSlot { zmi_ctx* ctx = nullptr; hipStream_t stream = nullptr; bool busy = false; };
+constexpr int kAbiSlots = 16;
+AbiSlot g_slots[kAbiSlots];
+std::mutex g_mu;                 // pool bookkeeping only (slots, device buffers): never held across device work
+std::condition_variable g_slot_free;
+struct AbiLease {
+    AbiDevice on_dev;
+    int slot = -1;
+    zmi_ctx* ctx = nullptr;
+    hipStream_t stream = nullptr;
+    AbiLease() {
+        std::unique_lock<std::mutex> lk(g_mu);
+        for (;;) {
+            int fresh = -1;
+            for (int i = 0; i < kAbiSlots && slot < 0; ++i) {
+                if (g_slots[i].busy) continue;
+                if (g_slots[i].ctx) slot = i;
+                else if (fresh < 0) fresh = i;
+            }
+            if (slot < 0 && fresh >= 0) {   // no idle context: make another one
+                zmi_ctx* c = nullptr;
+                if (zmi_ctx_create(&c, 0) != 0) return;   // no HIP device (or out of memory): ctx stays null
+                hipStream_t st = nullptr;
+                if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+                (void)zmi_ctx_set_stream(c, st);
+                g_slots[fresh].ctx = c;
+                g_slots[fresh].stream = st;
+                slot = fresh;
+            }
+            if (slot >= 0) break;
+            g_slot_free.wait(lk);           // all sixteen in use: wait for one
+        }
+        g_slots[slot].busy = true;
+        ctx = g_slots[slot].ctx;
+        stream = g_slots[slot].stream;
     }
-    return g_ctx;
-}
+    ~AbiLease() {
+        if (slot < 0) return;
+        { std::lock_guard<std::mutex> lk(g_mu); g_slots[slot].busy = false; }
+        g_slot_free.notify_one();
+    }
+    AbiLease(const AbiLease&) = delete;
+    AbiLease& operator=(const AbiLease&) = delete;
+};
+bool abi_device_present() { AbiLease l; return l.ctx != nullptr; }
 // Device buffers of one call.  They come from a small pool that outlives the call: hipMalloc / hipFree cost far more than
 // the kernels of a small compress2() (hipFree also waits for the device), and a caller that compresses many small buffers
-// repeats the same sizes.  The pool is only touched under g_mu (every user of DevBuf holds it); buffers above kPoolKeep are
+// repeats the same sizes.  The pool is touched under g_mu for the moment of taking / returning a buffer; buffers above kPoolKeep are
 // returned to the driver at once so that one large call does not pin its memory.
 struct PoolSlot { void* p = nullptr; size_t cap = 0; bool busy = false; };
-constexpr int kPoolSlots = 12;
+constexpr int kPoolSlots = 64;
 constexpr size_t kPoolKeep = (size_t)256 << 20;
 PoolSlot g_pool[kPoolSlots];
 struct DevBuf {
@@ -160,6 +201,7 @@ struct DevBuf {
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     ~DevBuf() {
+        std::lock_guard<std::mutex> lk(g_mu);
         if (slot >= 0) {
             PoolSlot& q = g_pool[slot];
             q.busy = false;
@@ -167,6 +209,7 @@ struct DevBuf {
         } else if (p) (void)hipFree(p);
     }
     bool alloc(size_t n) {
+        std::lock_guard<std::mutex> lk(g_mu);
         if (n == 0) n = 16;
         int fit = -1, spare = -1;
         for (int i = 0; i < kPoolSlots; ++i) {
@@ -215,9 +258,9 @@ int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_
         else { const uint8_t m[5] = {0x00, 0x00, 0x00, 0xFF, 0xFF}; out.insert(out.end(), m, m + 5); }
         return Z_OK;
     }
-    std::lock_guard<std::mutex> lk(g_mu);
-    AbiDevice on_dev;
-    zmi_ctx* c = abi_ctx();
+    AbiLease lease;
+    zmi_ctx* c = lease.ctx;
+    hipStream_t hs = lease.stream;
     if (!c) return Z_MEM_ERROR;
     const size_t kSegment = segment_bytes();
     const uint32_t nseg = (uint32_t)((n + kSegment - 1) / kSegment);
@@ -234,30 +277,39 @@ int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_
     // (the reference's bound for a finished stream) does not cover for very short incompressible segments (11 bytes: 13 bytes
     // of fixed-Huffman block + marker = 17 > bound 16)
     const uint64_t stride = zmi_deflate_bound(max_len, ZMI_WRAP_RAW) + 16u;
-    DevBuf d_in, d_off, d_len, d_out, d_olen, d_st;
+    DevBuf d_in, d_off, d_len, d_out, d_olen, d_st, d_slab, d_soff;
     if (!d_in.alloc(base + n + 16) || !d_off.alloc(nseg * 8) || !d_len.alloc(nseg * 4) || !d_out.alloc((size_t)nseg * stride) ||
-        !d_olen.alloc(nseg * 4) || !d_st.alloc(nseg * 4))
+        !d_olen.alloc(nseg * 4) || !d_st.alloc(nseg * 4) || !d_slab.alloc((size_t)nseg * stride) || !d_soff.alloc(((size_t)nseg + 1) * 8))
         return Z_MEM_ERROR;
-    if (hist_len && hipMemcpy((uint8_t*)d_in.p + base - hist_len, hist, hist_len, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
-    if (hipMemcpy((uint8_t*)d_in.p + base, in, n, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
-    if (hipMemcpy(d_off.p, off.data(), nseg * 8, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
-    if (hipMemcpy(d_len.p, len.data(), nseg * 4, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
+    struct Sync { hipStream_t s; ~Sync() { (void)hipStreamSynchronize(s); } } sync_at_exit{hs};   // nothing in flight when the buffers go back
+    if (hist_len && hipMemcpyAsync((uint8_t*)d_in.p + base - hist_len, hist, hist_len, hipMemcpyHostToDevice, hs) != hipSuccess) return Z_MEM_ERROR;
+    if (hipMemcpyAsync((uint8_t*)d_in.p + base, in, n, hipMemcpyHostToDevice, hs) != hipSuccess) return Z_MEM_ERROR;
+    if (hipMemcpyAsync(d_off.p, off.data(), nseg * 8, hipMemcpyHostToDevice, hs) != hipSuccess) return Z_MEM_ERROR;
+    if (hipMemcpyAsync(d_len.p, len.data(), nseg * 4, hipMemcpyHostToDevice, hs) != hipSuccess) return Z_MEM_ERROR;
     // windowBits < 15: distances stay inside the window the header announces (deflate.rs:1423-1425)
     if (zmi_deflate_chain_window_dev(c, d_in.p, (const uint64_t*)d_off.p, (const uint32_t*)d_len.p, nseg, max_len, level, strategy,
                                      finish ? 1 : 0, (uint32_t)hist_len, (uint32_t)wbits, d_out.p, stride, (uint32_t*)d_olen.p,
-                                     (int32_t*)d_st.p, nullptr) != 0)
+                                     (int32_t*)d_st.p, hs) != 0)
         return Z_MEM_ERROR;
     DevBuf d_sum;
     if (check && wrap != 0) {
         if (!d_sum.alloc((size_t)nseg * 8)) return Z_MEM_ERROR;
         if (zmi_checksum_batch_dev(c, d_in.p, (const uint64_t*)d_off.p, (const uint32_t*)d_len.p, nseg, wrap == 1 ? 1 : 2,
-                                   (uint32_t*)d_sum.p, (uint32_t*)d_sum.p + nseg, nullptr) != 0)
+                                   (uint32_t*)d_sum.p, (uint32_t*)d_sum.p + nseg, hs) != 0)
             return Z_MEM_ERROR;
     }
-    if (hipDeviceSynchronize() != hipSuccess) return Z_MEM_ERROR;
+    // the segments' slots are packed into one dense slab on the device (csrc/pack.hip): the compressed stream leaves in
+    // ONE copy, whatever the number of segments (round 1: a copy per segment)
+    if (zmi_pack_slab_dev(c, d_out.p, stride, (const uint32_t*)d_olen.p, nseg, d_slab.p, (uint64_t)nseg * stride, (uint64_t*)d_soff.p, hs) != 0)
+        return Z_MEM_ERROR;
+    std::vector<uint64_t> soff((size_t)nseg + 1);
+    std::vector<int32_t> st(nseg);
+    std::vector<uint32_t> sums((size_t)nseg * 2);
+    if (hipMemcpyAsync(soff.data(), d_soff.p, ((size_t)nseg + 1) * 8, hipMemcpyDeviceToHost, hs) != hipSuccess) return Z_MEM_ERROR;
+    if (hipMemcpyAsync(st.data(), d_st.p, nseg * 4, hipMemcpyDeviceToHost, hs) != hipSuccess) return Z_MEM_ERROR;
+    if (check && wrap != 0 && hipMemcpyAsync(sums.data(), d_sum.p, (size_t)nseg * 8, hipMemcpyDeviceToHost, hs) != hipSuccess) return Z_MEM_ERROR;
+    if (hipStreamSynchronize(hs) != hipSuccess) return Z_MEM_ERROR;
     if (check && wrap != 0) {
-        std::vector<uint32_t> sums((size_t)nseg * 2);
-        if (hipMemcpy(sums.data(), d_sum.p, (size_t)nseg * 8, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR;
         uint32_t acc = wrap == 1 ? 1u : 0u;
         for (uint32_t i = 0; i < nseg; ++i) {
             if (wrap == 1) acc = host_adler_combine(acc, sums[i], len[i]);
@@ -265,18 +317,13 @@ int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_
         }
         *check = acc;
     }
-    std::vector<uint32_t> olen(nseg);
-    std::vector<int32_t> st(nseg);
-    if (hipMemcpy(olen.data(), d_olen.p, nseg * 4, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR;
-    if (hipMemcpy(st.data(), d_st.p, nseg * 4, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR;
-    for (uint32_t i = 0; i < nseg; ++i) {
+    for (uint32_t i = 0; i < nseg; ++i)
         if (st[i] != 0) return Z_BUF_ERROR;
-        size_t at = out.size();
-        if (last_at) *last_at = at;
-        out.resize(at + olen[i]);
-        if (hipMemcpy(out.data() + at, (const uint8_t*)d_out.p + (uint64_t)i * stride, olen[i], hipMemcpyDeviceToHost) != hipSuccess)
-            return Z_MEM_ERROR;
-    }
+    const size_t at0 = out.size(), total = (size_t)soff[nseg];
+    if (last_at) *last_at = at0 + (size_t)soff[nseg - 1];
+    out.resize(at0 + total);
+    if (total && hipMemcpyAsync(out.data() + at0, d_slab.p, total, hipMemcpyDeviceToHost, hs) != hipSuccess) return Z_MEM_ERROR;
+    if (hipStreamSynchronize(hs) != hipSuccess) return Z_MEM_ERROR;
     return Z_OK;
 }
 
@@ -284,40 +331,42 @@ int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_
 // dict / dict_len: preset dictionary (at most its last 32 KiB matter), placed directly in front of the output.
 int gpu_inflate_stream(const uint8_t* in, size_t n, int wrap, std::vector<uint8_t>& out, size_t cap, uint32_t* in_used,
                        int32_t* status, int32_t* detail, const uint8_t* dict = nullptr, size_t dict_len = 0) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    AbiDevice on_dev;
-    zmi_ctx* c = abi_ctx();
+    AbiLease lease;
+    zmi_ctx* c = lease.ctx;
+    hipStream_t hs = lease.stream;
     if (!c) return Z_MEM_ERROR;
     if (n > 0xFFFFFFF0ull || cap > 0xFFFFFFF0ull) return Z_MEM_ERROR;
     if (dict_len > 32768u) { dict += dict_len - 32768u; dict_len = 32768u; }
     const size_t base = (dict_len + 1023u) & ~(size_t)1023u;   // output region stays aligned; the dictionary ends where it starts
     DevBuf d_in, d_out, d_meta;
     if (!d_in.alloc(n + 16) || !d_out.alloc(base + cap + 16) || !d_meta.alloc(64)) return Z_MEM_ERROR;
-    if (n && hipMemcpy(d_in.p, in, n, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
-    if (dict_len && hipMemcpy((uint8_t*)d_out.p + base - dict_len, dict, dict_len, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
+    struct Sync { hipStream_t s; ~Sync() { (void)hipStreamSynchronize(s); } } sync_at_exit{hs};
+    if (n && hipMemcpyAsync(d_in.p, in, n, hipMemcpyHostToDevice, hs) != hipSuccess) return Z_MEM_ERROR;
+    if (dict_len && hipMemcpyAsync((uint8_t*)d_out.p + base - dict_len, dict, dict_len, hipMemcpyHostToDevice, hs) != hipSuccess) return Z_MEM_ERROR;
     // meta layout: in_off u64 | out_off u64 | in_len u32 | out_cap u32 | out_len u32 | status i32 | in_used u32 | detail i32 | hist u32
     uint64_t offs[2] = {0, (uint64_t)base};
     uint32_t lens[2] = {(uint32_t)n, (uint32_t)cap};
     uint32_t hist = (uint32_t)dict_len;
     uint8_t* m = (uint8_t*)d_meta.p;
-    if (hipMemcpy(m, offs, 16, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
-    if (hipMemcpy(m + 16, lens, 8, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
-    if (hipMemcpy(m + 40, &hist, 4, hipMemcpyHostToDevice) != hipSuccess) return Z_MEM_ERROR;
+    if (hipMemcpyAsync(m, offs, 16, hipMemcpyHostToDevice, hs) != hipSuccess) return Z_MEM_ERROR;
+    if (hipMemcpyAsync(m + 16, lens, 8, hipMemcpyHostToDevice, hs) != hipSuccess) return Z_MEM_ERROR;
+    if (hipMemcpyAsync(m + 40, &hist, 4, hipMemcpyHostToDevice, hs) != hipSuccess) return Z_MEM_ERROR;
     (void)zmi_ctx_set_inflate_out_limit(c, (uint64_t)cap + 4096u);
     if (zmi_inflate_batch_dict_dev(c, d_in.p, (const uint64_t*)m, (const uint32_t*)(m + 16), 1, wrap, d_out.p,
                                    (const uint64_t*)(m + 8), (const uint32_t*)(m + 20), (const uint32_t*)(m + 40),
-                                   (uint32_t*)(m + 24), (int32_t*)(m + 28), (uint32_t*)(m + 32), (int32_t*)(m + 36), nullptr) != 0)
+                                   (uint32_t*)(m + 24), (int32_t*)(m + 28), (uint32_t*)(m + 32), (int32_t*)(m + 36), hs) != 0)
         return Z_MEM_ERROR;
-    if (hipDeviceSynchronize() != hipSuccess) return Z_MEM_ERROR;
     uint32_t res[4];
-    if (hipMemcpy(res, m + 24, 16, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR;
+    if (hipMemcpyAsync(res, m + 24, 16, hipMemcpyDeviceToHost, hs) != hipSuccess) return Z_MEM_ERROR;
+    if (hipStreamSynchronize(hs) != hipSuccess) return Z_MEM_ERROR;
     uint32_t olen = res[0];
     *status = (int32_t)res[1];
     *in_used = res[2];
     *detail = (int32_t)res[3];
     if (olen > cap) olen = (uint32_t)cap;
     out.resize(olen);
-    if (olen && hipMemcpy(out.data(), (const uint8_t*)d_out.p + base, olen, hipMemcpyDeviceToHost) != hipSuccess) return Z_MEM_ERROR;
+    if (olen && hipMemcpyAsync(out.data(), (const uint8_t*)d_out.p + base, olen, hipMemcpyDeviceToHost, hs) != hipSuccess) return Z_MEM_ERROR;
+    if (hipStreamSynchronize(hs) != hipSuccess) return Z_MEM_ERROR;
     return Z_OK;
 }
 
@@ -592,8 +641,8 @@ size_t take_limit() { return abi_limit("ZMI_ABI_TAKE", (size_t)256 << 20); }
 // Decode what is buffered, from the checkpoint.  Queues every new byte, moves the checkpoint to the last block
 // boundary reached, and changes the mode when the final block ended or the data is invalid.
 int inflate_attempt(InflateState* s) {
-    std::lock_guard<std::mutex> lk(g_mu);
-    zmi_ctx* c = abi_ctx();
+    AbiLease lease;
+    zmi_ctx* c = lease.ctx;
     if (!c) return Z_MEM_ERROR;
     const size_t kTake = take_limit(), kQueueLimit = queue_limit();
     size_t take = s->in.size() < kTake ? s->in.size() : kTake;
@@ -805,10 +854,7 @@ int deflateInit2_(z_streamp strm, int level, int method, int windowBits, int mem
         strategy < 0 || strategy > Z_FIXED || (windowBits == 8 && wrap != 1))
         return Z_STREAM_ERROR;  // deflate.rs:299-306
     if (windowBits == 8) windowBits = 9;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        if (!abi_ctx()) { strm->msg = "no HIP device"; return Z_MEM_ERROR; }
-    }
+    if (!abi_device_present()) { strm->msg = "no HIP device"; return Z_MEM_ERROR; }
     DeflateState* s = alloc_state<DeflateState>(strm);
     if (!s) return Z_MEM_ERROR;
     s->level = level; s->strategy = strategy; s->wrap = wrap; s->wbits = windowBits;
@@ -972,8 +1018,8 @@ int deflateUsed(z_streamp strm, int* bits) {
     DeflateState* s = dstate(strm);
     if (!s) return Z_STREAM_ERROR;
     if (s->used_bits < 0) {
-        std::lock_guard<std::mutex> lk(g_mu);
-        zmi_ctx* c = abi_ctx();
+        AbiLease lease;
+        zmi_ctx* c = lease.ctx;
         if (!c) return Z_MEM_ERROR;
         // a flush ends with the empty stored block 00 00 FF FF: without those four bytes the decode stops at its header
         size_t n = s->last_seg.size();
@@ -1094,10 +1140,7 @@ int inflateInit2_(z_streamp strm, int windowBits, const char* version, int strea
     strm->msg = nullptr;
     int wrap = 0, wb = 0;
     if (parse_window_bits(windowBits, &wrap, &wb) != Z_OK) return Z_STREAM_ERROR;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        if (!abi_ctx()) { strm->msg = "no HIP device"; return Z_MEM_ERROR; }
-    }
+    if (!abi_device_present()) { strm->msg = "no HIP device"; return Z_MEM_ERROR; }
     InflateState* s = alloc_state<InflateState>(strm);
     if (!s) return Z_MEM_ERROR;
     s->wrap = wrap; s->wbits = wb;
@@ -1379,10 +1422,7 @@ int inflateBackInit_(z_streamp strm, int windowBits, unsigned char* window, cons
     if (!version_ok(version, stream_size)) return Z_VERSION_ERROR;
     if (!strm || !window || windowBits < 8 || windowBits > 15) return Z_STREAM_ERROR;
     strm->msg = nullptr;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        if (!abi_ctx()) { strm->msg = "no HIP device"; return Z_MEM_ERROR; }
-    }
+    if (!abi_device_present()) { strm->msg = "no HIP device"; return Z_MEM_ERROR; }
     InflateState* s = alloc_state<InflateState>(strm);
     if (!s) return Z_MEM_ERROR;
     s->wrap = ZMI_WRAP_RAW; s->wbits = windowBits; s->back_window = window;

@@ -75,6 +75,7 @@ struct zmi_ctx {
     hipStream_t hs_in = nullptr, hs_k = nullptr, hs_out = nullptr;
     bool hb_live = false;
     uint64_t inflate_out_limit = 0;  // output bytes one inflate batch may cover; 0 = scratch_limit
+    hipStream_t host_stream = nullptr;  // zmi_ctx_set_stream: where the host-buffer wrappers copy and launch
 };
 
 static int zmi_reserve(zmi_buf& b, size_t bytes) {
@@ -148,6 +149,15 @@ struct zmi_scope_timer {
 };
 
 extern "C" int zmi_ctx_device(const zmi_ctx* c) { return c ? c->device : -1; }
+
+// The single-stream host wrappers (zmi_inflate_resume) copy and launch on this stream and wait for it alone -- a caller
+// that gives every context its own non-blocking stream can drive several contexts from several threads without one
+// call stalling the device for the others (the stream ABI does, zlib_abi.hip).  Default: the null stream.
+extern "C" int zmi_ctx_set_stream(zmi_ctx* c, void* stream) {
+    if (!c) return zmi_fail(ZMI_E_ARG, "null context");
+    c->host_stream = (hipStream_t)stream;
+    return ZMI_E_OK;
+}
 
 extern "C" int zmi_ctx_set_timing(zmi_ctx* c, int on) {
     if (!c) return zmi_fail(ZMI_E_ARG, "null context");
@@ -930,28 +940,32 @@ extern "C" int zmi_inflate_resume(zmi_ctx* c, const uint8_t* in, uint32_t in_len
     if (!rc) rc = zmi_reserve(c->st_out, base + (size_t)out_cap + 64u);
     if (!rc) rc = zmi_reserve(c->st_meta, 256u);
     if (rc) return rc;
-    if (in_len) ZMI_HIP(hipMemcpy(c->st_in.p, in, in_len, hipMemcpyHostToDevice));
-    if (hist_len) ZMI_HIP(hipMemcpy((uint8_t*)c->st_out.p + base - hist_len, hist, hist_len, hipMemcpyHostToDevice));
+    hipStream_t hs = c->host_stream;
+    if (in_len) ZMI_HIP(hipMemcpyAsync(c->st_in.p, in, in_len, hipMemcpyHostToDevice, hs));
+    if (hist_len) ZMI_HIP(hipMemcpyAsync((uint8_t*)c->st_out.p + base - hist_len, hist, hist_len, hipMemcpyHostToDevice, hs));
     // meta: in_off u64 | out_off u64 | in_len | out_cap | hist | in_bit || out_len | status | in_used | detail | resume[4]
     struct { uint64_t in_off, out_off; uint32_t in_len, out_cap, hist, in_bit; } m = {0, (uint64_t)base, in_len, out_cap, hist_len, in_bit};
     uint8_t* d = (uint8_t*)c->st_meta.p;
-    ZMI_HIP(hipMemcpy(d, &m, sizeof(m), hipMemcpyHostToDevice));
+    ZMI_HIP(hipMemcpyAsync(d, &m, sizeof(m), hipMemcpyHostToDevice, hs));
     const uint64_t saved_limit = c->inflate_out_limit;
     c->inflate_out_limit = (uint64_t)out_cap + (1ull << 16);
     struct restore { zmi_ctx* c; uint64_t v; ~restore() { c->inflate_out_limit = v; } } restore_limit{c, saved_limit};
     rc = zmi_inflate_resume_dev(c, c->st_in.p, (const uint64_t*)d, (const uint32_t*)(d + 16), (const uint32_t*)(d + 28), 1, c->st_out.p,
                                 (const uint64_t*)(d + 8), (const uint32_t*)(d + 20), (const uint32_t*)(d + 24), (uint32_t*)(d + 32),
-                                (int32_t*)(d + 36), (uint32_t*)(d + 40), (int32_t*)(d + 44), (uint32_t*)(d + 48), nullptr);
-    if (rc) return rc;
-    ZMI_HIP(hipDeviceSynchronize());
+                                (int32_t*)(d + 36), (uint32_t*)(d + 40), (int32_t*)(d + 44), (uint32_t*)(d + 48), hs);
+    if (rc) { (void)hipStreamSynchronize(hs); return rc; }
     uint32_t r[8];
-    ZMI_HIP(hipMemcpy(r, d + 32, sizeof(r), hipMemcpyDeviceToHost));
+    ZMI_HIP(hipMemcpyAsync(r, d + 32, sizeof(r), hipMemcpyDeviceToHost, hs));
+    ZMI_HIP(hipStreamSynchronize(hs));   // this stream only: other contexts keep running
     *out_len = r[0];
     *status = (int32_t)r[1];
     *in_used = r[2];
     *detail = (int32_t)r[3];
     for (int i = 0; i < 4; ++i) resume[i] = r[4 + i];
     const uint32_t n = r[0] < out_cap ? r[0] : out_cap;
-    if (n) ZMI_HIP(hipMemcpy(out, (const uint8_t*)c->st_out.p + base, n, hipMemcpyDeviceToHost));
+    if (n) {
+        ZMI_HIP(hipMemcpyAsync(out, (const uint8_t*)c->st_out.p + base, n, hipMemcpyDeviceToHost, hs));
+        ZMI_HIP(hipStreamSynchronize(hs));
+    }
     return ZMI_E_OK;
 }
