@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# the libraries read their ZMI_* tuning / test overrides only in a process that has ZMI_TUNING set (checked once, at the
+# first call): the tests use them (segment sizes, queue limits, chunk sizes), a product process never calls getenv()
+os.environ.setdefault("ZMI_TUNING", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))

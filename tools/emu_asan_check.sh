@@ -19,6 +19,7 @@ H.streaming_checks(lib, o.gen_shard(0, 40000) + o.gen_shard(3, 30000))
 for seed in range(10):
     H.random_streaming_roundtrips(lib, o, 4, seed, max_len=30000)
 H.golden_inflate_checks(lib, json.load(open("tests/golden/inflate_vectors.json")))
+os.environ["ZMI_TUNING"] = "1"
 os.environ["ZMI_ABI_SEGMENT"] = "4096"
 H.run_abi_checks(lib, o, sizes=(0, 1, 100, 5000, 20000))
 H.header_copy_checks(lib, o.gen_shard(2, 40000))

@@ -10,6 +10,7 @@ import time
 import zlib
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+os.environ.setdefault("ZMI_TUNING", "1")
 os.environ.setdefault("ZMI_ABI_SEGMENT", "8192")
 import oracle_lib
 import zlib_abi_harness as H

@@ -4,6 +4,8 @@ whatever ZMI_* tuning variables the environment carries.  Used to tune the level
 synthetic generator ("tuned on the synthetic Zipf generator only")."""
 import os
 import sys
+
+os.environ.setdefault("ZMI_TUNING", "1")   # the ZMI_* overrides are honoured only with this set
 import zlib
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

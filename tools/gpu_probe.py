@@ -5,6 +5,8 @@ import hashlib
 import json
 import os
 import sys
+
+os.environ.setdefault("ZMI_TUNING", "1")   # the ZMI_* overrides are honoured only with this set
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -218,7 +218,11 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                                                         const uint32_t* __restrict__ len, uint32_t first_shard,
                                                         uint32_t* __restrict__ match, uint64_t match_stride,
                                                         zmi_lz_params prm) {
+#ifdef ZMI_EMU
     ZMI_DYN_SMEM(smem);
+#else
+    __shared__ __attribute__((aligned(16))) uint8_t smem[LZ_SMEM];   // static: LDS addresses fold into the instructions' offsets
+#endif
     uint8_t* win = smem;
     uint16_t* prev = (uint16_t*)(smem + LZ_WSIZE + LZ_MIRROR);
     uint16_t* head = (uint16_t*)(smem + LZ_WSIZE + LZ_MIRROR + 2u * LZ_WSIZE);
@@ -320,6 +324,7 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
     // walk as a tight per-lane loop: ONE round of LDS reads per candidate (the prev link of the
     // candidate, its first 8 window bytes and, once the best match is >= 8, the 4 bytes ending at
     // the best length), so a chain step costs one LDS latency, not two.
+    bool barren = false;   // the previous claim of this wave found no match anywhere
     for (;;) {
         // claim prm.claim positions (64 per round, one position per lane); one LDS atomic per claim
         uint32_t base0 = 0;
@@ -363,8 +368,11 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                     if (l >= 4u) { blen = l; bdist = d4; }
                 }
             }
-            // candidates per position: max_chain counts the probe
+            // candidates per position: max_chain counts the probe.  A wave whose previous claim found no match at all
+            // (incompressible stretches: every candidate there is a hash collision, and each costs a full step) walks
+            // one link only until something matches again -- the claims of a wave lie close together
             uint32_t chain = H6 ? (prm.max_chain > 1u ? prm.max_chain - 1u : prm.max_chain) : prm.max_chain;
+            if (barren && chain > 1u) chain = 1u;
             if (maxlen >= 4u && delta != 0u && prm.max_chain != 0u) {
                 uint32_t cand = p - delta;
                 // a match this long ends the walk: nice_len, the end of the input -- and, for the short budgets, good_len
@@ -431,6 +439,7 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
             if (blen >= 4u) res |= (blen << 8) | ((bdist - 1u) << 17);
             mout[p] = res;
         }
+        barren = __ballot(res > 0xFFu) == 0ull;
       }
     }
     if (lane == 0) lz_st_rel(&ctl->wmin[wave], 0xFFFFFFFFu);
@@ -443,22 +452,17 @@ extern "C" int zmi_launch_lz77(const uint8_t* d_data, const uint64_t* d_off, con
     // ring budget: 32 KiB = max_dist + 2 tiles of producer run-ahead + 2 tiles of slack for the searches in flight
     if (prm.max_dist > LZ_WSIZE - 4u * LZ_T - 16u) prm.max_dist = LZ_WSIZE - 4u * LZ_T - 16u;
     if (prm.claim != 128u && prm.claim != 192u && prm.claim != 256u) prm.claim = 64u;
-#ifndef ZMI_EMU
-    // 152 KiB of dynamic LDS: above the 64 KiB default, must be requested explicitly
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)zmi_lz77_kernel_t<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LZ_SMEM);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)zmi_lz77_kernel_t<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LZ_SMEM);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    // 152 KiB of LDS per workgroup, allocated statically in the product build (LZ_DYN: the emulator hands it out at launch)
+#ifdef ZMI_EMU
+    const uint32_t LZ_DYN = LZ_SMEM;
+#else
+    const uint32_t LZ_DYN = 0u;
 #endif
     if (prm.hash6) {
-        ZMI_LAUNCH(zmi_lz77_kernel_t<true>, dim3(n_shards), dim3(1024), LZ_SMEM, stream, d_data, d_off, d_len, first_shard,
+        ZMI_LAUNCH(zmi_lz77_kernel_t<true>, dim3(n_shards), dim3(1024), LZ_DYN, stream, d_data, d_off, d_len, first_shard,
                    d_match, match_stride, prm);
     } else {
-        ZMI_LAUNCH(zmi_lz77_kernel_t<false>, dim3(n_shards), dim3(1024), LZ_SMEM, stream, d_data, d_off, d_len, first_shard,
+        ZMI_LAUNCH(zmi_lz77_kernel_t<false>, dim3(n_shards), dim3(1024), LZ_DYN, stream, d_data, d_off, d_len, first_shard,
                    d_match, match_stride, prm);
     }
     return 0;

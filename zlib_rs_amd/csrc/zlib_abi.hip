@@ -233,10 +233,15 @@ struct DevBuf {
     }
 };
 
+// test overrides of the ABI layer's sizes: only in a process started with ZMI_TUNING set (checked once)
+const char* abi_tune(const char* name) {
+    static const bool enabled = getenv("ZMI_TUNING") != nullptr;
+    return enabled ? getenv(name) : nullptr;
+}
 size_t segment_bytes() {  // 1 MiB segments; ZMI_ABI_SEGMENT (bytes, multiple of 64) overrides for tests
     static size_t v = 0;
     if (!v) {
-        const char* e = getenv("ZMI_ABI_SEGMENT");
+        const char* e = abi_tune("ZMI_ABI_SEGMENT");
         long n = e ? atol(e) : 0;
         v = (n >= 64 && n <= (1 << 28)) ? ((size_t)n & ~(size_t)63) : ((size_t)1 << 20);
     }
@@ -631,7 +636,7 @@ void inf_keep_hist(InflateState* s, const uint8_t* p, size_t n) {
 // decoded bytes waiting for the caller before decoding pauses / input bytes handed to one device decode.
 // ZMI_ABI_QUEUE and ZMI_ABI_TAKE (bytes) override them so that tests reach these paths with small streams.
 size_t abi_limit(const char* name, size_t dflt) {
-    const char* e = getenv(name);
+    const char* e = abi_tune(name);
     const long long v = e ? atoll(e) : 0;
     return v > 0 ? (size_t)v : dflt;
 }

@@ -26,6 +26,13 @@ static int zmi_fail(int code, const char* what, hipError_t e = hipSuccess) {
     g_err = buf;
     return code;
 }
+// Tuning overrides (ZMI_CHAIN, ZMI_BLOCK_SPAN, ZMI_HOST_CHUNK ...) exist for the tests and the probe tools.  They are read
+// only in a process that was started with ZMI_TUNING set: checked once, so a product process never calls getenv() on its
+// hot path and its behaviour does not depend on whatever else is in the environment.
+static const char* zmi_tune(const char* name) {
+    static const bool enabled = getenv("ZMI_TUNING") != nullptr;
+    return enabled ? getenv(name) : nullptr;
+}
 #define ZMI_HIP(call)                                              \
     do {                                                           \
         hipError_t e_ = (call);                                    \
@@ -372,11 +379,11 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     if (window_bits < 15u) lp.max_dist = (1u << window_bits) - 262u;   // w_size - MIN_LOOKAHEAD (deflate.rs:1423-1425)
     lp.hash6 = 1u;  // 6-byte-hash chain + one 4-byte probe: ~1.5x fewer chain steps than a 4-byte chain at equal ratio
     lp.claim = 64u;
-    const char* claim_env = getenv("ZMI_CLAIM");
+    const char* claim_env = zmi_tune("ZMI_CLAIM");
     if (claim_env) lp.claim = (uint32_t)atoi(claim_env);
-    const char* md_env = getenv("ZMI_MAXDIST");
+    const char* md_env = zmi_tune("ZMI_MAXDIST");
     if (md_env && atoi(md_env) > 0 && (uint32_t)atoi(md_env) < lp.max_dist) lp.max_dist = (uint32_t)atoi(md_env);
-    const char* h6_env = getenv("ZMI_HASH6");
+    const char* h6_env = zmi_tune("ZMI_HASH6");
     if (h6_env) lp.hash6 = atoi(h6_env) ? 1u : 0u;
     zmi_enc_params ep;
     ep.max_lazy = L.lazy;
@@ -391,32 +398,32 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
                                                                  // position gets a candidate (a zero chain budget alone still
                                                                  // examines the first one)
     if (strategy == 3) lp.max_dist = 1;           // Z_RLE: distance-1 matches only
-    const char* chain_env = getenv("ZMI_CHAIN");  // tuning aid: override the chain budget of the selected level
+    const char* chain_env = zmi_tune("ZMI_CHAIN");  // tuning aid: override the chain budget of the selected level
     if (chain_env && atoi(chain_env) > 0 && level > 0 && strategy != 2) lp.max_chain = (uint32_t)atoi(chain_env);
-    const char* good_env = getenv("ZMI_GOOD");
+    const char* good_env = zmi_tune("ZMI_GOOD");
     if (good_env && atoi(good_env) > 0) lp.good_len = (uint32_t)atoi(good_env);
-    const char* nice_env = getenv("ZMI_NICE");
+    const char* nice_env = zmi_tune("ZMI_NICE");
     if (nice_env && atoi(nice_env) > 0) lp.nice_len = (uint32_t)atoi(nice_env);
-    const char* lazy_env = getenv("ZMI_LAZY");
+    const char* lazy_env = zmi_tune("ZMI_LAZY");
     if (lazy_env && atoi(lazy_env) >= 0) ep.max_lazy = (uint32_t)atoi(lazy_env);
     lp.carry = chain_mode != 0u ? 1u : 0u;   // segments of one stream: a segment sees the window in front of it
     lp.dict_len = chain_mode != 0u ? dict_len : 0u;
-    if (const char* cv = getenv("ZMI_CARRY")) lp.carry = (chain_mode != 0u && atoi(cv)) ? 1u : 0u;
+    if (const char* cv = zmi_tune("ZMI_CARRY")) lp.carry = (chain_mode != 0u && atoi(cv)) ? 1u : 0u;
     lp.producers = L.chain <= 5u ? 2u : 1u;   // short chains: 14 searcher waves outrun one producer wave
-    if (const char* pv = getenv("ZMI_PRODUCERS")) lp.producers = atoi(pv) > 1 ? 2u : 1u;
+    if (const char* pv = zmi_tune("ZMI_PRODUCERS")) lp.producers = atoi(pv) > 1 ? 2u : 1u;
     // short far matches are judged by the encoder, block by block, from the codes it just used (enc_far_limits); the
     // search reports every match of 4+ bytes
     lp.far4 = 32768u;
     lp.far5 = 32768u;
     ep.far4 = 2048u;    // the first block of a piece, before any code exists
     ep.far5 = 16384u;
-    if (const char* f4 = getenv("ZMI_FAR4")) ep.far4 = (uint32_t)atoi(f4);
-    if (const char* f5 = getenv("ZMI_FAR5")) ep.far5 = (uint32_t)atoi(f5);
+    if (const char* f4 = zmi_tune("ZMI_FAR4")) ep.far4 = (uint32_t)atoi(f4);
+    if (const char* f5 = zmi_tune("ZMI_FAR5")) ep.far5 = (uint32_t)atoi(f5);
     ep.block_tokens = L.tok;
     ep.split_hdr_bits = 640u;
-    if (const char* hb = getenv("ZMI_SPLIT_HDR")) ep.split_hdr_bits = (uint32_t)atoi(hb);
-    if (const char* bt = getenv("ZMI_BLOCK_TOKENS")) ep.block_tokens = (uint32_t)atoi(bt) >= 64u ? (uint32_t)atoi(bt) : 64u;
-    const char* span_env = getenv("ZMI_BLOCK_SPAN");
+    if (const char* hb = zmi_tune("ZMI_SPLIT_HDR")) ep.split_hdr_bits = (uint32_t)atoi(hb);
+    if (const char* bt = zmi_tune("ZMI_BLOCK_TOKENS")) ep.block_tokens = (uint32_t)atoi(bt) >= 64u ? (uint32_t)atoi(bt) : 64u;
+    const char* span_env = zmi_tune("ZMI_BLOCK_SPAN");
     if (span_env && atoi(span_env) >= 64) ep.block_span = (uint32_t)atoi(span_env);
 
     // match/token scratch: one u32 per position, shards padded to a multiple of 64 positions
@@ -432,7 +439,7 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     uint32_t pieces = (max_len + ep.block_span - 1u) / ep.block_span;
     if (pieces < 1u) pieces = 1u;
     if (pieces > 16u) pieces = 16u;
-    const char* pieces_env = getenv("ZMI_PIECES");
+    const char* pieces_env = zmi_tune("ZMI_PIECES");
     if (pieces_env && atoi(pieces_env) >= 1 && atoi(pieces_env) <= 64) pieces = (uint32_t)atoi(pieces_env);
     // every piece region must hold its worst case (stored blocks + marker) and stay 16-byte aligned
     while (pieces > 1u) {
@@ -653,7 +660,7 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     // 128-shard chunks made the kernels, not PCIe, the bottleneck).  ZMI_HOST_CHUNK (bytes) overrides both bounds (tests).
     uint64_t budget = 256ull << 20;
     uint32_t min_count = 1024u;
-    if (const char* e = getenv("ZMI_HOST_CHUNK")) { if (atoll(e) > 0) { budget = (uint64_t)atoll(e); min_count = 1u; } }
+    if (const char* e = zmi_tune("ZMI_HOST_CHUNK")) { if (atoll(e) > 0) { budget = (uint64_t)atoll(e); min_count = 1u; } }
     struct chunk { uint32_t first, count; uint64_t bytes; std::vector<uint64_t> doff; };
     std::vector<chunk> chunks;
     for (uint32_t i = 0; i < n;) {
@@ -668,7 +675,7 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         }
         chunks.push_back(std::move(ck));
     }
-    const char* pl = getenv("ZMI_HOST_PIPELINE");   // 0: the plain copy-in / kernels / copy-out sequence
+    const char* pl = zmi_tune("ZMI_HOST_PIPELINE");   // 0: the plain copy-in / kernels / copy-out sequence
     if (chunks.size() < 3 || (pl && !atoi(pl)))   // two chunks overlap too little to pay for the whole-slot copies
         return zmi_deflate_batch_simple(c, in, in_off, in_len, n, level, strategy, wrap, out, out_stride, out_len, status);
     ZMI_ON_DEVICE(c);
@@ -812,7 +819,7 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     // 17 GiB/s, 16384 at 41), so only very large host batches are cut.  ZMI_HOST_CHUNK (bytes) overrides both bounds (tests).
     uint64_t budget = 1ull << 30;
     uint32_t min_count = 8192u;
-    if (const char* e = getenv("ZMI_HOST_CHUNK")) { if (atoll(e) > 0) { budget = (uint64_t)atoll(e); min_count = 1u; } }
+    if (const char* e = zmi_tune("ZMI_HOST_CHUNK")) { if (atoll(e) > 0) { budget = (uint64_t)atoll(e); min_count = 1u; } }
     struct chunk { uint32_t first, count; uint64_t in_bytes, out_bytes; bool packed; std::vector<uint64_t> ioff, ooff; };
     std::vector<chunk> chunks;
     for (uint32_t i = 0; i < n;) {
@@ -830,7 +837,7 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         }
         chunks.push_back(std::move(ck));
     }
-    const char* pl = getenv("ZMI_HOST_PIPELINE");
+    const char* pl = zmi_tune("ZMI_HOST_PIPELINE");
     if (chunks.size() < 3 || (pl && !atoi(pl)))
         return zmi_inflate_batch_simple(c, in, in_off, in_len, n, wrap, out, out_off, out_cap, out_len, status);
     ZMI_ON_DEVICE(c);
