@@ -107,43 +107,22 @@ static __device__ __forceinline__ void lz_store_chunk(uint8_t* win, uint32_t pos
 }
 
 // insert the 1024 positions of one tile into the hash structures in position order (one wave, 16
-// steps of 64; the three phases let the LDS reads, the atomics and the stores of all steps pipeline).
-// H6 = false: one chain keyed by a 4-byte hash (the reference's structure, hash_calc.rs:30-59).
-// H6 = true : the chain is keyed by a 6-byte hash -- far sparser, every link is a >= 6-byte match --
-//             and a second, chain-less table remembers the most recent position of every 4-byte
-//             hash; its answer for position p is parked in a small ring (c4) until p is searched.
-// The positions of one step that share a bucket do not see each other through the table (plain read, then write): the
-// nearest one within two lanes below is found with DPP lane shifts instead -- runs and short periods (zeros, "abab")
-// keep their distance-1 / -2 predecessors, which is where such data gets its cheapest matches.
-// per step and lane ONE register: bucket of the 6-byte hash (14 bits) | bucket of the 4-byte hash (13 bits) << 14 |
-// sibling distance of the 6-byte hash (2 bits) << 27 | of the 4-byte hash << 29 (the kernel sits at the 128-VGPR limit
-// of a 1024-thread workgroup: two arrays of 16 spilled)
-static __device__ __forceinline__ uint32_t lz_pack_step(uint32_t h, uint32_t h4v, bool ok6, bool ok4) {
-    const uint32_t lane = zmi_lane();
-    // both buckets in one key: 6-byte hash in bits 0-13, 4-byte hash in bits 14-26.  Positions without their 6 (4) bytes
-    // (only in the last tile of a shard) take no part: their field holds a value no bucket has
-    const uint32_t key = (ok6 ? h : LZ_HSIZE + (lane & 3u)) | ((ok4 ? h4v : LZ_H4SIZE + (lane & 3u)) << 15);
-    const uint32_t x1 = zmi_lane_up1(key, ~key) ^ key;                 // lane 0 has no lane below: every field differs
-    const uint32_t u2 = zmi_lane_up1(zmi_lane_up1(key, ~key), ~key);
-    const uint32_t x2 = u2 ^ key;
-    // field equal <=> its bits of the XOR are zero
-    const uint32_t e1 = (x1 & 0x7FFFu) == 0u, e2 = (x2 & 0x7FFFu) == 0u, f1 = (x1 >> 15) == 0u, f2 = (x2 >> 15) == 0u;
-    const uint32_t sib = e1 ? 1u : (e2 ? 2u : 0u), sib4 = f1 ? 1u : (f2 ? 2u : 0u);
-    return h | (h4v << LZ_HBITS) | (sib << 27) | (sib4 << 29);
-}
-
-// insert the 1024 positions of one tile into the hash structures in position order (one wave, 16
 // steps of 64; the three phases let the LDS reads, the table updates and the stores of all steps pipeline).
 // H6 = false: one chain keyed by a 4-byte hash (the reference's structure, hash_calc.rs:30-59).
 // H6 = true : the chain is keyed by a 6-byte hash -- far sparser, every link is a >= 6-byte match --
 //             and a second, chain-less table remembers the most recent position of every 4-byte
 //             hash; its answer for position p is parked in a small ring (c4) until p is searched.
+// Registers: per step ONE word (6-byte bucket | 4-byte bucket << 14, later the two old head values) plus one word with
+// the sibling distances of all 16 steps, 2 bits each -- the kernel sits at the 128-VGPR limit of a 1024-thread
+// workgroup, and the producer's instructions come out of the same VALU budget as the searchers' (a third of it before
+// this was slimmed down).
 template <bool H6, bool full>   // full: every position of the tile has its 6 bytes (all tiles but the last): no bounds checks
 static __device__ __forceinline__ void lz_build_tile_t(const uint8_t* win, uint16_t* prev, uint16_t* head, uint16_t* head4,
                                                        uint16_t* c4, uint32_t tile, uint32_t n, uint32_t max_dist, LzCtl* ctl,
                                                        uint32_t producers) {
     const uint32_t lane = zmi_lane();
     uint32_t st[LZ_SUB];
+    uint32_t sibs = 0;   // step s, bits 2s..2s+1: 1 / 2 = the lane 1 / 2 below holds the same 6-byte bucket in this step
 #pragma unroll
     for (uint32_t s = 0; s < LZ_SUB; ++s) {
         const uint32_t p = tile * LZ_T + s * 64u + lane;
@@ -162,7 +141,15 @@ static __device__ __forceinline__ void lz_build_tile_t(const uint8_t* win, uint1
             const uint32_t v = lz_ring32(win, p);
             h = (v * 2654435761u) >> (32 - LZ_HBITS);  // multiplier as hash_calc.rs:30-33
         }
-        st[s] = lz_pack_step(h, h4v, full || p + (H6 ? 6u : 4u) <= n, H6 && (full || p + 4u <= n));
+        // The positions of one step that share a bucket do not see each other through the table (plain read, then write):
+        // the nearest one within two lanes below is found with DPP lane shifts instead -- runs and short periods (zeros,
+        // "abab") keep their distance-1 / -2 links, which is where such data gets its cheapest matches.  (+1: bucket 0 must
+        // not look like the zero that lanes 0 and 1 read from "below the wave"; positions without their bytes -- last
+        // tile only -- carry a key no bucket has.)
+        const uint32_t key = (full || p + (H6 ? 6u : 4u) <= n) ? h + 1u : LZ_HSIZE + 1u + (lane & 3u);
+        const uint32_t u1 = zmi_lane_up1(key), u2 = zmi_lane_up1(u1);
+        sibs |= (u1 == key ? 1u : (u2 == key ? 2u : 0u)) << (2u * s);
+        st[s] = h | (h4v << LZ_HBITS);
         if ((s & 7u) == 7u) zmi_sched_fence();   // eight steps' loads in flight at a time, not sixteen (registers)
     }
     // two producers hash alternate tiles concurrently; the inserts themselves must happen in position order
@@ -174,15 +161,12 @@ static __device__ __forceinline__ void lz_build_tile_t(const uint8_t* win, uint1
 #pragma unroll
     for (uint32_t s = 0; s < LZ_SUB; ++s) {
         const uint32_t p = tile * LZ_T + s * 64u + lane;
-        const uint32_t h = st[s] & (LZ_HSIZE - 1u), h4v = (st[s] >> LZ_HBITS) & (LZ_H4SIZE - 1u);
-        const uint32_t sib = (st[s] >> 27) & 3u, sib4 = st[s] >> 29;
+        const uint32_t h = st[s] & (LZ_HSIZE - 1u), h4v = st[s] >> LZ_HBITS;
         const bool in6 = full || p + (H6 ? 6u : 4u) <= n, in4 = H6 && (full || p + 4u <= n);
-        uint32_t old = in6 ? head[h] : 0u, old4 = in4 ? head4[h4v] : 0u;
+        const uint32_t old = in6 ? head[h] : 0u, old4 = in4 ? head4[h4v] : 0u;
         zmi_wave_order();   // all 64 reads of the step, then its writes (one instruction each on the hardware)
         if (in6) head[h] = (uint16_t)(p + 1u);
         if (in4) head4[h4v] = (uint16_t)(p + 1u);
-        if (sib) old = (p + 1u - sib) & 0xFFFFu;       // a sibling of the same step is the nearer predecessor
-        if (sib4) old4 = (p + 1u - sib4) & 0xFFFFu;
         st[s] = old | (old4 << 16);
         zmi_wave_order();  // steps are position-ordered
     }
@@ -190,17 +174,18 @@ static __device__ __forceinline__ void lz_build_tile_t(const uint8_t* win, uint1
     if (producers > 1u && lane == 0) lz_st_rel(&ctl->atok, tile + 1u);
 #pragma unroll
     for (uint32_t s = 0; s < LZ_SUB; ++s) {
-        uint32_t p = tile * LZ_T + s * 64u + lane;
-        // head values are positions + 1 modulo 2^16: the distance decides whether the entry is alive
-        const uint32_t old = st[s] & 0xFFFFu;
-        uint32_t d = (p + 1u - old) & 0xFFFFu;
-        const uint32_t delta = (old != 0u && d != 0u && d <= max_dist && d <= p) ? d : 0u;
+        const uint32_t p = tile * LZ_T + s * 64u + lane;
+        // head values are positions + 1 modulo 2^16 (0: never written -- its "distance" p + 1 is out of range while
+        // p < 2^16, later it is a stale entry like any other): alive if 1 <= distance <= min(max_dist, p)
+        const uint32_t lim = p < max_dist ? p : max_dist;
+        uint32_t d = (p + 1u - (st[s] & 0xFFFFu)) & 0xFFFFu;
+        uint32_t delta = d - 1u < lim ? d : 0u;
+        const uint32_t sb = (sibs >> (2u * s)) & 3u;
+        delta = sb ? sb : delta;               // a sibling of the same step is the nearer predecessor
         prev[p & LZ_WMASK] = (uint16_t)delta;
         if (H6) {
-            const uint32_t o4 = st[s] >> 16;
-            d = (p + 1u - o4) & 0xFFFFu;
-            const uint32_t d4 = (o4 != 0u && d != 0u && d <= max_dist && d <= p) ? d : 0u;
-            c4[p & (LZ_C4RING - 1u)] = (uint16_t)d4;
+            d = (p + 1u - (st[s] >> 16)) & 0xFFFFu;
+            c4[p & (LZ_C4RING - 1u)] = (uint16_t)(d - 1u < lim ? d : 0u);
         }
     }
 }
@@ -324,7 +309,6 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
     // walk as a tight per-lane loop: ONE round of LDS reads per candidate (the prev link of the
     // candidate, its first 8 window bytes and, once the best match is >= 8, the 4 bytes ending at
     // the best length), so a chain step costs one LDS latency, not two.
-    bool barren = false;   // the previous claim of this wave found no match anywhere
     for (;;) {
         // claim prm.claim positions (64 per round, one position per lane); one LDS atomic per claim
         uint32_t base0 = 0;
@@ -343,15 +327,15 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
 
         const uint32_t p = base + lane;
         uint32_t res = 0;
+        uint32_t mylo = 0, myhi = 0, my2 = 0, my3 = 0, maxlen = 0, delta = 0;
+        uint32_t blen = 3u, bdist = 0u, tail = 0u;
         if (p < n) {
-            uint32_t mylo, myhi, my2, my3;
             lz_ring64(win, p, mylo, myhi);
             lz_ring64(win, p + 8u, my2, my3);
             res = mylo & 0xFFu;
-            uint32_t maxlen = n - p;
+            maxlen = n - p;
             if (maxlen > 258u) maxlen = 258u;
-            const uint32_t delta = prev[p & LZ_WMASK];
-            uint32_t blen = 3u, bdist = 0u, tail = 0u;
+            delta = prev[p & LZ_WMASK];
             // H6: the most recent 4-byte match (no chain of its own) is looked at first, outside the chain loop and with an
             // 8-byte compare only: what it is for are the 4- and 5-byte matches the 6-byte chain cannot see; a longer match
             // is in the chain as well.  (Peeling a full-size step out of the loop was slower -- lanes without a probe idle
@@ -368,11 +352,15 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                     if (l >= 4u) { blen = l; bdist = d4; }
                 }
             }
-            // candidates per position: max_chain counts the probe.  A wave whose previous claim found no match at all
-            // (incompressible stretches: every candidate there is a hash collision, and each costs a full step) walks
-            // one link only until something matches again -- the claims of a wave lie close together
+        }
+        const bool barren = H6 && __ballot(blen >= 4u) == 0ull;   // (all lanes vote: outside the bounds check)
+        if (p < n) {
+            // candidates per position: max_chain counts the probe.  In a claim where not one of the 64 probes hit (a
+            // stretch of incompressible data: every chain candidate there is a hash collision, and each costs a full step)
+            // the positions walk one link only.  (Decided from the claim's own data: the output does not depend on which
+            // wave ran which claim.)
             uint32_t chain = H6 ? (prm.max_chain > 1u ? prm.max_chain - 1u : prm.max_chain) : prm.max_chain;
-            if (barren && chain > 1u) chain = 1u;
+            if (H6 && barren && chain > 1u) chain = 1u;
             if (maxlen >= 4u && delta != 0u && prm.max_chain != 0u) {
                 uint32_t cand = p - delta;
                 // a match this long ends the walk: nice_len, the end of the input -- and, for the short budgets, good_len
@@ -439,7 +427,6 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
             if (blen >= 4u) res |= (blen << 8) | ((bdist - 1u) << 17);
             mout[p] = res;
         }
-        barren = __ballot(res > 0xFFu) == 0ull;
       }
     }
     if (lane == 0) lz_st_rel(&ctl->wmin[wave], 0xFFFFFFFFu);

@@ -42,16 +42,17 @@ static inline void zmi_sched_fence() {}
 static __device__ __forceinline__ void zmi_sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 #endif
 
-// the value of the lane below (lane 0: `fill`).  DPP wave_shr:1 -- one VALU move, no LDS crossbar round trip and no
-// result register parked until it arrives (four ds_bpermute per step spilled the hash builder of lz77.hip to scratch)
+// the value of the lane below; lane 0 reads 0.  DPP wave_shr:1 with bound_ctrl -- one VALU move, no LDS crossbar round
+// trip, no result register parked until it arrives and no fill value to set up (four ds_bpermute per step spilled the
+// hash builder of lz77.hip to scratch)
 #ifdef ZMI_EMU
-static inline uint32_t zmi_lane_up1(uint32_t v, uint32_t fill) {
+static inline uint32_t zmi_lane_up1(uint32_t v) {
     const uint32_t r = (uint32_t)__shfl_up((int)v, 1u);
-    return (threadIdx.x & 63u) == 0u ? fill : r;
+    return (threadIdx.x & 63u) == 0u ? 0u : r;
 }
 #else
-static __device__ __forceinline__ uint32_t zmi_lane_up1(uint32_t v, uint32_t fill) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xF, 0xF, false);
+static __device__ __forceinline__ uint32_t zmi_lane_up1(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x138, 0xF, 0xF, true);
 }
 #endif
 
