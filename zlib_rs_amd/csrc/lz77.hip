@@ -121,35 +121,44 @@ static __device__ __forceinline__ void lz_build_tile_t(const uint8_t* win, uint1
                                                        uint16_t* c4, uint32_t tile, uint32_t n, uint32_t max_dist, LzCtl* ctl,
                                                        uint32_t producers) {
     const uint32_t lane = zmi_lane();
+    // A tile is 1024-aligned and the rings are multiples of 1024: inside a tile nothing wraps, so every address below is
+    // "tile base + lane + 64 s" with the 64 s folding into the instruction's offset field, and the byte alignment of a
+    // lane's window reads (lane & 3) is the same in all 16 steps
+    const uint32_t p0 = tile * LZ_T + lane;
+    const uint8_t* wt = win + ((tile * LZ_T) & LZ_WMASK) + (lane & ~3u);
+    uint16_t* pt = prev + ((tile * LZ_T) & LZ_WMASK) + lane;
+    uint16_t* ct = c4 + ((tile * LZ_T) & (LZ_C4RING - 1u)) + lane;
+    const uint32_t sh = lane & 3u;
     uint32_t st[LZ_SUB];
     uint32_t sibs = 0;   // step s, bits 2s..2s+1: 1 / 2 = the lane 1 / 2 below holds the same 6-byte bucket in this step
 #pragma unroll
     for (uint32_t s = 0; s < LZ_SUB; ++s) {
-        const uint32_t p = tile * LZ_T + s * 64u + lane;
-        uint32_t h, h4v = 0;
+        const uint32_t p = p0 + s * 64u;
+        const uint32_t* w = (const uint32_t*)(wt + s * 64u);
+        uint32_t h2, h42 = 0;   // byte offsets into the tables: bucket * 2
         if (H6) {
-            uint32_t lo, hi;
-            lz_ring64(win, p, lo, hi);
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, sh), hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
             // full-rate 24 x 24 bit multiplies (v_mul_u32_u24) instead of the quarter-rate 32-bit ones a 64-bit
             // multiplicative hash needs: bytes 0-2, 3-5 (and byte 3 alone for the 4-byte hash) are scrambled
             // separately and summed; the top bits of the sum depend on every input bit
             const uint32_t a = lo & 0xFFFFFFu, b = (lo >> 24) | ((hi & 0xFFFFu) << 8);
             const uint32_t ma = __umul24(a, 0x9E3779u);
-            h = (ma + __umul24(b, 0x85EBCBu)) >> (32 - LZ_HBITS);
-            h4v = (ma + __umul24(lo >> 24, 0xC2B2AFu)) >> (32 - LZ_H4BITS);
+            h2 = ((ma + __umul24(b, 0x85EBCBu)) >> (31 - LZ_HBITS)) & ~1u;
+            h42 = ((ma + __umul24(lo >> 24, 0xC2B2AFu)) >> (31 - LZ_H4BITS)) & ~1u;
         } else {
-            const uint32_t v = lz_ring32(win, p);
-            h = (v * 2654435761u) >> (32 - LZ_HBITS);  // multiplier as hash_calc.rs:30-33
+            const uint32_t v = __builtin_amdgcn_alignbyte(w[1], w[0], sh);
+            h2 = ((v * 2654435761u) >> (31 - LZ_HBITS)) & ~1u;  // multiplier as hash_calc.rs:30-33
         }
         // The positions of one step that share a bucket do not see each other through the table (plain read, then write):
         // the nearest one within two lanes below is found with DPP lane shifts instead -- runs and short periods (zeros,
         // "abab") keep their distance-1 / -2 links, which is where such data gets its cheapest matches.  (+1: bucket 0 must
         // not look like the zero that lanes 0 and 1 read from "below the wave"; positions without their bytes -- last
         // tile only -- carry a key no bucket has.)
-        const uint32_t key = (full || p + (H6 ? 6u : 4u) <= n) ? h + 1u : LZ_HSIZE + 1u + (lane & 3u);
+        const uint32_t key = (full || p + (H6 ? 6u : 4u) <= n) ? h2 + 1u : 2u * LZ_HSIZE + 1u + 2u * (lane & 3u);
         const uint32_t u1 = zmi_lane_up1(key), u2 = zmi_lane_up1(u1);
         sibs |= (u1 == key ? 1u : (u2 == key ? 2u : 0u)) << (2u * s);
-        st[s] = h | (h4v << LZ_HBITS);
+        st[s] = h2 | (h42 << 16);
         if ((s & 7u) == 7u) zmi_sched_fence();   // eight steps' loads in flight at a time, not sixteen (registers)
     }
     // two producers hash alternate tiles concurrently; the inserts themselves must happen in position order
@@ -160,32 +169,34 @@ static __device__ __forceinline__ void lz_build_tile_t(const uint8_t* win, uint1
     // the 64 reads of a step see the writes of the step before without any wait in between
 #pragma unroll
     for (uint32_t s = 0; s < LZ_SUB; ++s) {
-        const uint32_t p = tile * LZ_T + s * 64u + lane;
-        const uint32_t h = st[s] & (LZ_HSIZE - 1u), h4v = st[s] >> LZ_HBITS;
+        const uint32_t p = p0 + s * 64u;
+        uint16_t* hp = (uint16_t*)((uint8_t*)head + (st[s] & 0xFFFFu));
+        uint16_t* h4p = (uint16_t*)((uint8_t*)head4 + (st[s] >> 16));
         const bool in6 = full || p + (H6 ? 6u : 4u) <= n, in4 = H6 && (full || p + 4u <= n);
-        const uint32_t old = in6 ? head[h] : 0u, old4 = in4 ? head4[h4v] : 0u;
+        const uint32_t old = in6 ? *hp : 0u, old4 = in4 ? *h4p : 0u;
         zmi_wave_order();   // all 64 reads of the step, then its writes (one instruction each on the hardware)
-        if (in6) head[h] = (uint16_t)(p + 1u);
-        if (in4) head4[h4v] = (uint16_t)(p + 1u);
+        if (in6) *hp = (uint16_t)(p + 1u);
+        if (in4) *h4p = (uint16_t)(p + 1u);
         st[s] = old | (old4 << 16);
         zmi_wave_order();  // steps are position-ordered
     }
     // once this store is visible the table updates above have been applied (in-order LDS)
     if (producers > 1u && lane == 0) lz_st_rel(&ctl->atok, tile + 1u);
+    const bool near = tile * LZ_T < max_dist;   // only the first tiles of a shard can reach back before its start
 #pragma unroll
     for (uint32_t s = 0; s < LZ_SUB; ++s) {
-        const uint32_t p = tile * LZ_T + s * 64u + lane;
+        const uint32_t p = p0 + s * 64u;
         // head values are positions + 1 modulo 2^16 (0: never written -- its "distance" p + 1 is out of range while
         // p < 2^16, later it is a stale entry like any other): alive if 1 <= distance <= min(max_dist, p)
-        const uint32_t lim = p < max_dist ? p : max_dist;
+        const uint32_t lim = near ? (p < max_dist ? p : max_dist) : max_dist;
         uint32_t d = (p + 1u - (st[s] & 0xFFFFu)) & 0xFFFFu;
         uint32_t delta = d - 1u < lim ? d : 0u;
         const uint32_t sb = (sibs >> (2u * s)) & 3u;
         delta = sb ? sb : delta;               // a sibling of the same step is the nearer predecessor
-        prev[p & LZ_WMASK] = (uint16_t)delta;
+        pt[s * 64u] = (uint16_t)delta;
         if (H6) {
             d = (p + 1u - (st[s] >> 16)) & 0xFFFFu;
-            c4[p & (LZ_C4RING - 1u)] = (uint16_t)(d - 1u < lim ? d : 0u);
+            ct[s * 64u] = (uint16_t)(d - 1u < lim ? d : 0u);
         }
     }
 }
