@@ -192,7 +192,7 @@ static __device__ __forceinline__ void lz_build_tile_t(const uint8_t* win, uint1
         uint32_t d = (p + 1u - (st[s] & 0xFFFFu)) & 0xFFFFu;
         uint32_t delta = d - 1u < lim ? d : 0u;
         const uint32_t sb = (sibs >> (2u * s)) & 3u;
-        delta = sb ? sb : delta;               // a sibling of the same step is the nearer predecessor
+        delta = (sb != 0u && sb <= lim) ? sb : delta;   // a sibling of the same step is the nearer predecessor
         pt[s * 64u] = (uint16_t)delta;
         if (H6) {
             d = (p + 1u - (st[s] >> 16)) & 0xFFFFu;
