@@ -842,7 +842,11 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
         m_next = m_next2;
         const uint32_t done = (seg + 1u) * 64u;
         const bool last_seg = seg + 1u == nseg;
-        if (ntok - nH >= prm.block_tokens || done - bstart >= prm.block_span || last_seg) {
+        // a sub-block closes after block_tokens tokens, optionally not before it spans min_sub_span bytes of input (or holds
+        // twice the tokens): literal-dense data cuts a block, with a full tree construction, every 4 KiB -- the random-walk
+        // class spends half of its encode time building trees, but those small blocks are also where its ratio comes from
+        const bool sub_full = ntok - nH >= prm.block_tokens && (done - bendH >= prm.min_sub_span || ntok - nH >= 2u * prm.block_tokens);
+        if (sub_full || done - bstart >= prm.block_span || last_seg) {
             // ---- sub-block boundary: join the open block, or close it and start the next one here ----
             uint32_t bmid = done + e;
             if (bmid > pend) bmid = pend;

@@ -229,9 +229,11 @@ static const zmi_level_cfg kLevels[10] = {
     {3, 64, 16, 8, 4096},        // 4
     {4, 128, 32, 16, 4096},      // 5
     {5, 128, 32, 16, 4096},      // 6
-    {7, 128, 32, 32, 4096},      // 7
-    {16, 258, 64, 128, 4096},    // 8
-    {128, 258, 128, 258, 2048},  // 9
+    {8, 128, 32, 32, 4096},      // 7
+    {16, 258, 64, 128, 2048},    // 8
+    // 9: the ratio curve is flat beyond ~24 candidates (lcet10.txt 2.8776 at 24, 2.8802 at 128; benchmark shards 2.2726 /
+    // 2.2807, the reference's level 9: 2.2735) while every candidate costs the same: round 1's 128 ran at 5.6 GiB/s
+    {22, 258, 128, 258, 2048},
 };
 
 extern "C" int zmi_checksum_batch_dev(zmi_ctx* c, const void* d_data, const uint64_t* d_off, const uint32_t* d_len,
@@ -422,6 +424,8 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     if (const char* f5 = zmi_tune("ZMI_FAR5")) ep.far5 = (uint32_t)atoi(f5);
     ep.block_tokens = L.tok;
     ep.split_hdr_bits = 640u;
+    ep.min_sub_span = 0u;      // (8192 would halve the tree constructions of literal-dense data: -0.8 % ratio on the benchmark mix, not taken)
+    if (const char* ms = zmi_tune("ZMI_MIN_SUB_SPAN")) ep.min_sub_span = (uint32_t)atoi(ms);
     if (const char* hb = zmi_tune("ZMI_SPLIT_HDR")) ep.split_hdr_bits = (uint32_t)atoi(hb);
     if (const char* bt = zmi_tune("ZMI_BLOCK_TOKENS")) ep.block_tokens = (uint32_t)atoi(bt) >= 64u ? (uint32_t)atoi(bt) : 64u;
     const char* span_env = zmi_tune("ZMI_BLOCK_SPAN");

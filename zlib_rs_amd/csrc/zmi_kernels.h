@@ -34,6 +34,7 @@ struct zmi_enc_params {
     uint32_t block_tokens; // tokens per sub-block: after each one the encoder decides whether it joins the open block or starts
                            // a new one (the reference cuts at 16383 symbols, deflate.rs:321)
     uint32_t split_hdr_bits; // what a block of its own must save: the cost of another dynamic header
+    uint32_t min_sub_span;   // input bytes a sub-block covers at least (unless it holds 2 * block_tokens tokens already)
     uint32_t strategy;    // 0 default, 4 = Z_FIXED (static trees only)
     uint32_t far4, far5;  // first block of a piece: a 4- (5-) byte match further back than this is dropped; later blocks derive
                           // their limits from the codes of the block before (enc_far_limits)
