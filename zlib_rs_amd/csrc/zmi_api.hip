@@ -227,10 +227,10 @@ static const zmi_level_cfg kLevels[10] = {
     {3, 32, 8, 0, 8192},         // 2
     {3, 32, 8, 4, 4096},         // 3
     {3, 64, 16, 8, 4096},        // 4
-    {4, 128, 32, 16, 4096},      // 5
-    {5, 128, 32, 16, 4096},      // 6
-    {8, 128, 32, 32, 4096},      // 7
-    {16, 258, 64, 128, 2048},    // 8
+    {3, 128, 32, 16, 4096},      // 5
+    {4, 128, 32, 32, 4096},      // 6
+    {6, 128, 32, 32, 4096},      // 7
+    {14, 258, 64, 128, 2048},    // 8
     // 9: the ratio curve is flat beyond ~24 candidates (lcet10.txt 2.8776 at 24, 2.8802 at 128; benchmark shards 2.2726 /
     // 2.2807, the reference's level 9: 2.2735) while every candidate costs the same: round 1's 128 ran at 5.6 GiB/s
     {22, 258, 128, 258, 2048},
@@ -389,6 +389,10 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     if (h6_env) lp.hash6 = atoi(h6_env) ? 1u : 0u;
     zmi_enc_params ep;
     ep.max_lazy = L.lazy;
+    ep.lazy2 = 1u;
+    ep.lazy3 = 2u;
+    if (const char* l3 = zmi_tune("ZMI_LAZY3")) ep.lazy3 = (uint32_t)atoi(l3);
+    if (const char* l2 = zmi_tune("ZMI_LAZY2")) ep.lazy2 = (uint32_t)atoi(l2);
     ep.wrap = (uint32_t)wrap;
     ep.level = (uint32_t)level;
     ep.block_span = 65536u;    // one encoder wave per 64 KiB piece, 16 per 1 MiB shard (128 KiB pieces: +0.15 % ratio, but 137 -> 161 ms
@@ -412,7 +416,8 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     lp.carry = chain_mode != 0u ? 1u : 0u;   // segments of one stream: a segment sees the window in front of it
     lp.dict_len = chain_mode != 0u ? dict_len : 0u;
     if (const char* cv = zmi_tune("ZMI_CARRY")) lp.carry = (chain_mode != 0u && atoi(cv)) ? 1u : 0u;
-    lp.producers = L.chain <= 5u ? 2u : 1u;   // short chains: 14 searcher waves outrun one producer wave
+    lp.producers = L.chain <= 8u ? 2u : 1u;   // short chains: 14 searcher waves outrun one producer wave (measured at budget 5:
+                                              // 227 ms with two producers, 273 ms with one)
     if (const char* pv = zmi_tune("ZMI_PRODUCERS")) lp.producers = atoi(pv) > 1 ? 2u : 1u;
     // short far matches are judged by the encoder, block by block, from the codes it just used (enc_far_limits); the
     // search reports every match of 4+ bytes

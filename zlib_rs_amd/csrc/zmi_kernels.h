@@ -28,6 +28,7 @@ struct zmi_lz_params {
 
 struct zmi_enc_params {
     uint32_t max_lazy;    // defer a match shorter than this if the next position has a longer one (0 = greedy)
+    uint32_t lazy2, lazy3; // ... or if the position after that (the one after) has one longer by more than this (>= 258: off)
     uint32_t wrap;        // 0 raw deflate, 1 zlib (RFC 1950), 2 gzip (RFC 1952)
     uint32_t level;       // only used for the header's level hint bits
     uint32_t block_span;  // input bytes per deflate block (multiple of 64) ...
