@@ -13,6 +13,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement).  Besides the co
                  inflated in 16 Ki-stream launches, every stream compared with the regenerated plaintext
   levels         configs[3]: level 1 and level 9, GiB/s + ratio + the oracle's ratio at the same level
   pcie_inclusive host buffers in, host buffers out (never `value`)
+  stream_abi     configs[0]: one ~15.74 MB stream through deflate() / inflate() of the drop-in library, one thread
   stitch         N > 1 only: slab packing + the point-to-point slab exchange (outside the timed region)
   cpu_baseline   the oracle's level-6 restatement on the host cores (N = 1 only)
 """
@@ -358,6 +359,13 @@ def main():
             pcie_obj = {"error": repr(ex)[:200]}
     del back
 
+    stream_obj = None
+    if extras:
+        try:
+            stream_obj = stream_abi_leg(args.level)
+        except Exception as ex:  # noqa: BLE001
+            stream_obj = {"error": repr(ex)[:200]}
+
     if rank == 0:
         value = raw_total * args.steps / GIB / elapsed
         lz_ms = sums[1] / max(1, cnts[1])
@@ -404,6 +412,8 @@ def main():
             line["levels"] = levels_obj
         if pcie_obj is not None:
             line["pcie_inclusive"] = pcie_obj
+        if stream_obj is not None:
+            line["stream_abi"] = stream_obj
         if stitch_obj is not None:
             line["stitch"] = stitch_obj
         if world == 1 and not args.no_cpu:
@@ -414,6 +424,37 @@ def main():
     if world > 1:
         dist.destroy_process_group()
     e.close()
+
+
+def stream_abi_leg(level):
+    """BASELINE.json configs[0] (plumbing / reference): one ~15.74 MB input (silesia-small.tar is not in the reference
+    checkout: 15 synthetic shards + the bytes that make up the size) through the stream ABI of libz_mi355.so exactly as
+    test-libz-rs-sys/examples/blogpost-compress.rs:94-115 drives deflate() -- one stream, input fed in chunks, one thread --
+    and back through inflate() (blogpost-uncompress.rs:6-44); beside it the oracle (reference algorithm) on one host thread."""
+    import zlib_abi_harness as H
+    from zlib_rs_amd import _build
+    lib = H.bind(C.CDLL(_build.ABI_LIB))
+    o = _oracle()
+    total = 15740000
+    data = b"".join(o.gen_shard(i, 1 << 20) for i in range(15))
+    data += o.gen_shard(15, 1 << 20)[:total - len(data)]
+    H.deflate_stream(lib, data[:1 << 20], level=level, wbits=31, chunk_in=1 << 20, chunk_out=1 << 20)   # first-use costs
+    t0 = time.perf_counter()
+    comp = H.deflate_stream(lib, data, level=level, wbits=31, chunk_in=1 << 22, chunk_out=1 << 22)
+    td = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    rc, back, unused = H.inflate_stream(lib, comp, 31, chunk_in=1 << 22, chunk_out=1 << 22)
+    ti = time.perf_counter() - t0
+    assert rc == 1 and back == data and unused == 0, "stream ABI round trip failed"
+    rc, ocomp = o.deflate(data[:4 << 20], level, 2)
+    t0 = time.perf_counter()
+    rc, ocomp = o.deflate(data, level, 2)
+    to = time.perf_counter() - t0
+    assert o.inflate(comp, len(data), 2)[1] == data          # the oracle reads the GPU's stream
+    return {"input_bytes": len(data), "path": "deflateInit2_(level, gzip) + deflate() in 4 MiB chunks + inflate() back, one thread, host buffers",
+            "deflate_GiB_s": len(data) / GIB / td, "inflate_GiB_s": len(data) / GIB / ti, "ratio": len(data) / float(len(comp)),
+            "oracle_single_thread_GiB_s": len(data) / GIB / to, "oracle_ratio": len(data) / float(len(ocomp)),
+            "note": "one stream = 16 segments of 1 MiB on the device: a plumbing check, not a throughput configuration"}
 
 
 def stitch_leg(e, zdist, dist, torch, out, olen, table, dev):

@@ -37,3 +37,43 @@ for n in (1 << 10, 1 << 14, 1 << 17, 1 << 20, 1 << 22, 1 << 24):
         tu = (time.perf_counter() - t0) / reps
     assert back.raw == data and zlib.decompress(comp) == data
     print("%d,%.0f,%.0f,%.1f,%.1f" % (n, tc * 1e6, tu * 1e6, n / tc / (1 << 20), n / tu / (1 << 20)))
+
+# ---- thread scaling: N threads, each compressing and expanding its own 1 MiB buffers through compress2 / uncompress.
+# Round 1 held one process-wide lock across every call (copy, kernels, device synchronisation, copies): N threads ran
+# no faster than one.  Every call now leases a context with its own HIP stream (csrc/zlib_abi.hip AbiLease).
+import threading
+
+n = 1 << 20
+datas = [o.gen_shard(i % 8, n) for i in range(16)]
+
+
+def worker(t, calls, out):
+    cap = C.c_ulong(lib.compressBound(n))
+    dst = C.create_string_buffer(cap.value)
+    back = C.create_string_buffer(n)
+    ok = True
+    for k in range(calls):
+        cap.value = len(dst)
+        ok &= lib.compress2(dst, C.byref(cap), datas[(t + k) % 16], n, 6) == 0
+        ocap = C.c_ulong(n)
+        ok &= lib.uncompress(back, C.byref(ocap), dst.raw[:cap.value], cap.value) == 0
+        ok &= back.raw == datas[(t + k) % 16]
+    out[t] = ok
+
+
+print("threads,calls_per_thread,seconds,roundtrips_per_s,speedup_vs_1")
+base = None
+for nt in (1, 2, 4, 8, 16):
+    calls = 12
+    res = [None] * nt
+    ths = [threading.Thread(target=worker, args=(t, calls, res)) for t in range(nt)]
+    t0 = time.perf_counter()
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    dt = time.perf_counter() - t0
+    assert all(res), res
+    rate = nt * calls / dt
+    base = base or rate
+    print("%d,%d,%.3f,%.1f,%.2f" % (nt, calls, dt, rate, rate / base))
