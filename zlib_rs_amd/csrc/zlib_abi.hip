@@ -186,50 +186,57 @@ struct AbiLease {
     AbiLease& operator=(const AbiLease&) = delete;
 };
 bool abi_device_present() { AbiLease l; return l.ctx != nullptr; }
+// The HIP runtime multiplexes a process's streams onto 4 hardware queues unless told otherwise (GPU_MAX_HW_QUEUES): with
+// the default, four concurrent zlib streams is where the scaling stopped (measured: 1.9x at 2 threads, 3.3x at 4 and at
+// 8).  Ask for 16 when the library is loaded -- only if the host has not decided, and it only takes effect when the
+// runtime has not been initialised yet by someone else.
+__attribute__((constructor)) void abi_ask_for_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 // Device buffers of one call.  They come from a small pool that outlives the call: hipMalloc / hipFree cost far more than
 // the kernels of a small compress2() (hipFree also waits for the device), and a caller that compresses many small buffers
 // repeats the same sizes.  The pool is touched under g_mu for the moment of taking / returning a buffer; buffers above kPoolKeep are
 // returned to the driver at once so that one large call does not pin its memory.
-struct PoolSlot { void* p = nullptr; size_t cap = 0; bool busy = false; };
-constexpr int kPoolSlots = 64;
+struct PoolSlot { void* p = nullptr; size_t cap = 0; };   // a parked (idle) device buffer
+constexpr int kPoolSlots = 192;
 constexpr size_t kPoolKeep = (size_t)256 << 20;
 PoolSlot g_pool[kPoolSlots];
 struct DevBuf {
     void* p = nullptr;
-    int slot = -1;
+    size_t cap = 0;
     DevBuf() = default;
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
+    // hipMalloc / hipFree never run under the lock (hipFree waits for the device): the lock covers only the moment a
+    // buffer is taken out of or put back into the pool
     ~DevBuf() {
-        std::lock_guard<std::mutex> lk(g_mu);
-        if (slot >= 0) {
-            PoolSlot& q = g_pool[slot];
-            q.busy = false;
-            if (q.cap > kPoolKeep) { (void)hipFree(q.p); q.p = nullptr; q.cap = 0; }
-        } else if (p) (void)hipFree(p);
+        if (!p) return;
+        void* drop = p;
+        if (cap <= kPoolKeep) {
+            std::lock_guard<std::mutex> lk(g_mu);
+            int at = -1;
+            for (int i = 0; i < kPoolSlots && at < 0; ++i)
+                if (!g_pool[i].p) at = i;
+            if (at < 0)                                   // pool full: the smallest parked buffer makes room if this one is larger
+                for (int i = 0; i < kPoolSlots; ++i)
+                    if (g_pool[i].cap < cap && (at < 0 || g_pool[i].cap < g_pool[at].cap)) at = i;
+            if (at >= 0) { drop = g_pool[at].p; g_pool[at].p = p; g_pool[at].cap = cap; }
+        }
+        if (drop) (void)hipFree(drop);
     }
     bool alloc(size_t n) {
-        std::lock_guard<std::mutex> lk(g_mu);
         if (n == 0) n = 16;
-        int fit = -1, spare = -1;
-        for (int i = 0; i < kPoolSlots; ++i) {
-            const PoolSlot& q = g_pool[i];
-            if (q.busy) continue;
-            if (q.cap >= n && (fit < 0 || q.cap < g_pool[fit].cap)) fit = i;                 // smallest buffer that is large enough
-            if (q.cap < n && (spare < 0 || q.cap < g_pool[spare].cap)) spare = i;            // too small: an empty slot first, else the smallest
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            int fit = -1;
+            for (int i = 0; i < kPoolSlots; ++i)           // smallest parked buffer that is large enough
+                if (g_pool[i].p && g_pool[i].cap >= n && (fit < 0 || g_pool[i].cap < g_pool[fit].cap)) fit = i;
+            if (fit >= 0) { p = g_pool[fit].p; cap = g_pool[fit].cap; g_pool[fit].p = nullptr; g_pool[fit].cap = 0; return true; }
         }
-        if (fit >= 0) { g_pool[fit].busy = true; slot = fit; p = g_pool[fit].p; return true; }
-        if (spare < 0) return hipMalloc(&p, n) == hipSuccess;                                // pool exhausted: a plain allocation
-        PoolSlot& q = g_pool[spare];
-        if (q.p) { (void)hipFree(q.p); q.p = nullptr; q.cap = 0; }
-        const size_t want = n + n / 4 + 256;                                                 // some room for the next, slightly larger, call
-        if (hipMalloc(&q.p, want) != hipSuccess) {
-            q.p = nullptr;
-            if (hipMalloc(&q.p, n) != hipSuccess) { q.p = nullptr; return false; }
-            q.cap = n;
-        } else q.cap = want;
-        q.busy = true; slot = spare; p = q.p;
-        return true;
+        const size_t want = n + n / 4 + 256;               // some room for the next, slightly larger, call
+        if (hipMalloc(&p, want) == hipSuccess) { cap = want; return true; }
+        p = nullptr;
+        if (hipMalloc(&p, n) == hipSuccess) { cap = n; return true; }
+        p = nullptr;
+        return false;
     }
 };
 
