@@ -16,13 +16,14 @@
  *              28 KiB in front of it, like a preset dictionary (deflate.rs:499-564).  Across separate
  *              deflate() calls the last 32 KiB of input stay the window; only Z_FULL_FLUSH forgets them
  *              (deflate.rs:2739-2752).
- *   inflate()  takes all of avail_in on every call and decodes as far as that input allows, so the output of
- *              a flushed packet is there when the call returns.  The device decodes from a checkpoint -- the
- *              last block boundary it reached -- with the 32 KiB of output in front of it as history
+ *   inflate()  decodes as far as the input it is given allows, so the output of a flushed packet is there when the call
+ *              returns.  The caller's input is taken a piece at a time and only while the decoder can use it; what a pause
+ *              (much output queued, Z_NEED_DICT) leaves unread is handed back.  The device decodes from a checkpoint -- the
+ *              last block boundary it reached -- with the window of output in front of it as history
  *              (zmi_inflate_resume, include/zmi355.h; the reference's Mode / BitReader / Window,
  *              zlib-rs/src/inflate.rs:288-320): a block is decoded again only while it is incomplete, memory
- *              is bounded by the block size.  Bytes behind the end of the stream are handed back (avail_in) as
- *              far as they arrived with the call that reaches the end.  Wrapper header / trailer are parsed on the host.  Z_BLOCK and
+ *              is bounded by the block size.  Bytes behind the end of the stream are handed back (avail_in / next_in)
+ *              exactly, whenever the end is reached.  Wrapper header / trailer are parsed on the host.  Z_BLOCK and
  *              Z_TREES do not stop at block ends (they behave like Z_NO_FLUSH).  The bytes in front of a corrupt
  *              spot are delivered before Z_DATA_ERROR, as the reference does; header, trailer and deflate-data errors
  *              carry the reference's messages ("invalid stored block lengths", "invalid distance too far back", ...:

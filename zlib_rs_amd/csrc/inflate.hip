@@ -73,6 +73,12 @@ struct InfShared {
     __attribute__((aligned(16))) uint8_t inbuf[INF_CHUNK + 32];  // staged compressed input (one coalesced load per KiB)
     uint32_t rs[4];       // resumable decode: where the block being decoded starts (byte, bit, output position, complete)
 };
+// the batch instantiation also holds the compressed bytes of one fast pass (inf_fast_pass): 64 sub-sequences of 56 bytes
+#define INF_SUB_BITS 448u
+#define INF_FAST_BYTES 4096u     // 16 (alignment) + 64 * 56 + 6 (a token may end 48 bits behind the last boundary) + read slack
+struct InfFast {
+    __attribute__((aligned(16))) uint8_t fb[INF_FAST_BYTES];
+};
 
 struct InfBits {
     const uint8_t* src;
@@ -370,6 +376,152 @@ static __device__ __forceinline__ void inf_emit(uint8_t* dst, uint32_t* bm32, bo
     }
 }
 
+// ---- lane-serial fast path (batch decode only) ----------------------------------------------------------------------
+// The token rounds above spend 64 lanes on the ~8-15 tokens that really start inside a 128-bit window: ~230 VALU + ~250
+// SALU instructions per round.  A prefix code resynchronises: a decoder started at a wrong bit falls into step with the
+// true token sequence after a few dozen bits (the property massively parallel Huffman decoders are built on).  So the
+// next 3.5 KiB of the block are cut into 64 sub-sequences of 448 bits and every LANE decodes its own one serially --
+// 64 tokens per ~45 instructions instead of ~10 per ~480:
+//   1. sync:  lane 0 starts at the true position, lane i at "bit i * 448"; each decodes until it crosses into the next
+//             sub-sequence and reports where (its exit).  Lanes whose start is not the exit of the lane below restart
+//             there; after a few iterations a prefix 0..m of the lanes is consistent -- lane 0 is right by construction,
+//             so the whole prefix is the true token chain.  The same pass counts every lane's output bytes and how far its
+//             matches reach back.
+//   2. scan:  output offsets; the prefix is cut in front of a lane that saw an invalid code, would pass the output
+//             capacity or reaches behind the history -- those cases are left to the token rounds, which report them
+//             with the reference's codes and byte counts.
+//   3. write: the lanes of the prefix decode once more and store literals / back-reference records where they belong.
+// Nothing is committed unless it is certain; whenever the pass cannot commit a single lane the caller runs one token
+// round instead.  Needs ~4 KiB of input behind the current position (ends of streams go through the token rounds).
+struct InfLane {
+    uint32_t exit;    // bit position (relative to fb) behind the last token decoded
+    uint32_t nout;    // output bytes of those tokens
+    uint32_t need;    // bytes of history in front of this lane's first output byte that its matches reach
+    uint32_t flags;   // 1 invalid code, 2 end of block (exit = first bit behind it)
+};
+template <bool RESUME> struct InfFastOf { typedef InfFast type; };
+template <> struct InfFastOf<true> { struct type { uint8_t none[16]; }; };
+template <bool WRITE>
+static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, const uint8_t* fb, uint32_t start, uint32_t boundary,
+                                                          bool active, uint8_t* dst, uint32_t* bm32, uint32_t obase) {
+    InfLane R;
+    R.exit = start; R.nout = 0; R.need = 0; R.flags = 0;
+    const uint32_t* fw = (const uint32_t*)fb;
+    uint32_t pos = start;
+    bool go = active && pos < boundary;
+    while (go) {
+        const uint32_t wi = pos >> 5, sh = pos & 31u;
+        const uint32_t d0 = fw[wi], d1 = fw[wi + 1u], d2 = fw[wi + 2u];
+        const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+        uint32_t e = S->ltab[lo & ((1u << INF_LROOT) - 1u)];
+        if ((e >> 8) & INF_OP_LINK) {
+            const uint32_t sb = (e >> 8) & 0x0Fu;
+            e = S->ltab[(e >> 16) + ((lo >> INF_LROOT) & ((1u << sb) - 1u))];
+        }
+        const uint32_t bits = e & 0xFFu, op = (e >> 8) & 0xFFu;
+        if (op == INF_OP_BAD || bits == 0u) { R.flags |= 1u; break; }
+        if (op == INF_OP_EOB) { R.flags |= 2u; pos += bits; break; }
+        if (op & INF_OP_BASE) {
+            const uint32_t xb = op & 0x0Fu;
+            const uint32_t len = (e >> 16) + ((lo >> bits) & ((1u << xb) - 1u));
+            const uint32_t used = bits + xb;                                   // <= 20
+            const uint32_t rest = __builtin_amdgcn_alignbit(hi, lo, used);
+            uint32_t d = S->dtab[rest & ((1u << INF_DROOT) - 1u)];
+            if ((d >> 8) & INF_OP_LINK) {
+                const uint32_t sb = (d >> 8) & 0x0Fu;
+                d = S->dtab[(d >> 16) + ((rest >> INF_DROOT) & ((1u << sb) - 1u))];
+            }
+            const uint32_t dbits = d & 0xFFu, dop = (d >> 8) & 0xFFu;
+            if (dop == INF_OP_BAD || dbits == 0u || !(dop & INF_OP_BASE)) { R.flags |= 1u; break; }
+            const uint32_t dxb = dop & 0x0Fu;
+            const uint32_t dist = (d >> 16) + ((rest >> dbits) & ((1u << dxb) - 1u));
+            if (dist > R.nout && dist - R.nout > R.need) R.need = dist - R.nout;
+            if (WRITE) {
+                const uint32_t off = obase + R.nout;
+                const uint32_t rec = (dist - 1u) | ((len - 3u) << 15);     // the record the resolve pass reads (inf_emit)
+                dst[off] = (uint8_t)rec;
+                dst[off + 1u] = (uint8_t)(rec >> 8);
+                dst[off + 2u] = (uint8_t)(rec >> 16);
+                atomicOr(&bm32[off >> 5], 1u << (off & 31u));
+            }
+            R.nout += len;
+            pos += used + dbits + dxb;
+        } else {
+            if (WRITE) dst[obase + R.nout] = (uint8_t)(e >> 16);
+            R.nout += 1u;
+            pos += bits;
+        }
+        go = pos < boundary;
+    }
+    R.exit = pos;
+    return R;
+}
+
+// One fast pass from bit P of the stream.  Returns the number of lanes committed (0: nothing done); *bits_used / *out_made
+// / *hit_eob describe what was committed.  All lanes call.
+#ifdef ZMI_EMU
+extern "C" { unsigned long long zmi_dbg_inf[8]; }
+#define IDBG(i, v) do { if ((threadIdx.x & 63u) == 0u) zmi_dbg_inf[i] += (v); } while (0)
+#else
+#define IDBG(i, v) do {} while (0)
+#endif
+static __device__ __noinline__ uint32_t inf_fast_pass(const InfShared* S, InfFast* F, const uint8_t* src, uint64_t P, uint8_t* dst,
+                                                      uint32_t* bm32, uint32_t opos, uint32_t cap, uint32_t hist,
+                                                      uint32_t* bits_used, uint32_t* out_made, uint32_t* hit_eob) {
+    const uint32_t lane = zmi_lane();
+    // stage the input: from the 16-byte line holding bit P, 4 KiB, four coalesced loads
+    const uint32_t ib = (uint32_t)(P >> 3);
+    const uint32_t mis = (uint32_t)((uintptr_t)(src + ib) & 15u);
+    const uint8_t* line = src + ib - mis;
+    zmi_wave_order();
+#pragma unroll
+    for (uint32_t k = 0; k < INF_FAST_BYTES / 1024u; ++k) *(uint4*)(F->fb + 16u * (lane + 64u * k)) = *(const uint4*)(line + 16u * (lane + 64u * k));
+    zmi_wave_order();
+    const uint32_t p_rel = (mis << 3) | ((uint32_t)P & 7u);
+    const uint32_t boundary = p_rel + (lane + 1u) * INF_SUB_BITS;
+    // 1. sync
+    uint32_t start = lane == 0u ? p_rel : p_rel + lane * INF_SUB_BITS;
+    InfLane R = inf_lane_decode<false>(S, F->fb, start, boundary, true, nullptr, nullptr, 0u);
+    uint32_t good = 1u;   // lanes 0 .. good-1 are known to sit on the true token chain
+    for (uint32_t it = 0;; ++it) {
+        // the lane below tells where this lane has to start
+        const uint32_t below_exit = (uint32_t)__shfl_up((int)R.exit, 1u);
+        const bool wrong = lane != 0u && below_exit != start;
+        const uint64_t stopm = __ballot(R.flags != 0u);      // lanes that ended their walk early (end of block / invalid code)
+        const uint64_t wrongm = __ballot(wrong);
+        // Lane 0 is right by construction, so every lane below the first wrong one is on the true chain -- up to and
+        // including the first of them that stopped: behind an end of block (or an invalid code) the chain does not go on
+        const uint32_t first_wrong = wrongm ? (uint32_t)__ffsll((unsigned long long)wrongm) - 1u : 64u;
+        const uint32_t first_stop = stopm ? (uint32_t)__ffsll((unsigned long long)stopm) : 64u;   // index + 1
+        good = first_wrong < first_stop ? first_wrong : first_stop;
+        IDBG(3, 1);
+        if (first_stop <= first_wrong || first_wrong >= 64u || it == 5u) break;
+        // restart the wrong lanes where their neighbours ended (most fall into step inside their own sub-sequence, so
+        // the next check usually finds everything consistent)
+        if (wrong) start = below_exit;
+        const InfLane N = inf_lane_decode<false>(S, F->fb, start, boundary, wrong, nullptr, nullptr, 0u);
+        if (wrong) R = N;
+    }
+    // 2. scan: offsets, and what can be committed
+    const bool in = lane < good;
+    const uint32_t nout = in ? R.nout : 0u;
+    const uint32_t incl = zmi_wave_incl_scan(nout);
+    const uint32_t base = opos + incl - nout;
+    const bool bad = in && ((R.flags & 1u) != 0u || base + nout > cap || R.need > base + hist);
+    const uint64_t badm = __ballot(bad);
+    uint32_t commit = good;
+    if (badm) { const uint32_t fb1 = (uint32_t)__ffsll((unsigned long long)badm) - 1u; commit = fb1 < commit ? fb1 : commit; }
+    IDBG(0, 1); IDBG(1, commit); IDBG(2, good);
+    if (commit == 0u) return 0u;
+    // 3. write
+    (void)inf_lane_decode<true>(S, F->fb, start, boundary, lane < commit, dst, bm32, base);
+    const uint32_t last = commit - 1u;
+    *bits_used = zmi_readlane(R.exit, last) - p_rel;
+    *out_made = zmi_readlane(incl, last);
+    *hit_eob = (zmi_readlane(R.flags, last) >> 1) & 1u;
+    return commit;
+}
+
 // wrap: 0 raw, 1 zlib, 2 gzip, 3 auto (zlib or gzip by magic)
 // RESUME (raw streams only; the streaming ABI's resumable inflate, zlib-rs/src/inflate.rs:288-320 keeps the same
 // facts in its Mode / BitReader / Window): stream s starts at bit in_bit[s] (0..7) of its first byte, and
@@ -388,6 +540,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                                                          const uint32_t* __restrict__ in_bit, uint32_t* __restrict__ resume) {
     __shared__ InfShared Sh;
     InfShared* S = &Sh;
+    __shared__ typename InfFastOf<RESUME>::type Ff;   // (empty in the resumable instantiation)
     const uint32_t lane = zmi_lane();
     const uint32_t s = zmi_xcd_spread(blockIdx.x, gridDim.x);
     InfBits B;
@@ -627,6 +780,21 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             const uint32_t* iw = (const uint32_t*)B.inbuf;
             bool eob = false;
             while (!eob && st == ZMI_OK) {
+                if (!RESUME) {
+                    // lane-serial fast pass while there are >= 4 KiB of input behind P (see inf_fast_pass); it commits only
+                    // what is certain, everything unusual falls through to a token round below
+                    if (Pend - P >= 8ull * (INF_FAST_BYTES + 32u)) {
+                        uint32_t fbits = 0, fout = 0, feob = 0;
+                        const uint32_t lanes = zmi_uniform(inf_fast_pass(S, (InfFast*)&Ff, B.src, P, dst, bm32, opos, cap, hist, &fbits, &fout, &feob));
+                        if (lanes != 0u) {
+                            P += zmi_uniform(fbits);
+                            opos += zmi_uniform(fout);
+                            eob = zmi_uniform(feob) != 0u;
+                            B.cbase = -(int32_t)(2u * INF_CHUNK);   // the token rounds' input chunk is stale now
+                            continue;
+                        }
+                    }
+                }
                 uint32_t ib = (uint32_t)(P >> 3);
                 uint32_t relbyte = (uint32_t)((int32_t)ib - B.cbase);
                 // the two windows read up to 27 bytes past their first byte; the serial reader may also have
