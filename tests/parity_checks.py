@@ -100,3 +100,39 @@ def real_fixtures():
 
 def tile(raw, size=1 << 20):
     return (raw * (size // len(raw) + 1))[:size]
+
+
+def large_stream_checks(inflate_fn, o, deflate_fn=None, size=1 << 17):
+    """Streams long enough for the decode kernel's lane-serial fast pass (it needs >= 4 KiB of input behind the current
+    position; the small vectors above never get there): every data class, three zlib levels, three wrappers, this
+    engine's own output (many blocks and byte-aligned pieces), and -- with the oracle's exact code per stream -- corrupt
+    variants, every kind of capacity shortfall and inputs cut at many points around the 4 KiB switch-over."""
+    blobs = [o.gen_shard(c, size) for c in range(8)] + [bytes(size + 999), o.prng_bytes(3, size - 7, 1), b"ab" * (size // 3)]
+    for lvl in (1, 6, 9):
+        for wrap, wb in ((1, 15), (2, 31), (0, -15)):
+            streams = []
+            for b in blobs:
+                co = zlib.compressobj(lvl, zlib.DEFLATED, wb)
+                streams.append(co.compress(b) + co.flush())
+            outs, st = inflate_fn(streams, [len(b) for b in blobs], wrap)
+            assert [int(x) for x in st] == [0] * len(blobs), (lvl, wrap, list(st))
+            assert outs == blobs, (lvl, wrap)
+    if deflate_fn is not None:
+        outs, st = deflate_fn(blobs, 6, 2)
+        back, st2 = inflate_fn(outs, [len(b) for b in blobs], 2)
+        assert [int(x) for x in st2] == [0] * len(blobs) and back == blobs
+    n = corrupt_streams_exact(inflate_fn, o, o.gen_shard(2, size)) + corrupt_streams_exact(inflate_fn, o, o.gen_shard(5, size // 2))
+    d = o.gen_shard(0, size)
+    good = zlib.compress(d, 6)
+    caps = [len(d) - 1, len(d), len(d) - 5000, size // 2, 0, 1]
+    outs, st = inflate_fn([good] * len(caps), caps, 1)
+    for c, s_, ou in zip(caps, st, outs):
+        rc, want, _ = _want(o, good, c, 1)
+        assert int(s_) == rc, (c, int(s_), rc)
+        if rc == 0:
+            assert ou == want
+    cuts = [len(good) - k for k in (1, 2, 3, 4, 5, 6, 100, 4000, 4097, 4127, 4128, 4129, 4200, 5000, 9000, 20000) if k < len(good)]
+    outs, st = inflate_fn([good[:c] for c in cuts], [len(d)] * len(cuts), 1)
+    for c, s_ in zip(cuts, st):
+        assert int(s_) == _want(o, good[:c], len(d), 1)[0], c
+    return n

@@ -309,3 +309,9 @@ def test_pack_slab_kernel(eng, o):
     few = [o.prng_bytes(9, 70001, 1), o.prng_bytes(8, 65536, 1)]          # few large ranges: several workgroups per range
     slab, off = eng.pack_slab(few, 70016)
     assert slab == b"".join(few) and off == [0, 70001, 70001 + 65536]
+
+
+def test_inflate_large_streams_fast_pass(eng, o):
+    """the lane-serial fast pass of the decode kernel (inflate.hip inf_fast_pass) only runs on streams with >= 4 KiB left"""
+    import parity_checks
+    assert parity_checks.large_stream_checks(eng.inflate, o, lambda blobs, lvl, wrap: eng.deflate(blobs, level=lvl, wrap=wrap)) > 60

@@ -415,3 +415,12 @@ def test_pack_slab_and_global_stitch_on_gpu(engine):
     assert blob == b"".join(outs[g % world][g // world] for g in range(world * n_local))
     want = b"".join(_gen(engine, world * n_local, B))
     assert gzip.decompress(blob) == want
+
+
+def test_inflate_large_streams_fast_pass_on_gpu(engine):
+    import oracle_lib
+    import parity_checks
+    o = oracle_lib.load(rebuild=False)
+    n = parity_checks.large_stream_checks(_inflate_fn(engine), o, lambda blobs, lvl, wrap: _deflate(engine, blobs, level=lvl, wrap=wrap),
+                                          size=1 << 19)
+    assert n > 60

@@ -409,49 +409,64 @@ static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, co
     const uint32_t* fw = (const uint32_t*)fb;
     uint32_t pos = start;
     bool go = active && pos < boundary;
-    while (go) {
+    // One token per lane and iteration.  Straight-line selects instead of branches (a divergent branch costs exec-mask
+    // bookkeeping on the scalar unit; as nested ifs this loop had ~15 of them per token); the second-level table reads and
+    // the distance code sit behind wave-uniform branches, as in inf_tok.  The loop itself is wave-uniform too: lanes that
+    // are done ride along with their updates switched off.
+    while (__ballot(go)) {
         const uint32_t wi = pos >> 5, sh = pos & 31u;
         const uint32_t d0 = fw[wi], d1 = fw[wi + 1u], d2 = fw[wi + 2u];
         const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
         uint32_t e = S->ltab[lo & ((1u << INF_LROOT) - 1u)];
-        if ((e >> 8) & INF_OP_LINK) {
+        const bool link = ((e >> 8) & INF_OP_LINK) != 0u;
+        if (__ballot(link)) {
             const uint32_t sb = (e >> 8) & 0x0Fu;
-            e = S->ltab[(e >> 16) + ((lo >> INF_LROOT) & ((1u << sb) - 1u))];
+            const uint32_t e2 = S->ltab[link ? (e >> 16) + ((lo >> INF_LROOT) & ((1u << sb) - 1u)) : 0u];
+            e = link ? e2 : e;
         }
         const uint32_t bits = e & 0xFFu, op = (e >> 8) & 0xFFu;
-        if (op == INF_OP_BAD || bits == 0u) { R.flags |= 1u; break; }
-        if (op == INF_OP_EOB) { R.flags |= 2u; pos += bits; break; }
-        if (op & INF_OP_BASE) {
-            const uint32_t xb = op & 0x0Fu;
-            const uint32_t len = (e >> 16) + ((lo >> bits) & ((1u << xb) - 1u));
-            const uint32_t used = bits + xb;                                   // <= 20
+        const bool bad = go && (op == INF_OP_BAD || bits == 0u);
+        const bool is_eob = go && op == INF_OP_EOB;
+        const bool is_len = go && (op & INF_OP_BASE) != 0u && !bad;
+        const uint32_t xb = is_len ? (op & 0x0Fu) : 0u;
+        const uint32_t val = (e >> 16) + ((lo >> bits) & ((1u << xb) - 1u));   // literal byte | match length
+        const uint32_t used = bits + xb;                                       // <= 20
+        uint32_t dist = 0, dl = 0;
+        bool dbad = false;
+        if (__ballot(is_len)) {
             const uint32_t rest = __builtin_amdgcn_alignbit(hi, lo, used);
             uint32_t d = S->dtab[rest & ((1u << INF_DROOT) - 1u)];
-            if ((d >> 8) & INF_OP_LINK) {
+            const bool dlink = is_len && ((d >> 8) & INF_OP_LINK) != 0u;
+            if (__ballot(dlink)) {
                 const uint32_t sb = (d >> 8) & 0x0Fu;
-                d = S->dtab[(d >> 16) + ((rest >> INF_DROOT) & ((1u << sb) - 1u))];
+                const uint32_t d2x = S->dtab[dlink ? (d >> 16) + ((rest >> INF_DROOT) & ((1u << sb) - 1u)) : 0u];
+                d = dlink ? d2x : d;
             }
             const uint32_t dbits = d & 0xFFu, dop = (d >> 8) & 0xFFu;
-            if (dop == INF_OP_BAD || dbits == 0u || !(dop & INF_OP_BASE)) { R.flags |= 1u; break; }
+            dbad = is_len && (dop == INF_OP_BAD || dbits == 0u || !(dop & INF_OP_BASE));
             const uint32_t dxb = dop & 0x0Fu;
-            const uint32_t dist = (d >> 16) + ((rest >> dbits) & ((1u << dxb) - 1u));
-            if (dist > R.nout && dist - R.nout > R.need) R.need = dist - R.nout;
-            if (WRITE) {
-                const uint32_t off = obase + R.nout;
-                const uint32_t rec = (dist - 1u) | ((len - 3u) << 15);     // the record the resolve pass reads (inf_emit)
+            dist = (d >> 16) + ((rest >> dbits) & ((1u << dxb) - 1u));
+            dl = dbits + dxb;
+        }
+        const bool err = bad || dbad;
+        const bool mat = is_len && !err, lit = go && !is_len && !is_eob && !err;
+        if (WRITE) {
+            const uint32_t off = obase + R.nout;
+            if (lit) dst[off] = (uint8_t)val;
+            if (mat) {
+                const uint32_t rec = (dist - 1u) | ((val - 3u) << 15);     // the record the resolve pass reads (inf_emit)
                 dst[off] = (uint8_t)rec;
                 dst[off + 1u] = (uint8_t)(rec >> 8);
                 dst[off + 2u] = (uint8_t)(rec >> 16);
                 atomicOr(&bm32[off >> 5], 1u << (off & 31u));
             }
-            R.nout += len;
-            pos += used + dbits + dxb;
-        } else {
-            if (WRITE) dst[obase + R.nout] = (uint8_t)(e >> 16);
-            R.nout += 1u;
-            pos += bits;
         }
-        go = pos < boundary;
+        const uint32_t reach = dist > R.nout ? dist - R.nout : 0u;            // history in front of this lane's output
+        R.need = (mat && reach > R.need) ? reach : R.need;
+        R.nout += mat ? val : (lit ? 1u : 0u);
+        pos += (err || !go) ? 0u : (is_len ? used + dl : bits);
+        R.flags |= err ? 1u : (is_eob ? 2u : 0u);
+        go = go && !err && !is_eob && pos < boundary;
     }
     R.exit = pos;
     return R;
@@ -459,12 +474,6 @@ static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, co
 
 // One fast pass from bit P of the stream.  Returns the number of lanes committed (0: nothing done); *bits_used / *out_made
 // / *hit_eob describe what was committed.  All lanes call.
-#ifdef ZMI_EMU
-extern "C" { unsigned long long zmi_dbg_inf[8]; }
-#define IDBG(i, v) do { if ((threadIdx.x & 63u) == 0u) zmi_dbg_inf[i] += (v); } while (0)
-#else
-#define IDBG(i, v) do {} while (0)
-#endif
 static __device__ __noinline__ uint32_t inf_fast_pass(const InfShared* S, InfFast* F, const uint8_t* src, uint64_t P, uint8_t* dst,
                                                       uint32_t* bm32, uint32_t opos, uint32_t cap, uint32_t hist,
                                                       uint32_t* bits_used, uint32_t* out_made, uint32_t* hit_eob) {
@@ -494,7 +503,6 @@ static __device__ __noinline__ uint32_t inf_fast_pass(const InfShared* S, InfFas
         const uint32_t first_wrong = wrongm ? (uint32_t)__ffsll((unsigned long long)wrongm) - 1u : 64u;
         const uint32_t first_stop = stopm ? (uint32_t)__ffsll((unsigned long long)stopm) : 64u;   // index + 1
         good = first_wrong < first_stop ? first_wrong : first_stop;
-        IDBG(3, 1);
         if (first_stop <= first_wrong || first_wrong >= 64u || it == 5u) break;
         // restart the wrong lanes where their neighbours ended (most fall into step inside their own sub-sequence, so
         // the next check usually finds everything consistent)
@@ -511,7 +519,6 @@ static __device__ __noinline__ uint32_t inf_fast_pass(const InfShared* S, InfFas
     const uint64_t badm = __ballot(bad);
     uint32_t commit = good;
     if (badm) { const uint32_t fb1 = (uint32_t)__ffsll((unsigned long long)badm) - 1u; commit = fb1 < commit ? fb1 : commit; }
-    IDBG(0, 1); IDBG(1, commit); IDBG(2, good);
     if (commit == 0u) return 0u;
     // 3. write
     (void)inf_lane_decode<true>(S, F->fb, start, boundary, lane < commit, dst, bm32, base);
