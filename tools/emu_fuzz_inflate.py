@@ -21,7 +21,7 @@ while time.time() - t0 < float(sys.argv[2]):
     wrap = rnd.randrange(3)
     streams, caps, want = [], [], []
     for _ in range(rnd.randrange(1, 5)):
-        n = rnd.choice([0, 5, 300, 5000, rnd.randrange(40000)])
+        n = rnd.choice([0, 5, 300, 5000, rnd.randrange(40000), rnd.randrange(40000), 40000 + rnd.randrange(260000)])   # the larger ones reach the decode kernel's lane-serial fast pass (>= 4 KiB of input)
         d = o.gen_shard(rnd.randrange(8), n) if rnd.random() < 0.8 else bytes(rnd.randrange(3) for _ in range(n))
         co = zlib.compressobj(rnd.choice([0, 1, 6, 9]), zlib.DEFLATED, WB[wrap], 8, rnd.choice([0, 0, 2, 3, 4]))
         c = bytearray(co.compress(d) + co.flush())
