@@ -401,58 +401,6 @@ struct InfLane {
 };
 template <bool RESUME> struct InfFastOf { typedef InfFast type; };
 template <> struct InfFastOf<true> { struct type { uint8_t none[16]; }; };
-// One token at bit `pos` of fb, for every lane (wave-uniform call; `go` switches a lane's result off).  Straight-line selects
-// instead of branches (a divergent branch costs exec-mask bookkeeping on the scalar unit; as nested ifs the lane loop had
-// ~15 of them per token); the second-level table reads and the distance code sit behind wave-uniform branches, as in inf_tok.
-struct InfOne {
-    uint32_t adv;    // bits the token takes (0 for an invalid code or a lane that is off)
-    uint32_t kind;   // 0 literal, 1 match, 2 end of block, 3 invalid code, 4 lane off
-    uint32_t val;    // literal byte | match length
-    uint32_t dist;
-};
-static __device__ __forceinline__ InfOne inf_one_token(const InfShared* S, const uint32_t* fw, uint32_t pos, bool go) {
-    const uint32_t wi = pos >> 5, sh = pos & 31u;
-    const uint32_t d0 = fw[wi], d1 = fw[wi + 1u], d2 = fw[wi + 2u];
-    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
-    uint32_t e = S->ltab[lo & ((1u << INF_LROOT) - 1u)];
-    const bool link = ((e >> 8) & INF_OP_LINK) != 0u;
-    if (__ballot(link)) {
-        const uint32_t sb = (e >> 8) & 0x0Fu;
-        const uint32_t e2 = S->ltab[link ? (e >> 16) + ((lo >> INF_LROOT) & ((1u << sb) - 1u)) : 0u];
-        e = link ? e2 : e;
-    }
-    const uint32_t bits = e & 0xFFu, op = (e >> 8) & 0xFFu;
-    const bool bad = op == INF_OP_BAD || bits == 0u;
-    const bool is_eob = op == INF_OP_EOB;
-    const bool is_len = go && (op & INF_OP_BASE) != 0u && !bad;
-    const uint32_t xb = is_len ? (op & 0x0Fu) : 0u;
-    InfOne T;
-    T.val = (e >> 16) + ((lo >> bits) & ((1u << xb) - 1u));
-    const uint32_t used = bits + xb;                                       // <= 20
-    T.dist = 0;
-    uint32_t dl = 0;
-    bool dbad = false;
-    if (__ballot(is_len)) {
-        const uint32_t rest = __builtin_amdgcn_alignbit(hi, lo, used);
-        uint32_t d = S->dtab[rest & ((1u << INF_DROOT) - 1u)];
-        const bool dlink = is_len && ((d >> 8) & INF_OP_LINK) != 0u;
-        if (__ballot(dlink)) {
-            const uint32_t sb = (d >> 8) & 0x0Fu;
-            const uint32_t d2x = S->dtab[dlink ? (d >> 16) + ((rest >> INF_DROOT) & ((1u << sb) - 1u)) : 0u];
-            d = dlink ? d2x : d;
-        }
-        const uint32_t dbits = d & 0xFFu, dop = (d >> 8) & 0xFFu;
-        dbad = is_len && (dop == INF_OP_BAD || dbits == 0u || !(dop & INF_OP_BASE));
-        const uint32_t dxb = dop & 0x0Fu;
-        T.dist = (d >> 16) + ((rest >> dbits) & ((1u << dxb) - 1u));
-        dl = dbits + dxb;
-    }
-    const bool err = bad || dbad;
-    T.kind = !go ? 4u : (err ? 3u : (is_len ? 1u : (is_eob ? 2u : 0u)));
-    T.adv = (!go || err) ? 0u : (is_len ? used + dl : bits);
-    return T;
-}
-
 template <bool WRITE>
 static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, const uint8_t* fb, uint32_t start, uint32_t boundary,
                                                           bool active, uint8_t* dst, uint32_t* bm32, uint32_t obase) {
@@ -461,72 +409,66 @@ static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, co
     const uint32_t* fw = (const uint32_t*)fb;
     uint32_t pos = start;
     bool go = active && pos < boundary;
-    // one token per lane and iteration; the loop is wave-uniform: lanes that are done ride along switched off
+    // One token per lane and iteration.  Straight-line selects instead of branches (a divergent branch costs exec-mask
+    // bookkeeping on the scalar unit; as nested ifs this loop had ~15 of them per token); the second-level table reads and
+    // the distance code sit behind wave-uniform branches, as in inf_tok.  The loop itself is wave-uniform too: lanes that
+    // are done ride along with their updates switched off.
     while (__ballot(go)) {
-        const InfOne T = inf_one_token(S, fw, pos, go);
-        const bool mat = T.kind == 1u, lit = T.kind == 0u;
+        const uint32_t wi = pos >> 5, sh = pos & 31u;
+        const uint32_t d0 = fw[wi], d1 = fw[wi + 1u], d2 = fw[wi + 2u];
+        const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+        uint32_t e = S->ltab[lo & ((1u << INF_LROOT) - 1u)];
+        const bool link = ((e >> 8) & INF_OP_LINK) != 0u;
+        if (__ballot(link)) {
+            const uint32_t sb = (e >> 8) & 0x0Fu;
+            const uint32_t e2 = S->ltab[link ? (e >> 16) + ((lo >> INF_LROOT) & ((1u << sb) - 1u)) : 0u];
+            e = link ? e2 : e;
+        }
+        const uint32_t bits = e & 0xFFu, op = (e >> 8) & 0xFFu;
+        const bool bad = go && (op == INF_OP_BAD || bits == 0u);
+        const bool is_eob = go && op == INF_OP_EOB;
+        const bool is_len = go && (op & INF_OP_BASE) != 0u && !bad;
+        const uint32_t xb = is_len ? (op & 0x0Fu) : 0u;
+        const uint32_t val = (e >> 16) + ((lo >> bits) & ((1u << xb) - 1u));   // literal byte | match length
+        const uint32_t used = bits + xb;                                       // <= 20
+        uint32_t dist = 0, dl = 0;
+        bool dbad = false;
+        if (__ballot(is_len)) {
+            const uint32_t rest = __builtin_amdgcn_alignbit(hi, lo, used);
+            uint32_t d = S->dtab[rest & ((1u << INF_DROOT) - 1u)];
+            const bool dlink = is_len && ((d >> 8) & INF_OP_LINK) != 0u;
+            if (__ballot(dlink)) {
+                const uint32_t sb = (d >> 8) & 0x0Fu;
+                const uint32_t d2x = S->dtab[dlink ? (d >> 16) + ((rest >> INF_DROOT) & ((1u << sb) - 1u)) : 0u];
+                d = dlink ? d2x : d;
+            }
+            const uint32_t dbits = d & 0xFFu, dop = (d >> 8) & 0xFFu;
+            dbad = is_len && (dop == INF_OP_BAD || dbits == 0u || !(dop & INF_OP_BASE));
+            const uint32_t dxb = dop & 0x0Fu;
+            dist = (d >> 16) + ((rest >> dbits) & ((1u << dxb) - 1u));
+            dl = dbits + dxb;
+        }
+        const bool err = bad || dbad;
+        const bool mat = is_len && !err, lit = go && !is_len && !is_eob && !err;
         if (WRITE) {
             const uint32_t off = obase + R.nout;
-            if (lit) dst[off] = (uint8_t)T.val;
+            if (lit) dst[off] = (uint8_t)val;
             if (mat) {
-                const uint32_t rec = (T.dist - 1u) | ((T.val - 3u) << 15);     // the record the resolve pass reads (inf_emit)
+                const uint32_t rec = (dist - 1u) | ((val - 3u) << 15);     // the record the resolve pass reads (inf_emit)
                 dst[off] = (uint8_t)rec;
                 dst[off + 1u] = (uint8_t)(rec >> 8);
                 dst[off + 2u] = (uint8_t)(rec >> 16);
                 atomicOr(&bm32[off >> 5], 1u << (off & 31u));
             }
         }
-        const uint32_t reach = T.dist > R.nout ? T.dist - R.nout : 0u;        // history in front of this lane's output
+        const uint32_t reach = dist > R.nout ? dist - R.nout : 0u;            // history in front of this lane's output
         R.need = (mat && reach > R.need) ? reach : R.need;
-        R.nout += mat ? T.val : (lit ? 1u : 0u);
-        pos += T.adv;
-        R.flags |= T.kind == 3u ? 1u : (T.kind == 2u ? 2u : 0u);
-        go = go && T.kind < 2u && pos < boundary;
+        R.nout += mat ? val : (lit ? 1u : 0u);
+        pos += (err || !go) ? 0u : (is_len ? used + dl : bits);
+        R.flags |= err ? 1u : (is_eob ? 2u : 0u);
+        go = go && !err && !is_eob && pos < boundary;
     }
     R.exit = pos;
-    return R;
-}
-
-// A lane that decoded its sub-sequence from `sold` (result Rold) learns that it has to start at `snew` instead.  The two
-// walks fall into step after a few tokens (that is why the scheme works at all), and from the bit where they meet they ARE
-// the same walk: so both are advanced token by token, always the one that is behind, only until they meet -- a dozen
-// tokens instead of the sub-sequence's forty -- and the rest is taken from Rold.  (`need`, the reach of the matches behind
-// the meeting point, was measured against the old walk's byte count; it is carried over with the difference added: an
-// upper bound, which can only send a lane at the very start of a stream's output to the token rounds unnecessarily.)
-static __device__ __forceinline__ InfLane inf_lane_rejoin(const InfShared* S, const uint8_t* fb, uint32_t snew, uint32_t sold,
-                                                          const InfLane& Rold, uint32_t boundary, bool active) {
-    const uint32_t* fw = (const uint32_t*)fb;
-    uint32_t pa = snew, pb = sold, na = 0, nb = 0, needa = 0, fla = 0;
-    bool goa = active && pa < boundary, gob = active && pb < boundary, met = false;
-    while (__ballot(goa && !met)) {
-        const bool run = goa && !met;
-        const bool sel_a = !gob || pa <= pb;                 // the walk that is behind moves
-        const InfOne T = inf_one_token(S, fw, sel_a ? pa : pb, run);
-        const bool mat = T.kind == 1u, lit = T.kind == 0u;
-        const uint32_t outn = mat ? T.val : (lit ? 1u : 0u);
-        const bool ua = run && sel_a, ub = run && !sel_a;
-        const uint32_t reach = T.dist > na ? T.dist - na : 0u;
-        needa = (ua && mat && reach > needa) ? reach : needa;
-        na += ua ? outn : 0u;
-        nb += ub ? outn : 0u;
-        pa += ua ? T.adv : 0u;
-        pb += ub ? T.adv : 0u;
-        fla |= ua ? (T.kind == 3u ? 1u : (T.kind == 2u ? 2u : 0u)) : 0u;
-        goa = ua ? (T.kind < 2u && pa < boundary) : goa;
-        gob = ub ? (T.kind < 2u && pb < boundary) : gob;
-        met = run && goa && gob && pa == pb;
-    }
-    InfLane R;
-    if (met) {
-        R.exit = Rold.exit;
-        R.nout = na + (Rold.nout - nb);
-        const uint32_t shift = nb > na ? nb - na : 0u;
-        const uint32_t carried = Rold.need + shift;
-        R.need = needa > carried ? needa : carried;
-        R.flags = Rold.flags;
-    } else {
-        R.exit = pa; R.nout = na; R.need = needa; R.flags = fla;
-    }
     return R;
 }
 
@@ -564,8 +506,9 @@ static __device__ __noinline__ uint32_t inf_fast_pass(const InfShared* S, InfFas
         if (first_stop <= first_wrong || first_wrong >= 64u || it == 5u) break;
         // restart the wrong lanes where their neighbours ended (most fall into step inside their own sub-sequence, so
         // the next check usually finds everything consistent)
-        const InfLane N = inf_lane_rejoin(S, F->fb, below_exit, start, R, boundary, wrong);
-        if (wrong) { start = below_exit; R = N; }
+        if (wrong) start = below_exit;
+        const InfLane N = inf_lane_decode<false>(S, F->fb, start, boundary, wrong, nullptr, nullptr, 0u);
+        if (wrong) R = N;
     }
     // 2. scan: offsets, and what can be committed
     const bool in = lane < good;
