@@ -75,6 +75,7 @@ struct InfShared {
 };
 // the batch instantiation also holds the compressed bytes of one fast pass (inf_fast_pass): 64 sub-sequences of 56 bytes
 #define INF_SUB_BITS 448u
+#define INF_WARM_BITS 192u
 #define INF_FAST_BYTES 4096u     // 16 (alignment) + 64 * 56 + 6 (a token may end 48 bits behind the last boundary) + read slack
 struct InfFast {
     __attribute__((aligned(16))) uint8_t fb[INF_FAST_BYTES];
@@ -488,8 +489,15 @@ static __device__ __noinline__ uint32_t inf_fast_pass(const InfShared* S, InfFas
     zmi_wave_order();
     const uint32_t p_rel = (mis << 3) | ((uint32_t)P & 7u);
     const uint32_t boundary = p_rel + (lane + 1u) * INF_SUB_BITS;
-    // 1. sync
-    uint32_t start = lane == 0u ? p_rel : p_rel + lane * INF_SUB_BITS;
+    // 1. sync.  A lane's first guess is not "my sub-sequence starts with a token" but the result of a short warm-up walk
+    // through the tail of the sub-sequence below: after INF_WARM_BITS most walks are in step already, so the first full
+    // walk is usually the right one and the restart round below has few (often no) lanes to fix.
+    uint32_t start = p_rel + lane * INF_SUB_BITS;
+    {
+        // (lane 0 rides along switched off: it must still hold a position inside the staged bytes, its reads happen)
+        const InfLane Wm = inf_lane_decode<false>(S, F->fb, lane != 0u ? start - INF_WARM_BITS : start, start, lane != 0u, nullptr, nullptr, 0u);
+        if (lane != 0u && Wm.flags == 0u) start = Wm.exit;   // (a warm-up that ran into an invalid code or an end of block: keep the guess)
+    }
     InfLane R = inf_lane_decode<false>(S, F->fb, start, boundary, true, nullptr, nullptr, 0u);
     uint32_t good = 1u;   // lanes 0 .. good-1 are known to sit on the true token chain
     for (uint32_t it = 0;; ++it) {
