@@ -2,6 +2,7 @@
 // hip_emu.h).  Never linked into the product library.
 #include "hip_emu.h"
 #include <sys/mman.h>
+#include <mutex>
 
 namespace emu {
 State g;
@@ -150,6 +151,10 @@ static void run_block(dim3 block, unsigned bx, size_t shmem) {
 }
 
 void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body) {
+    // one kernel at a time: the scheduler state, the built-in index variables and the kernels' static LDS are process
+    // globals, while the stream ABI runs device work of different host threads side by side
+    static std::mutex one_launch;
+    std::lock_guard<std::mutex> lk(one_launch);
     g.body = body;
     blockDim = block;
     gridDim = grid;
