@@ -15,6 +15,18 @@
 #include "zmi_device.h"
 
 #define ZMI_ADLER_BASE 65521u
+
+// sum of the four bytes of w, plus acc / sum of byte_i(w) * byte_i(k), plus acc
+#ifdef ZMI_EMU
+static inline uint32_t zmi_sum4(uint32_t w, uint32_t acc) { return acc + (w & 0xFFu) + ((w >> 8) & 0xFFu) + ((w >> 16) & 0xFFu) + (w >> 24); }
+static inline uint32_t zmi_dot4(uint32_t w, uint32_t k, uint32_t acc) {
+    for (int i = 0; i < 4; ++i) acc += ((w >> (8 * i)) & 0xFFu) * ((k >> (8 * i)) & 0xFFu);
+    return acc;
+}
+#else
+static __device__ __forceinline__ uint32_t zmi_sum4(uint32_t w, uint32_t acc) { return __builtin_amdgcn_sad_u8(w, 0u, acc); }
+static __device__ __forceinline__ uint32_t zmi_dot4(uint32_t w, uint32_t k, uint32_t acc) { return __builtin_amdgcn_udot4(w, k, acc, false); }
+#endif
 #define ZMI_CRC_POLY 0xEDB88320u
 
 // a(x) * b(x) mod P, reflected bit order (bit 31 = x^0)
@@ -54,8 +66,25 @@ __global__ void __launch_bounds__(256) zmi_checksum_kernel(const uint8_t* __rest
 
     if (kind & 1u) {
         uint32_t A = 0;
-        uint64_t B = 0;
-        for (uint32_t i0 = t * 16u; i0 < n; i0 += 256u * 16u) {
+        uint64_t B = 0;   // the weight of byte i is n - i: (n - i0) * (sum of the stripe) - sum(j * b_j) per 16-byte stripe;
+                          // a thread's share stays below n * n / 256 * 255 < 2^64, so nothing is reduced inside the loop
+        uint32_t i0 = t * 16u;
+        // four stripes (four independent 16-byte loads) per trip; byte sums are v_sad_u8 against zero, the weighted sums
+        // v_dot4_u32_u8 against the byte offsets: 2 instructions per 4 bytes
+        for (; aligned && (uint64_t)i0 + 3u * 4096u + 16u <= n; i0 += 4u * 4096u) {
+            uint4 q[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) q[k] = *(const uint4*)(src + i0 + k * 4096u);
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) {
+                const uint32_t sb = zmi_sum4(q[k].x, zmi_sum4(q[k].y, zmi_sum4(q[k].z, zmi_sum4(q[k].w, 0u))));
+                const uint32_t sjb = zmi_dot4(q[k].x, 0x03020100u, zmi_dot4(q[k].y, 0x07060504u,
+                                     zmi_dot4(q[k].z, 0x0B0A0908u, zmi_dot4(q[k].w, 0x0F0E0D0Cu, 0u))));
+                A += sb;
+                B += (uint64_t)(n - i0 - k * 4096u) * sb - sjb;
+            }
+        }
+        for (; i0 < n; i0 += 256u * 16u) {
             uint32_t nv = n - i0;
             zmi_b16 v = zmi_ld16(src + i0, nv, aligned);
             uint32_t sb = 0, sjb = 0;
@@ -66,8 +95,8 @@ __global__ void __launch_bounds__(256) zmi_checksum_kernel(const uint8_t* __rest
                 sjb += j * b;
             }
             A += sb;
-            // weight of byte i is (n - i); bytes past n were read as zero so they add nothing
-            B += (uint64_t)((n - i0) % ZMI_ADLER_BASE) * sb + (uint64_t)(16u * ZMI_ADLER_BASE) - sjb;
+            // bytes past n were read as zero so they add nothing
+            B += (uint64_t)(n - i0) * sb - sjb;
         }
         uint32_t a = A % ZMI_ADLER_BASE;
         uint32_t b = (uint32_t)(B % ZMI_ADLER_BASE);
