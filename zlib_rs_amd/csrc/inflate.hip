@@ -40,8 +40,10 @@
 enum { DE_STORED_LEN = 1, DE_BLOCK_TYPE, DE_TOO_MANY_SYMS, DE_CODE_LENGTHS_SET, DE_BIT_LENGTH_REPEAT, DE_MISSING_EOB,
        DE_LITLEN_SET, DE_DIST_SET, DE_TOO_FAR_BACK, DE_HEADER_CHECK, DE_CODE };
 #define INF_CHUNK 1024u
-#define RES_RING 36864u              // resolve pass: output history kept in LDS: 32768 + RES_SPAN + 258 + RES_BLK and slack; a
-                                     // multiple of RES_BLK; with the chunk tables 39.5 KiB per stream, four streams per CU
+#define RES_RING 12288u              // resolve pass: output history kept in LDS: RES_NEAR + RES_SPAN + 258 + RES_BLK and slack; a
+                                     // multiple of RES_BLK; with the chunk tables 15.5 KiB per stream, ten streams per CU
+#define RES_NEAR 7680u               // resolve pass: a back-reference further than this reads its source from HBM (final there:
+                                     // everything in front of the batch has been written back), a nearer one from the ring
 #define RES_BLK 1024u                // resolve pass: bytes staged per load step
 #define RES_SPAN 2048u               // resolve pass: output bytes one batch of holes may span
 #define ZMI_NO_SCRATCH (-4)          // Z_MEM_ERROR: the bitmap scratch of the context does not cover this stream
@@ -1012,18 +1014,15 @@ static __device__ __forceinline__ uint4 res_fetch(const uint8_t* dst, uint32_t n
 }
 // `pre` holds block [loaded, loaded + RES_BLK) when `have` is set: the load of the next block is always in
 // flight while the holes of the current one are filled
-// `keep` = lowest output byte the batch being staged for may still read (its first hole - 32768)
+// `keep` = lowest output byte the batch being staged for may still read from the ring (its first hole - RES_NEAR)
 static __device__ __forceinline__ void res_stage(uint8_t* ring, const uint8_t* dst, uint32_t n_out, uint32_t& loaded, uint32_t upto,
                                                  bool aligned16, uint4& pre, bool& have, uint32_t& rb, uint32_t lo, uint32_t keep) {
     const uint32_t lane = zmi_lane();
     zmi_wave_order();   // ring reads issued so far (write-back of final lines) stay in front of the stores below
-    if (upto > loaded + RES_RING - 2048u) {   // a long stretch without holes: only the window matters
-        // restart at the block holding the oldest byte the batch can reference: `upto` is up to RES_SPAN + 3 past the
-        // first hole, so a start derived from it alone could land up to 3 bytes above first hole - 32768 (a distance of
-        // 32766..32768 then read bytes that were never staged).  Ring budget: keep's block start .. upto + RES_BLK
-        // <= 1023 + 32768 + RES_SPAN + 258 + RES_BLK <= RES_RING.
-        const uint32_t a = (upto - 32768u - 2u * RES_BLK) & ~(RES_BLK - 1u), b = keep & ~(RES_BLK - 1u);
-        loaded = a < b ? a : b;
+    if (upto > loaded + RES_RING - 2048u) {   // a long stretch without holes: only the near window matters
+        // restart at the block holding the oldest byte the batch can read from the ring.  Ring budget: keep's block
+        // start .. upto + RES_BLK <= 1023 + RES_NEAR + RES_SPAN + 258 + RES_BLK <= RES_RING.
+        loaded = keep & ~(RES_BLK - 1u);
         have = false;
     }
     while (loaded < upto) {
@@ -1056,6 +1055,26 @@ static __device__ __forceinline__ void res_writeback(const uint8_t* ring, uint8_
 // done; `need` is that count, found by ranking the source end in the chunk's bitmap.  Short, non-overlapping
 // holes that are ready are filled together (lane-per-hole, 16 bytes per step); self-overlapping ones are
 // filled by the whole wave when they are the first unfinished hole.  Text-like data finishes a batch in 3-5 steps.
+// the first `left` (<= 16) bytes of w[] -> ring[ip...] (byte stores: neighbouring holes may share a word)
+static __device__ __forceinline__ void res_put16(uint8_t* ring, uint32_t ip, const uint32_t* w, uint32_t left) {
+    if (ip + 16u <= RES_RING) {
+#pragma unroll
+        for (uint32_t j = 0; j < 16u; ++j)
+            if (j < left) ring[ip + j] = (uint8_t)(w[j >> 2] >> (8u * (j & 3u)));
+    } else {
+#pragma unroll
+        for (uint32_t j = 0; j < 16u; ++j)
+            if (j < left) ring[res_inc(ip, j)] = (uint8_t)(w[j >> 2] >> (8u * (j & 3u)));
+    }
+}
+// one word of output that this kernel (this wave) may have written back earlier: read past the CU's L1
+static __device__ __forceinline__ uint32_t res_ld_final(const uint32_t* p) {
+#ifdef ZMI_EMU
+    return *p;
+#else
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
 #define RES_SHORT 16u
 struct ResChunk {
     uint64_t cw[64];       // bitmap words of the chunk
@@ -1123,7 +1142,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, c
             if (!any) {
                 // first hole of the stream: everything in front of it is final already; start one window back
                 any = true;
-                loaded = p_first > 32768u ? (p_first - 32768u) & ~(RES_BLK - 1u) : 0u;
+                loaded = p_first > RES_NEAR ? (p_first - RES_NEAR) & ~(RES_BLK - 1u) : 0u;
                 wb = p_first & ~255u;
             }
             {   // lines in front of this batch can no longer change
@@ -1131,7 +1150,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, c
                 if (upto > wb) res_writeback(ring, dst, n_out, wb, upto, aligned4, rb);
                 if (fin > wb) wb = fin;
             }
-            const uint32_t keep = p_first > 32768u ? p_first - 32768u : 0u;
+            const uint32_t keep = p_first > RES_NEAR ? p_first - RES_NEAR : 0u;
             if (p_last + 3u > loaded) res_stage(ring, dst, n_out, loaded, p_last + 3u, aligned16, pre, have, rb, lo, keep);
             uint32_t rec = 0;
             if (active) {
@@ -1154,6 +1173,38 @@ __global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, c
             const uint32_t mpack = mlen | (md << 16);
             uint64_t done = nb == 64u ? 0ull : ~0ull << nb;
             zmi_wave_order();
+            // holes whose source lies further back than the ring reaches: the source is final in HBM (it ends in front of
+            // this batch's first hole, and everything up to there has been resolved and written back), so they are
+            // filled first, all at once, whatever order the holes of the batch depend on each other in
+            const bool farh = active && md > RES_NEAR;
+            if (__ballot(farh)) {
+#ifndef ZMI_EMU
+                __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): this wave's write-backs have reached L2
+#endif
+                const uint32_t lim = farh ? mlen : 0u;
+                for (uint32_t base = 0; __ballot(base < lim); base += RES_SHORT) {
+                    uint32_t w[4] = {0u, 0u, 0u, 0u};
+                    const uint32_t left = base < lim ? lim - base : 0u;
+                    if (left) {
+                        const uintptr_t P = (uintptr_t)(dst + s0 + base);
+                        const uint32_t* q = (const uint32_t*)(P & ~(uintptr_t)3);
+                        const uint32_t sh = (uint32_t)(P & 3u), span = sh + (left < RES_SHORT ? left : RES_SHORT);
+                        // only words that hold source bytes are touched (the last one may end the allocation)
+                        const uint32_t q0 = res_ld_final(q);
+                        const uint32_t q1 = span > 4u ? res_ld_final(q + 1) : 0u;
+                        const uint32_t q2 = span > 8u ? res_ld_final(q + 2) : 0u;
+                        const uint32_t q3 = span > 12u ? res_ld_final(q + 3) : 0u;
+                        const uint32_t q4 = span > 16u ? res_ld_final(q + 4) : 0u;
+                        w[0] = __builtin_amdgcn_alignbyte(q1, q0, sh);
+                        w[1] = __builtin_amdgcn_alignbyte(q2, q1, sh);
+                        w[2] = __builtin_amdgcn_alignbyte(q3, q2, sh);
+                        w[3] = __builtin_amdgcn_alignbyte(q4, q3, sh);
+                    }
+                    res_put16(ring, res_ri(p + base, rb), w, left);
+                }
+                done |= __ballot(farh);
+                zmi_wave_order();
+            }
             while (~done) {
                 const uint32_t D = (uint32_t)__ffsll((unsigned long long)~done) - 1u;   // first unfinished hole
                 const uint64_t R = __ballot(active && !((done >> lane) & 1ull) && !coop && need <= D);
@@ -1182,16 +1233,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, c
                             w[3] = __builtin_amdgcn_alignbyte(q4, q3, sh);
                         }
                         const uint32_t left = base < lim ? lim - base : 0u;
-                        const uint32_t ip = res_ri(p + base, rb);
-                        if (ip + RES_SHORT <= RES_RING) {
-#pragma unroll
-                            for (uint32_t j = 0; j < RES_SHORT; ++j)
-                                if (j < left) ring[ip + j] = (uint8_t)(w[j >> 2] >> (8u * (j & 3u)));
-                        } else {
-#pragma unroll
-                            for (uint32_t j = 0; j < RES_SHORT; ++j)
-                                if (j < left) ring[res_inc(ip, j)] = (uint8_t)(w[j >> 2] >> (8u * (j & 3u)));
-                        }
+                        res_put16(ring, res_ri(p + base, rb), w, left);
                     }
                     done |= R;
                 } else {
