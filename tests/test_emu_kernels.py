@@ -169,6 +169,60 @@ def test_inflate_resolve_window_edge(eng, o):
     assert outs == [w for _, w in cases]
 
 
+def resolve_near_far_streams(o):
+    """The resolve pass keeps RES_NEAR (2560) bytes of history in its LDS ring and reads sources further back from HBM,
+    where they must already be final.  Raw fixed-Huffman streams around that boundary: distances RES_NEAR - 1 .. + 2
+    and 32768, sources that are themselves the output of earlier (near and far) back-references, far and near holes
+    mixed inside one batch and depending on each other, 258-byte copies, a far copy right behind a hole-free stretch
+    longer than the ring.  Shared with the GPU test.  Returns [(stream, expected)]."""
+    import deflate_craft
+    cases = []
+    for seed, lead in ((1, 3000), (2, 2563), (3, 40000)):
+        lits = o.prng_bytes(900 + seed, 120000, 1)
+        toks, n = [], 0
+
+        def lit(k, toks=toks):
+            nonlocal n
+            toks += list(lits[n:n + k]); n += k
+
+        def cp(length, dist, toks=toks):
+            nonlocal n
+            assert dist <= n
+            toks.append((length, dist)); n += length
+
+        lit(lead)
+        for d in (2559, 2560, 2561, 2562):            # one batch: near and far next to each other
+            cp(5, d); lit(2)
+        cp(258, 2561); cp(258, 2560); cp(17, 258 + 2561)     # far source = the far copy just made
+        lit(7)
+        for rep in range(40):                          # dense holes: sources are earlier holes, near and far alternate
+            cp(3 + rep % 9, 2550 + rep % 20); cp(4, 1 + rep % 7); lit(1)
+        lit(9000)                                      # hole-free stretch longer than the ring
+        cp(9, min(n, 32768)); cp(3, 2561); cp(258, min(n, 32768)); cp(6, 2560)
+        lit(3)
+        for rep in range(70):                          # > 64 holes: the batch boundary falls inside the run
+            cp(3, 2561 + rep); cp(3, 3)
+        lit(100)
+        cases.append((deflate_craft.fixed_block(toks), deflate_craft.expand(toks)))
+    return cases
+
+
+def test_inflate_resolve_near_far_boundary(eng, o):
+    cases = resolve_near_far_streams(o)
+    for s, want in cases:
+        assert zlib.decompress(s, -15) == want
+    # odd output offsets as well: the HBM reads of far sources round their address down to a word
+    outs, st = eng.inflate([s for s, _ in cases], [len(w) for _, w in cases], 0)
+    assert st == [0] * len(cases)
+    assert outs == [w for _, w in cases]
+    ioff, ooff, a, b_ = [], [], 1, 3
+    for s, w in cases:
+        ioff.append(a); a += len(s) + 5
+        ooff.append(b_); b_ += len(w) + 1
+    outs, st, guard = eng.inflate_dev([s for s, _ in cases], [len(w) for _, w in cases], ioff, ooff, 0, out_limit=1 << 20)
+    assert st == [0] * len(cases) and outs == [w for _, w in cases]
+
+
 def test_inflate_unaligned_layout_and_scratch_limit(eng, o):
     blobs = [o.gen_shard(1, 5000), o.gen_shard(4, 3001), b"q" * 777 + o.gen_shard(6, 2000), o.gen_shard(2, 4097)]
     streams = [zlib.compress(b, 6) for b in blobs]

@@ -347,6 +347,16 @@ def test_resolve_window_edge_on_gpu(engine):
     assert outs == [w for _, w in cases]
 
 
+def test_resolve_near_far_boundary_on_gpu(engine):
+    """back-references around RES_NEAR (ring vs HBM source), sources that are earlier holes, mixed batches"""
+    import oracle_lib
+    from test_emu_kernels import resolve_near_far_streams
+    cases = resolve_near_far_streams(oracle_lib.load(rebuild=False))
+    outs, st = _inflate(engine, [c for c, _ in cases], [len(w) for _, w in cases], wrap=0)
+    assert (st == 0).all()
+    assert outs == [w for _, w in cases]
+
+
 def test_real_fixtures_roundtrip_and_ratio_vs_oracle(engine):
     """SURVEY 8(d) non-synthetic cross-check: lcet10.txt, paper-100k.pdf, fireworks.jpg
     (test-libz-rs-sys/src/deflate.rs:1982-2003) tiled to 1 MiB, levels 1 / 6 / 9: a conformant inflater and the GPU

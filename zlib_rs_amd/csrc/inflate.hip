@@ -40,12 +40,14 @@
 enum { DE_STORED_LEN = 1, DE_BLOCK_TYPE, DE_TOO_MANY_SYMS, DE_CODE_LENGTHS_SET, DE_BIT_LENGTH_REPEAT, DE_MISSING_EOB,
        DE_LITLEN_SET, DE_DIST_SET, DE_TOO_FAR_BACK, DE_HEADER_CHECK, DE_CODE };
 #define INF_CHUNK 1024u
-#define RES_RING 12288u              // resolve pass: output history kept in LDS: RES_NEAR + RES_SPAN + 258 + RES_BLK and slack; a
+#define RES_RING 6144u               // resolve pass: output history kept in LDS: RES_NEAR + RES_SPAN + 258 + RES_BLK and slack; a
                                      // multiple of RES_BLK; with the chunk tables 15.5 KiB per stream, ten streams per CU
-#define RES_NEAR 7680u               // resolve pass: a back-reference further than this reads its source from HBM (final there:
+#define RES_NEAR 2560u               // resolve pass: a back-reference further than this reads its source from HBM (final there:
                                      // everything in front of the batch has been written back), a nearer one from the ring
 #define RES_BLK 1024u                // resolve pass: bytes staged per load step
-#define RES_SPAN 2048u               // resolve pass: output bytes one batch of holes may span
+#define RES_SPAN 1024u               // resolve pass: output bytes one batch of holes may span
+static_assert(RES_NEAR >= RES_SPAN + 258u + 255u, "a far source must end in front of the write-back frontier (first hole of the batch, rounded down to 256)");
+static_assert(1023u + RES_NEAR + RES_SPAN + 258u + RES_BLK <= RES_RING && RES_RING % RES_BLK == 0u, "ring budget");
 #define ZMI_NO_SCRATCH (-4)          // Z_MEM_ERROR: the bitmap scratch of the context does not cover this stream
 // roots 9 / 8: worst-case table sizes 852 (zlib's ENOUGH_LENS, inftrees.h) and 400 (exhaustive search over all
 // complete 30-symbol codes with the exact-fit sub-tables inf_build makes; root 6 gives zlib's 592)
