@@ -8,7 +8,7 @@
 //   Adler-32:  s1 = 1 + sum(b_i),  s2 = n + sum((n - i) * b_i)   (mod 65521)
 //              -> every thread takes 16-byte stripes (coalesced), no sequential dependency.
 //   CRC-32:    thread t owns one contiguous segment, computes the zero-init raw CRC with a
-//              slice-by-4 table in LDS, multiplies it by x^(8 * bytes_after_segment) mod P
+//              slice-by-16 table in LDS, multiplies it by x^(8 * bytes_after_segment) mod P
 //              (the crc32_combine algebra of crc32/combine.rs:26-61 applied per thread) and the
 //              workgroup XOR-reduces.  Pre/post conditioning is folded in at the end.
 // HBM-bound by construction: 1 byte read per input byte, 4 bytes written per shard.
@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) zmi_checksum_kernel(const uint8_t* __rest
                                                            const uint32_t* __restrict__ len, uint32_t kind,
                                                            uint32_t* __restrict__ out_adler,
                                                            uint32_t* __restrict__ out_crc) {
-    __shared__ uint32_t tab[4][256];
+    __shared__ uint32_t tab[16][256];
     __shared__ uint32_t red[3][4];
     const uint32_t s = blockIdx.x;
     const uint32_t t = threadIdx.x;
@@ -105,15 +105,17 @@ __global__ void __launch_bounds__(256) zmi_checksum_kernel(const uint8_t* __rest
         if (zmi_lane() == 0) { red[0][zmi_wave()] = a % ZMI_ADLER_BASE; red[1][zmi_wave()] = b % ZMI_ADLER_BASE; }
     }
     if (kind & 2u) {
-        // slice-by-4 tables
+        // slice-by-16 tables: tab[k][b] = CRC of byte b followed by k zero bytes.  One 16-byte step is 16 independent
+        // lookups (only the four of the first word wait for the running CRC): one LDS round trip per 16 bytes instead of
+        // the four of slice-by-4
         uint32_t c = t;
         for (int k = 0; k < 8; ++k) c = (c >> 1) ^ ((c & 1u) ? ZMI_CRC_POLY : 0u);
         tab[0][t] = c;
         __syncthreads();
-        uint32_t c1 = (c >> 8) ^ tab[0][c & 0xFFu];
-        uint32_t c2 = (c1 >> 8) ^ tab[0][c1 & 0xFFu];
-        uint32_t c3 = (c2 >> 8) ^ tab[0][c2 & 0xFFu];
-        tab[1][t] = c1; tab[2][t] = c2; tab[3][t] = c3;
+        for (uint32_t k = 1; k < 16u; ++k) {
+            c = (c >> 8) ^ tab[0][c & 0xFFu];
+            tab[k][t] = c;
+        }
         __syncthreads();
         // contiguous segment per thread, length multiple of 16
         uint32_t seg = ((n + 255u) / 256u + 15u) & ~15u;
@@ -127,11 +129,15 @@ __global__ void __launch_bounds__(256) zmi_checksum_kernel(const uint8_t* __rest
                 uint32_t nv = end - i0;
                 zmi_b16 v = zmi_ld16(src + i0, nv, aligned);
                 if (nv >= 16u) {
+                    const uint32_t x = crc ^ v.w[0];
+                    uint32_t r = tab[15][x & 0xFFu] ^ tab[14][(x >> 8) & 0xFFu] ^ tab[13][(x >> 16) & 0xFFu] ^ tab[12][x >> 24];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        uint32_t x = crc ^ v.w[q];
-                        crc = tab[3][x & 0xFFu] ^ tab[2][(x >> 8) & 0xFFu] ^ tab[1][(x >> 16) & 0xFFu] ^ tab[0][x >> 24];
+                    for (int q = 1; q < 4; ++q) {
+                        const uint32_t y = v.w[q];
+                        r ^= tab[15 - 4 * q][y & 0xFFu] ^ tab[14 - 4 * q][(y >> 8) & 0xFFu] ^ tab[13 - 4 * q][(y >> 16) & 0xFFu] ^
+                             tab[12 - 4 * q][y >> 24];
                     }
+                    crc = r;
                 } else {
                     for (uint32_t j = 0; j < nv; ++j) {
                         uint32_t b = (v.w[j >> 2] >> (8u * (j & 3u))) & 0xFFu;
