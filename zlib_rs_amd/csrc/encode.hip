@@ -97,6 +97,19 @@ static __device__ __forceinline__ void enc_len_sym(uint32_t len, uint32_t& idx, 
     }
 }
 // distance 1..32768 -> (code 0..29, extra bit count, extra value)
+// the symbol indices alone, without branches (the tokeniser counts symbols; the extra bits matter at emission only)
+static __device__ __forceinline__ uint32_t enc_len_idx(uint32_t len) {
+    const uint32_t l = len - 3u;
+    const uint32_t k = 31u - (uint32_t)__clz(l | 4u);            // >= 2
+    const uint32_t f = 4u * (k - 1u) + ((l >> (k - 2u)) & 3u);   // l in 4..7: k = 2, f = l
+    return l == 255u ? 28u : (l < 4u ? l : f);
+}
+static __device__ __forceinline__ uint32_t enc_dist_idx(uint32_t dist) {
+    const uint32_t d = dist - 1u;
+    const uint32_t k = 31u - (uint32_t)__clz(d | 2u);            // >= 1
+    const uint32_t f = 2u * k + ((d >> (k - 1u)) & 1u);          // d in 2..3: k = 1, f = d
+    return d < 2u ? d : f;
+}
 static __device__ __forceinline__ void enc_dist_sym(uint32_t dist, uint32_t& idx, uint32_t& eb, uint32_t& ev) {
     uint32_t d = dist - 1u;
     if (d < 4u) { idx = d; eb = 0; ev = 0; }
@@ -784,9 +797,8 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
             const uint32_t lim = l0 == 4u ? far4 : (l0 == 5u ? far5 : far6);
             if (l0 >= 4u && l0 <= 6u && d0 > lim) m_cur &= 0xFFu;
         }
-        uint32_t first_next = (uint32_t)__shfl((int)m_next, 0);
-        uint32_t m1 = __shfl_down(m_cur, 1u);
-        if (lane == 63u) m1 = first_next;
+        // the matches one, two and three positions on: the lane above (one DPP move each), the top lanes from the next segment
+        const uint32_t m1 = zmi_lane_down1(m_cur, zmi_readlane(m_next, 0u));
         const bool valid = pos < pend;
         uint32_t mlen = (m_cur >> 8) & 0x1FFu;
         uint32_t mlen1 = (m1 >> 8) & 0x1FFu;
@@ -795,13 +807,9 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
         // two / three positions on that is longer by more than the literals in between cost (all matches are known
         // here, so looking further than the reference's one-position lazy rule, algorithm/medium.rs / slow.rs, is a
         // shuffle, not a search: lcet10.txt +0.8 %, benchmark shards +0.6 % for ~12 instructions per 64 positions)
-        uint32_t m2 = __shfl_down(m_cur, 2u);
-        const uint32_t n2 = (uint32_t)__shfl((int)m_next, (int)((lane + 2u) & 63u));
-        if (lane >= 62u) m2 = n2;
+        const uint32_t m2 = zmi_lane_down1(m1, zmi_readlane(m_next, 1u));
         const uint32_t mlen2 = (m2 >> 8) & 0x1FFu;
-        uint32_t m3 = __shfl_down(m_cur, 3u);
-        const uint32_t n3 = (uint32_t)__shfl((int)m_next, (int)((lane + 3u) & 63u));
-        if (lane >= 61u) m3 = n3;
+        const uint32_t m3 = zmi_lane_down1(m2, zmi_readlane(m_next, 2u));
         const uint32_t mlen3 = (m3 >> 8) & 0x1FFu;
         const bool defer = mlen < prm.max_lazy && (mlen1 > mlen || mlen2 > mlen + prm.lazy2 || mlen3 > mlen + prm.lazy3);
         if (valid && mlen >= 4u && !defer) step = mlen;
@@ -815,21 +823,25 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
                 mask = ~0ull << e;
                 enext = 0u;
             } else {
+                // Which positions start a token: follow lane -> lane + step from `e`.  Pointer doubling, the two halves of
+                // the wave on their own: five rounds on (next position, 32-bit set of visited lanes of the half) instead of
+                // six on a 64-bit set, then the halves are joined through two scalar reads (e is wave-uniform).
+                const uint32_t hb = (lane & 32u) + 32u;          // end of this lane's half
                 uint32_t J = lane + step;
-                uint32_t Rlo = lane < 32u ? (1u << lane) : 0u;
-                uint32_t Rhi = lane >= 32u ? (1u << (lane - 32u)) : 0u;
+                uint32_t R = 1u << (lane & 31u);
 #pragma unroll
-                for (int r = 0; r < 6; ++r) {
-                    uint32_t srcl = J < 64u ? J : lane;
-                    uint32_t Jn = (uint32_t)__shfl((int)J, (int)srcl);
-                    uint32_t Ln = (uint32_t)__shfl((int)Rlo, (int)srcl);
-                    uint32_t Hn = (uint32_t)__shfl((int)Rhi, (int)srcl);
-                    if (J < 64u) { J = Jn; Rlo |= Ln; Rhi |= Hn; }
+                for (int r = 0; r < 5; ++r) {
+                    const bool inh = J < hb;
+                    const uint32_t srcl = inh ? J : lane;
+                    const uint32_t Jn = (uint32_t)__shfl((int)J, (int)srcl);
+                    const uint32_t Rn = (uint32_t)__shfl((int)R, (int)srcl);
+                    if (inh) { J = Jn; R |= Rn; }
                 }
-                uint32_t ml = (uint32_t)__shfl((int)Rlo, (int)e);
-                uint32_t mh = (uint32_t)__shfl((int)Rhi, (int)e);
-                mask = ((uint64_t)mh << 32) | ml;
-                enext = (uint32_t)__shfl((int)J, (int)e) - 64u;
+                uint32_t mlo = 0, mhi = 0, ex = e;               // e < 64 here
+                if (e < 32u) { mlo = zmi_readlane(R, e); ex = zmi_readlane(J, e); }
+                if (ex < 64u) { mhi = zmi_readlane(R, ex); ex = zmi_readlane(J, ex); }
+                mask = ((uint64_t)mhi << 32) | mlo;
+                enext = ex - 64u;
             }
             mask &= __ballot(valid);
             const bool in = (mask >> lane) & 1ull;
@@ -837,11 +849,8 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
                 uint32_t tk = step > 1u ? ((m_cur & ~(0x1FFu << 8)) | (step << 8)) : (m_cur & 0xFFu);
                 tokbuf[tok0 + ntok + zmi_mbcnt(mask)] = tk;
                 if (step > 1u) {
-                    uint32_t li, leb, lev, di, deb, dev;
-                    enc_len_sym(step, li, leb, lev);
-                    enc_dist_sym((m_cur >> 17) + 1u, di, deb, dev);
-                    atomicAdd(&S->lfreq2[257u + li], 1u);
-                    atomicAdd(&S->dfreq2[di], 1u);
+                    atomicAdd(&S->lfreq2[257u + enc_len_idx(step)], 1u);
+                    atomicAdd(&S->dfreq2[enc_dist_idx((m_cur >> 17) + 1u)], 1u);
                 } else {
                     atomicAdd(&S->lfreq2[m_cur & 0xFFu], 1u);
                 }

@@ -56,6 +56,18 @@ static __device__ __forceinline__ uint32_t zmi_lane_up1(uint32_t v) {
 }
 #endif
 
+// the value of the lane above; lane 63 reads `fill` (DPP wave_shl:1, lanes without a source keep the old value)
+#ifdef ZMI_EMU
+static inline uint32_t zmi_lane_down1(uint32_t v, uint32_t fill) {
+    const uint32_t r = (uint32_t)__shfl_down((int)v, 1u);
+    return (threadIdx.x & 63u) == 63u ? fill : r;
+}
+#else
+static __device__ __forceinline__ uint32_t zmi_lane_down1(uint32_t v, uint32_t fill) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xF, 0xF, false);
+}
+#endif
+
 // tell the compiler a value is the same in every lane (it then lives in an SGPR and branches on it are scalar)
 #ifdef ZMI_EMU
 static inline uint32_t zmi_uniform(uint32_t v) { return v; }
