@@ -137,6 +137,18 @@ def test_inflate_long_distances_and_runs(eng, o):
         assert outs == blobs
 
 
+def test_crc32_block_scheme_boundaries(eng, o):
+    """gzip trailers (CRC-32) of shards around the 16 KiB block size of the checksum kernel: alone in the buffer (16-byte
+    aligned: full blocks go through the interleaved scheme) and behind an odd-sized neighbour (unaligned: segment scheme)"""
+    sizes = [16383, 16384, 16385, 2 * 16384, 3 * 16384 + 7, (1 << 17) + 63, 5 * 16384 - 1]
+    for k, n in enumerate(sizes):
+        d = o.gen_shard(k, n)
+        outs, st = eng.deflate([d], level=1, wrap=2)
+        assert st == [0] and zlib.decompress(outs[0], 31) == d, n
+        outs, st = eng.deflate([b"x" * 3, d, d[:777], d], level=1, wrap=2)
+        assert st == [0] * 4 and [zlib.decompress(c, 31) for c in outs] == [b"x" * 3, d, d[:777], d], n
+
+
 def resolve_window_edge_streams(o):
     """after a long hole-free stretch the resolve pass restarts its ring one window in front of the
     batch.  The restart used to be derived from the LAST hole of the batch (+3), which with a batch spanning RES_SPAN

@@ -50,6 +50,34 @@ static __device__ __forceinline__ uint32_t zmi_gf2_xpow8(uint64_t nbytes) {
     return r;
 }
 
+// the same algebra at compile time, for the two constants of the block scheme below
+constexpr uint32_t zmi_cx_mulmod(uint32_t a, uint32_t b) {
+    uint32_t p = 0;
+    for (int i = 31; i >= 0; --i) {
+        if ((a >> i) & 1u) p ^= b;
+        b = (b >> 1) ^ ((b & 1u) ? ZMI_CRC_POLY : 0u);
+    }
+    return p;
+}
+constexpr uint32_t zmi_cx_xpow8(uint64_t nbytes) {
+    uint32_t r = 0x80000000u, pw = 0x00800000u;
+    while (nbytes) {
+        if (nbytes & 1u) r = zmi_cx_mulmod(r, pw);
+        pw = zmi_cx_mulmod(pw, pw);
+        nbytes >>= 1;
+    }
+    return r;
+}
+#define CRC_CHUNK 64u                       // bytes a thread takes from a block
+#define CRC_BLOCK (256u * CRC_CHUNK)        // bytes the workgroup takes per step
+constexpr uint32_t kCrcSkipBlock = zmi_cx_xpow8(CRC_BLOCK - CRC_CHUNK);   // x^(8 * (block - chunk)) mod P
+constexpr uint32_t kCrcSkipChunk = zmi_cx_xpow8(CRC_CHUNK);               // x^(8 * chunk) mod P
+
+// v * K mod P through four byte tables of K (multiplication by a constant is linear in v)
+static __device__ __forceinline__ uint32_t zmi_crc_mulk(const uint32_t (*kt)[256], uint32_t v) {
+    return kt[0][v & 0xFFu] ^ kt[1][(v >> 8) & 0xFFu] ^ kt[2][(v >> 16) & 0xFFu] ^ kt[3][v >> 24];
+}
+
 // kind: bit0 = adler32 wanted, bit1 = crc32 wanted.  out_adler/out_crc indexed by shard.
 __global__ void __launch_bounds__(256) zmi_checksum_kernel(const uint8_t* __restrict__ data,
                                                            const uint64_t* __restrict__ off,
@@ -57,6 +85,7 @@ __global__ void __launch_bounds__(256) zmi_checksum_kernel(const uint8_t* __rest
                                                            uint32_t* __restrict__ out_adler,
                                                            uint32_t* __restrict__ out_crc) {
     __shared__ uint32_t tab[16][256];
+    __shared__ uint32_t kblk[4][256], kchk[4][256], fold[256];
     __shared__ uint32_t red[3][4];
     const uint32_t s = blockIdx.x;
     const uint32_t t = threadIdx.x;
@@ -117,17 +146,57 @@ __global__ void __launch_bounds__(256) zmi_checksum_kernel(const uint8_t* __rest
             tab[k][t] = c;
         }
         __syncthreads();
-        // contiguous segment per thread, length multiple of 16
-        uint32_t seg = ((n + 255u) / 256u + 15u) & ~15u;
+        // Full blocks of 16 KiB: thread t takes the 64 bytes at t * 64 of every block (neighbouring lanes read
+        // neighbouring memory; one contiguous 4 KiB segment per thread made every load of a wave touch 64 different
+        // lines).  Between two blocks a thread's running value skips the 16 KiB - 64 bytes of the others: a multiplication
+        // by the constant x^(8 * 16320), four table reads.  At the end thread 0 folds the 256 values in order
+        // (value * x^(8 * 64) + next).
+        const uint32_t nfull = aligned ? n / CRC_BLOCK : 0u;
+        uint32_t full_raw = 0;
+        if (nfull) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; ++i) {
+                kblk[i][t] = zmi_gf2_mulmod(t << (8u * i), kCrcSkipBlock);
+                kchk[i][t] = zmi_gf2_mulmod(t << (8u * i), kCrcSkipChunk);
+            }
+            __syncthreads();
+            uint32_t acc = 0;
+            const uint8_t* pch = src + t * CRC_CHUNK;
+            for (uint32_t blk = 0; blk < nfull; ++blk, pch += CRC_BLOCK) {
+                uint4 q[4];
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) q[k] = *(const uint4*)(pch + 16u * k);
+                if (blk) acc = zmi_crc_mulk(kblk, acc);
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) {
+                    const uint32_t x = acc ^ q[k].x;
+                    acc = tab[15][x & 0xFFu] ^ tab[14][(x >> 8) & 0xFFu] ^ tab[13][(x >> 16) & 0xFFu] ^ tab[12][x >> 24] ^
+                          tab[11][q[k].y & 0xFFu] ^ tab[10][(q[k].y >> 8) & 0xFFu] ^ tab[9][(q[k].y >> 16) & 0xFFu] ^ tab[8][q[k].y >> 24] ^
+                          tab[7][q[k].z & 0xFFu] ^ tab[6][(q[k].z >> 8) & 0xFFu] ^ tab[5][(q[k].z >> 16) & 0xFFu] ^ tab[4][q[k].z >> 24] ^
+                          tab[3][q[k].w & 0xFFu] ^ tab[2][(q[k].w >> 8) & 0xFFu] ^ tab[1][(q[k].w >> 16) & 0xFFu] ^ tab[0][q[k].w >> 24];
+                }
+            }
+            fold[t] = acc;
+            __syncthreads();
+            if (t == 0) {
+                uint32_t tot = 0;
+                for (uint32_t i = 0; i < 256u; ++i) tot = zmi_crc_mulk(kchk, tot) ^ fold[i];
+                full_raw = tot;
+            }
+        }
+        // the rest (everything, for an unaligned shard): one contiguous segment per thread, length multiple of 16
+        const uint32_t n0 = nfull * CRC_BLOCK, nt = n - n0;
+        const uint8_t* tsrc = src + n0;
+        uint32_t seg = ((nt + 255u) / 256u + 15u) & ~15u;
         uint64_t beg = (uint64_t)t * seg;
         uint32_t crc = 0;
         uint64_t after = 0;
-        if (beg < n) {
-            uint32_t end = (beg + seg < n) ? (uint32_t)(beg + seg) : n;
-            after = n - end;
+        if (beg < nt) {
+            uint32_t end = (beg + seg < nt) ? (uint32_t)(beg + seg) : nt;
+            after = nt - end;
             for (uint32_t i0 = (uint32_t)beg; i0 < end; i0 += 16u) {
                 uint32_t nv = end - i0;
-                zmi_b16 v = zmi_ld16(src + i0, nv, aligned);
+                zmi_b16 v = zmi_ld16(tsrc + i0, nv, aligned);
                 if (nv >= 16u) {
                     const uint32_t x = crc ^ v.w[0];
                     uint32_t r = tab[15][x & 0xFFu] ^ tab[14][(x >> 8) & 0xFFu] ^ tab[13][(x >> 16) & 0xFFu] ^ tab[12][x >> 24];
@@ -147,6 +216,7 @@ __global__ void __launch_bounds__(256) zmi_checksum_kernel(const uint8_t* __rest
             }
             crc = zmi_gf2_mulmod(crc, zmi_gf2_xpow8(after));
         }
+        if (t == 0 && nfull) crc ^= zmi_gf2_mulmod(full_raw, zmi_gf2_xpow8(nt));   // the full blocks, moved in front of the rest
         // xor-reduce
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) crc ^= __shfl_xor(crc, d);
