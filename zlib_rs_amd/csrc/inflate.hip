@@ -405,7 +405,6 @@ struct InfLane {
     uint32_t flags;   // 1 invalid code, 2 end of block (exit = first bit behind it)
 };
 template <bool RESUME> struct InfFastOf { typedef InfFast type; };
-template <> struct InfFastOf<true> { struct type { uint8_t none[16]; }; };
 template <bool WRITE>
 static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, const uint8_t* fb, uint32_t start, uint32_t boundary,
                                                           bool active, uint8_t* dst, uint32_t* bm32, uint32_t obase) {
@@ -559,7 +558,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                                                          const uint32_t* __restrict__ in_bit, uint32_t* __restrict__ resume) {
     __shared__ InfShared Sh;
     InfShared* S = &Sh;
-    __shared__ typename InfFastOf<RESUME>::type Ff;   // (empty in the resumable instantiation)
+    __shared__ typename InfFastOf<RESUME>::type Ff;
     const uint32_t lane = zmi_lane();
     const uint32_t s = zmi_xcd_spread(blockIdx.x, gridDim.x);
     InfBits B;
@@ -799,7 +798,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             const uint32_t* iw = (const uint32_t*)B.inbuf;
             bool eob = false;
             while (!eob && st == ZMI_OK) {
-                if (!RESUME) {
+                {
                     // lane-serial fast pass while there are >= 4 KiB of input behind P (see inf_fast_pass); it commits only
                     // what is certain, everything unusual falls through to a token round below
                     if (Pend - P >= 8ull * (INF_FAST_BYTES + 32u)) {
