@@ -481,7 +481,7 @@ static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, co
 
 // One fast pass from bit P of the stream.  Returns the number of lanes committed (0: nothing done); *bits_used / *out_made
 // / *hit_eob describe what was committed.  All lanes call.
-static __device__ __noinline__ uint32_t inf_fast_pass(InfShared* S, const uint8_t* src, uint64_t P, uint8_t* dst,
+static __device__ __forceinline__ uint32_t inf_fast_pass(InfShared* S, const uint8_t* src, uint64_t P, uint8_t* dst,
                                                       uint32_t* bm32, uint32_t opos, uint32_t cap, uint32_t hist,
                                                       uint32_t* bits_used, uint32_t* out_made, uint32_t* hit_eob) {
     const uint32_t lane = zmi_lane();
