@@ -89,6 +89,10 @@ struct InfShared {
     };
 };
 
+// One per workgroup, at file scope: a function that is not inlined reaches it by name, as LDS (through a pointer argument
+// it would be a generic pointer -- a 64-bit add and a null check in front of every access)
+__shared__ InfShared g_inf_lds;
+
 struct InfBits {
     const uint8_t* src;
     uint32_t n;
@@ -101,7 +105,9 @@ struct InfBits {
 
 // (re)load the LDS input chunk so that it starts at the 16-byte aligned address at or below ipos;
 // returns the stream offset of inbuf[0] (negative for the first chunk of a misaligned stream)
-static __device__ __noinline__ int32_t inf_load_chunk(const uint8_t* src, uint32_t n, uint32_t ipos, uint8_t* inbuf) {
+static __device__ __noinline__ int32_t inf_load_chunk(const uint8_t* src, uint32_t n, uint32_t ipos, uint8_t* inbuf_) {
+    uint8_t* const inbuf = g_inf_lds.inbuf;   // (= inbuf_)
+    (void)inbuf_;
     const uint32_t lane = zmi_lane();
     const uint32_t mis = (uint32_t)((uintptr_t)(src + ipos) & 15u);
     const int32_t cbase = (int32_t)ipos - (int32_t)mis;
@@ -182,8 +188,11 @@ static __device__ __forceinline__ uint32_t inf_entry(uint32_t kind, uint32_t sym
 // its length + its rank among the lower-indexed symbols of that length: ballot + mbcnt, running counts in scalar
 // registers) and the root-table entries of the codes that fit the root.  Only the codes longer than the root (few)
 // are walked serially, because the sub-tables are sized by looking ahead in canonical order.
-static __device__ __noinline__ uint32_t inf_build(InfShared* S, uint32_t kind, uint32_t nsym, uint32_t* tab, uint32_t root,
+static __device__ __noinline__ uint32_t inf_build(InfShared* S_, uint32_t kind, uint32_t nsym, uint32_t* tab_, uint32_t root,
                                      uint32_t cap) {
+    InfShared* const S = &g_inf_lds;                           // (= S_)
+    uint32_t* const tab = kind == 1u ? S->ltab : S->dtab;      // (= tab_: the literal/length table, or the distance table --
+    (void)S_; (void)tab_;                                      //  which the code-length code borrows)
     const uint32_t lane = zmi_lane();
     if (lane < 16u) S->cnt[lane] = 0;
     zmi_wave_sync();
@@ -559,8 +568,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                                                          uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ bm_off,
                                                          const uint32_t* __restrict__ out_hist,
                                                          const uint32_t* __restrict__ in_bit, uint32_t* __restrict__ resume) {
-    __shared__ InfShared Sh;
-    InfShared* S = &Sh;
+    InfShared* S = &g_inf_lds;
     const uint32_t lane = zmi_lane();
     const uint32_t s = zmi_xcd_spread(blockIdx.x, gridDim.x);
     InfBits B;
