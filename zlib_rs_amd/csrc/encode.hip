@@ -686,6 +686,34 @@ static __device__ __noinline__ bool enc_split_pays(const EncShared* S, uint32_t 
     return apart + (float)hdr_bits < joined;
 }
 
+// One segment of 64 positions: drop the short far matches (enc_far_limits), apply the lazy rule, return the lane's step (1:
+// a literal).  m: the lane's match word (filtered in place); nxt: the words of the segment behind it (its first three
+// positions are the look-ahead of this segment's last three lanes).
+static __device__ __forceinline__ uint32_t enc_seg_step(uint32_t& m, uint32_t nxt, uint32_t pos, uint32_t pend, const zmi_enc_params& prm,
+                                                        uint32_t far4, uint32_t far5, uint32_t far6) {
+    {
+        const uint32_t l0 = (m >> 8) & 0x1FFu, d0 = (m >> 17) + 1u;
+        const uint32_t lim = l0 == 4u ? far4 : (l0 == 5u ? far5 : far6);
+        if (l0 >= 4u && l0 <= 6u && d0 > lim) m &= 0xFFu;
+    }
+    // the matches one, two and three positions on: the lane above (one DPP move each), the top lanes from the next segment
+    const uint32_t m1 = zmi_lane_down1(m, zmi_readlane(nxt, 0u));
+    const uint32_t m2 = zmi_lane_down1(m1, zmi_readlane(nxt, 1u));
+    const uint32_t m3 = zmi_lane_down1(m2, zmi_readlane(nxt, 2u));
+    const bool valid = pos < pend;
+    const uint32_t mlen = (m >> 8) & 0x1FFu, mlen1 = (m1 >> 8) & 0x1FFu, mlen2 = (m2 >> 8) & 0x1FFu, mlen3 = (m3 >> 8) & 0x1FFu;
+    // lazy evaluation, three positions deep: a short match steps aside for a longer one right behind it, or for one
+    // two / three positions on that is longer by more than the literals in between cost (all matches are known
+    // here, so looking further than the reference's one-position lazy rule, algorithm/medium.rs / slow.rs, is a
+    // shuffle, not a search: lcet10.txt +0.8 %, benchmark shards +0.6 % for ~12 instructions per 64 positions)
+    const bool defer = mlen < prm.max_lazy && (mlen1 > mlen || mlen2 > mlen + prm.lazy2 || mlen3 > mlen + prm.lazy3);
+    uint32_t step = 1u;
+    if (valid && mlen >= 4u && !defer) step = mlen;
+    // a token may not cross the end of the piece (the next piece starts a fresh parse there)
+    if (valid && pos + step > pend) { step = pend - pos; if (step < 3u) step = 1u; }
+    return step;
+}
+
 __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off,
                                                         const uint32_t* __restrict__ len, uint32_t first_shard,
                                                         uint32_t* match, uint64_t match_stride,
@@ -786,84 +814,75 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
     if (lane == 0) { S->misc[M_FAR4] = prm.far4; S->misc[M_FAR5] = prm.far5; S->misc[M_FAR6] = 32768u; }
     zmi_wave_sync();
     uint32_t far4 = prm.far4, far5 = prm.far5, far6 = 32768u;
-    uint32_t m_cur = (pstart + lane < pend) ? tokbuf[pstart + lane] : 0u;
-    uint32_t m_next = (pstart + 64u + lane < pend) ? tokbuf[pstart + 64u + lane] : 0u;
-    for (uint32_t seg = seg0; seg < nseg; ++seg) {
-        const uint32_t pos = seg * 64u + lane;
-        const uint32_t npos2 = pos + 128u;
-        const uint32_t m_next2 = (npos2 < pend) ? tokbuf[npos2] : 0u;
-        {
-            const uint32_t l0 = (m_cur >> 8) & 0x1FFu, d0 = (m_cur >> 17) + 1u;
-            const uint32_t lim = l0 == 4u ? far4 : (l0 == 5u ? far5 : far6);
-            if (l0 >= 4u && l0 <= 6u && d0 > lim) m_cur &= 0xFFu;
-        }
-        // the matches one, two and three positions on: the lane above (one DPP move each), the top lanes from the next segment
-        const uint32_t m1 = zmi_lane_down1(m_cur, zmi_readlane(m_next, 0u));
-        const bool valid = pos < pend;
-        uint32_t mlen = (m_cur >> 8) & 0x1FFu;
-        uint32_t mlen1 = (m1 >> 8) & 0x1FFu;
-        uint32_t step = 1u;
-        // lazy evaluation, three positions deep: a short match steps aside for a longer one right behind it, or for one
-        // two / three positions on that is longer by more than the literals in between cost (all matches are known
-        // here, so looking further than the reference's one-position lazy rule, algorithm/medium.rs / slow.rs, is a
-        // shuffle, not a search: lcet10.txt +0.8 %, benchmark shards +0.6 % for ~12 instructions per 64 positions)
-        const uint32_t m2 = zmi_lane_down1(m1, zmi_readlane(m_next, 1u));
-        const uint32_t mlen2 = (m2 >> 8) & 0x1FFu;
-        const uint32_t m3 = zmi_lane_down1(m2, zmi_readlane(m_next, 2u));
-        const uint32_t mlen3 = (m3 >> 8) & 0x1FFu;
-        const bool defer = mlen < prm.max_lazy && (mlen1 > mlen || mlen2 > mlen + prm.lazy2 || mlen3 > mlen + prm.lazy3);
-        if (valid && mlen >= 4u && !defer) step = mlen;
-        // a token may not cross the end of the piece (the next piece starts a fresh parse there)
-        if (valid && pos + step > pend) { step = pend - pos; if (step < 3u) step = 1u; }
-        if (e < 64u) {
-            uint64_t mask;
-            uint32_t enext;
-            uint64_t anym = __ballot(step > 1u && lane >= e);
-            if (anym == 0ull) {
-                mask = ~0ull << e;
-                enext = 0u;
-            } else {
-                // Which positions start a token: follow lane -> lane + step from `e`.  Pointer doubling, the two halves of
-                // the wave on their own: five rounds on (next position, 32-bit set of visited lanes of the half) instead of
-                // six on a 64-bit set, then the halves are joined through two scalar reads (e is wave-uniform).
-                const uint32_t hb = (lane & 32u) + 32u;          // end of this lane's half
-                uint32_t J = lane + step;
-                uint32_t R = 1u << (lane & 31u);
+    // Two segments (128 positions) per trip: their lazy rules and pointer-doubling chains do not depend on each other (only
+    // the last step, picking the chain that starts where the token before ended, is serial), so the two sets of
+    // shuffles are in flight together -- the kernel sits between latency and issue bound, and this is occupancy
+    // that costs no LDS.  Match words are fetched two trips ahead.
+    uint32_t m_a = (pstart + lane < pend) ? tokbuf[pstart + lane] : 0u;
+    uint32_t m_b = (pstart + 64u + lane < pend) ? tokbuf[pstart + 64u + lane] : 0u;
+    uint32_t m_c = (pstart + 128u + lane < pend) ? tokbuf[pstart + 128u + lane] : 0u;
+    for (uint32_t seg = seg0; seg < nseg; seg += 2u) {
+        const uint32_t posA = seg * 64u + lane, posB = posA + 64u;
+        const uint32_t m_d = (posA + 192u < pend) ? tokbuf[posA + 192u] : 0u;
+        const uint32_t m_e = (posA + 256u < pend) ? tokbuf[posA + 256u] : 0u;
+        const uint32_t stepA = enc_seg_step(m_a, m_b, posA, pend, prm, far4, far5, far6);
+        const uint32_t stepB = enc_seg_step(m_b, m_c, posB, pend, prm, far4, far5, far6);
+        const uint64_t validA = __ballot(posA < pend), validB = __ballot(posB < pend);
+        uint32_t JA = lane + stepA, RA = zmi_lane_bit32_here(lane), JB = lane + stepB, RB = RA;
+        const bool any_match = __ballot(stepA > 1u || stepB > 1u) != 0ull;
+        if (any_match) {
+            // Which positions start a token: follow lane -> lane + step.  Pointer doubling, the two halves of the wave on
+            // their own: five rounds on (next position, 32-bit set of visited lanes of the half) instead of six on a
+            // 64-bit set; the halves are joined through scalar reads below (the entry lane is wave-uniform).
+            const uint32_t hb = (lane & 32u) + 32u;          // end of this lane's half
 #pragma unroll
-                for (int r = 0; r < 5; ++r) {
-                    const bool inh = J < hb;
-                    const uint32_t srcl = inh ? J : lane;
-                    const uint32_t Jn = (uint32_t)__shfl((int)J, (int)srcl);
-                    const uint32_t Rn = (uint32_t)__shfl((int)R, (int)srcl);
-                    if (inh) { J = Jn; R |= Rn; }
-                }
-                uint32_t mlo = 0, mhi = 0, ex = e;               // e < 64 here
-                if (e < 32u) { mlo = zmi_readlane(R, e); ex = zmi_readlane(J, e); }
-                if (ex < 64u) { mhi = zmi_readlane(R, ex); ex = zmi_readlane(J, ex); }
-                mask = ((uint64_t)mhi << 32) | mlo;
-                enext = ex - 64u;
+            for (int r = 0; r < 5; ++r) {
+                const bool inA = JA < hb, inB = JB < hb;
+                const uint32_t sA = inA ? JA : lane, sB = inB ? JB : lane;
+                const uint32_t JAn = (uint32_t)__shfl((int)JA, (int)sA), RAn = (uint32_t)__shfl((int)RA, (int)sA);
+                const uint32_t JBn = (uint32_t)__shfl((int)JB, (int)sB), RBn = (uint32_t)__shfl((int)RB, (int)sB);
+                if (inA) { JA = JAn; RA |= RAn; }
+                if (inB) { JB = JBn; RB |= RBn; }
             }
-            mask &= __ballot(valid);
-            const bool in = (mask >> lane) & 1ull;
-            if (in) {
-                uint32_t tk = step > 1u ? ((m_cur & ~(0x1FFu << 8)) | (step << 8)) : (m_cur & 0xFFu);
-                tokbuf[tok0 + ntok + zmi_mbcnt(mask)] = tk;
-                if (step > 1u) {
-                    atomicAdd(&S->lfreq2[257u + enc_len_idx(step)], 1u);
-                    atomicAdd(&S->dfreq2[enc_dist_idx((m_cur >> 17) + 1u)], 1u);
-                } else {
-                    atomicAdd(&S->lfreq2[m_cur & 0xFFu], 1u);
-                }
-            }
-            ntok += (uint32_t)__popcll(mask);
-            e = enext;
-        } else {
-            e -= 64u;
         }
-        m_cur = m_next;
-        m_next = m_next2;
-        const uint32_t done = (seg + 1u) * 64u;
-        const bool last_seg = seg + 1u == nseg;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const uint32_t J = half ? JB : JA, R = half ? RB : RA, step = half ? stepB : stepA, mw = half ? m_b : m_a;
+            const uint64_t validm = half ? validB : validA;
+            if (e < 64u) {
+                uint64_t mask;
+                if (!any_match) {
+                    mask = ~0ull << e;
+                    e = 0u;
+                } else {
+                    uint32_t mlo = 0, mhi = 0, ex = e;
+                    if (e < 32u) { mlo = zmi_readlane(R, e); ex = zmi_readlane(J, e); }
+                    if (ex < 64u) { mhi = zmi_readlane(R, ex); ex = zmi_readlane(J, ex); }
+                    mask = ((uint64_t)mhi << 32) | mlo;
+                    e = ex - 64u;
+                }
+                mask &= validm;
+                const bool in = (mask >> lane) & 1ull;
+                if (in) {
+                    uint32_t tk = step > 1u ? ((mw & ~(0x1FFu << 8)) | (step << 8)) : (mw & 0xFFu);
+                    tokbuf[tok0 + ntok + zmi_mbcnt(mask)] = tk;
+                    if (step > 1u) {
+                        atomicAdd(&S->lfreq2[257u + enc_len_idx(step)], 1u);
+                        atomicAdd(&S->dfreq2[enc_dist_idx((mw >> 17) + 1u)], 1u);
+                    } else {
+                        atomicAdd(&S->lfreq2[mw & 0xFFu], 1u);
+                    }
+                }
+                ntok += (uint32_t)__popcll(mask);
+            } else {
+                e -= 64u;
+            }
+        }
+        m_a = m_c;
+        m_b = m_d;
+        m_c = m_e;
+        const uint32_t done = (seg + 2u) * 64u;   // (may lie one segment behind the piece: everything below clamps to pend)
+        const bool last_seg = seg + 2u >= nseg;
         // a sub-block closes after block_tokens tokens, optionally not before it spans min_sub_span bytes of input (or holds
         // twice the tokens): literal-dense data cuts a block, with a full tree construction, every 4 KiB -- the random-walk
         // class spends half of its encode time building trees, but those small blocks are also where its ratio comes from

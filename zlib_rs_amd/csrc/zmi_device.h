@@ -68,6 +68,18 @@ static __device__ __forceinline__ uint32_t zmi_lane_down1(uint32_t v, uint32_t f
 }
 #endif
 
+// 1 << (lane & 31), computed where it stands: the compiler would keep this loop-invariant value in a register of its own
+// across the whole tokeniser loop, and that register is the one that costs the encode kernel a wave per SIMD
+#ifdef ZMI_EMU
+static inline uint32_t zmi_lane_bit32_here(uint32_t lane) { return 1u << (lane & 31u); }
+#else
+static __device__ __forceinline__ uint32_t zmi_lane_bit32_here(uint32_t lane) {
+    uint32_t r;
+    asm volatile("v_lshlrev_b32 %0, %1, 1" : "=v"(r) : "v"(lane));   // the shift count is taken modulo 32
+    return r;
+}
+#endif
+
 // tell the compiler a value is the same in every lane (it then lives in an SGPR and branches on it are scalar)
 #ifdef ZMI_EMU
 static inline uint32_t zmi_uniform(uint32_t v) { return v; }
