@@ -38,9 +38,6 @@
 #define ENC_ND 32u
 #define ENC_NBL 19u
 #define ENC_STG 128u
-#ifndef ENC_TSEG
-#define ENC_TSEG 2u                // segments of 64 positions the tokeniser takes per trip
-#endif
 
 // 6.7 KiB per wave: 23 single-wave workgroups fit a CU's 160 KiB (the 9.2 KiB of round 1 held it at 17; the kernel waits on
 // memory half of its cycles, so resident waves are what hides that).  The code tables of the emission pass share their
@@ -817,30 +814,22 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
     if (lane == 0) { S->misc[M_FAR4] = prm.far4; S->misc[M_FAR5] = prm.far5; S->misc[M_FAR6] = 32768u; }
     zmi_wave_sync();
     uint32_t far4 = prm.far4, far5 = prm.far5, far6 = 32768u;
-    // ENC_TSEG segments (of 64 positions) per trip: their lazy rules and pointer-doubling chains do not depend on each other (only
-    // the last step, picking the chain that starts where the token before ended, is serial), so their
+    // Two segments (128 positions) per trip: their lazy rules and pointer-doubling chains do not depend on each other (only
+    // the last step, picking the chain that starts where the token before ended, is serial), so the two sets of
     // shuffles are in flight together -- the kernel sits between latency and issue bound, and this is occupancy
     // that costs no LDS.  Match words are fetched two trips ahead.
-    uint32_t mw[2u * ENC_TSEG + 1u];   // the trip's segments and the one behind them (look-ahead), then the next trip's (in flight)
-#pragma unroll
-    for (uint32_t k = 0; k <= ENC_TSEG; ++k) mw[k] = (pstart + 64u * k + lane < pend) ? tokbuf[pstart + 64u * k + lane] : 0u;
-    for (uint32_t seg = seg0; seg < nseg; seg += ENC_TSEG) {
-        const uint32_t pos0 = seg * 64u + lane;
-#pragma unroll
-        for (uint32_t k = 1; k <= ENC_TSEG; ++k)
-            mw[ENC_TSEG + k] = (pos0 + 64u * (ENC_TSEG + k) < pend) ? tokbuf[pos0 + 64u * (ENC_TSEG + k)] : 0u;
-        uint32_t stp[ENC_TSEG], J[ENC_TSEG], R[ENC_TSEG];
-        uint64_t validm[ENC_TSEG];
-        bool anyv = false;
-#pragma unroll
-        for (uint32_t k = 0; k < ENC_TSEG; ++k) {
-            stp[k] = enc_seg_step(mw[k], mw[k + 1u], pos0 + 64u * k, pend, prm, far4, far5, far6);
-            validm[k] = __ballot(pos0 + 64u * k < pend);
-            J[k] = lane + stp[k];
-            R[k] = zmi_lane_bit32_here(lane);
-            anyv = anyv || stp[k] > 1u;
-        }
-        const bool any_match = __ballot(anyv) != 0ull;
+    uint32_t m_a = (pstart + lane < pend) ? tokbuf[pstart + lane] : 0u;
+    uint32_t m_b = (pstart + 64u + lane < pend) ? tokbuf[pstart + 64u + lane] : 0u;
+    uint32_t m_c = (pstart + 128u + lane < pend) ? tokbuf[pstart + 128u + lane] : 0u;
+    for (uint32_t seg = seg0; seg < nseg; seg += 2u) {
+        const uint32_t posA = seg * 64u + lane, posB = posA + 64u;
+        const uint32_t m_d = (posA + 192u < pend) ? tokbuf[posA + 192u] : 0u;
+        const uint32_t m_e = (posA + 256u < pend) ? tokbuf[posA + 256u] : 0u;
+        const uint32_t stepA = enc_seg_step(m_a, m_b, posA, pend, prm, far4, far5, far6);
+        const uint32_t stepB = enc_seg_step(m_b, m_c, posB, pend, prm, far4, far5, far6);
+        const uint64_t validA = __ballot(posA < pend), validB = __ballot(posB < pend);
+        uint32_t JA = lane + stepA, RA = zmi_lane_bit32_here(lane), JB = lane + stepB, RB = RA;
+        const bool any_match = __ballot(stepA > 1u || stepB > 1u) != 0ull;
         if (any_match) {
             // Which positions start a token: follow lane -> lane + step.  Pointer doubling, the two halves of the wave on
             // their own: five rounds on (next position, 32-bit set of visited lanes of the half) instead of six on a
@@ -848,21 +837,18 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
             const uint32_t hb = (lane & 32u) + 32u;          // end of this lane's half
 #pragma unroll
             for (int r = 0; r < 5; ++r) {
-                uint32_t Jn[ENC_TSEG], Rn[ENC_TSEG];
-#pragma unroll
-                for (uint32_t k = 0; k < ENC_TSEG; ++k) {
-                    const uint32_t sl = J[k] < hb ? J[k] : lane;
-                    Jn[k] = (uint32_t)__shfl((int)J[k], (int)sl);
-                    Rn[k] = (uint32_t)__shfl((int)R[k], (int)sl);
-                }
-#pragma unroll
-                for (uint32_t k = 0; k < ENC_TSEG; ++k)
-                    if (J[k] < hb) { J[k] = Jn[k]; R[k] |= Rn[k]; }
+                const bool inA = JA < hb, inB = JB < hb;
+                const uint32_t sA = inA ? JA : lane, sB = inB ? JB : lane;
+                const uint32_t JAn = (uint32_t)__shfl((int)JA, (int)sA), RAn = (uint32_t)__shfl((int)RA, (int)sA);
+                const uint32_t JBn = (uint32_t)__shfl((int)JB, (int)sB), RBn = (uint32_t)__shfl((int)RB, (int)sB);
+                if (inA) { JA = JAn; RA |= RAn; }
+                if (inB) { JB = JBn; RB |= RBn; }
             }
         }
 #pragma unroll
-        for (uint32_t k = 0; k < ENC_TSEG; ++k) {
-            const uint32_t step = stp[k], w = mw[k];
+        for (int half = 0; half < 2; ++half) {
+            const uint32_t J = half ? JB : JA, R = half ? RB : RA, step = half ? stepB : stepA, mw = half ? m_b : m_a;
+            const uint64_t validm = half ? validB : validA;
             if (e < 64u) {
                 uint64_t mask;
                 if (!any_match) {
@@ -870,21 +856,21 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
                     e = 0u;
                 } else {
                     uint32_t mlo = 0, mhi = 0, ex = e;
-                    if (e < 32u) { mlo = zmi_readlane(R[k], e); ex = zmi_readlane(J[k], e); }
-                    if (ex < 64u) { mhi = zmi_readlane(R[k], ex); ex = zmi_readlane(J[k], ex); }
+                    if (e < 32u) { mlo = zmi_readlane(R, e); ex = zmi_readlane(J, e); }
+                    if (ex < 64u) { mhi = zmi_readlane(R, ex); ex = zmi_readlane(J, ex); }
                     mask = ((uint64_t)mhi << 32) | mlo;
                     e = ex - 64u;
                 }
-                mask &= validm[k];
+                mask &= validm;
                 const bool in = (mask >> lane) & 1ull;
                 if (in) {
-                    uint32_t tk = step > 1u ? ((w & ~(0x1FFu << 8)) | (step << 8)) : (w & 0xFFu);
+                    uint32_t tk = step > 1u ? ((mw & ~(0x1FFu << 8)) | (step << 8)) : (mw & 0xFFu);
                     tokbuf[tok0 + ntok + zmi_mbcnt(mask)] = tk;
                     if (step > 1u) {
                         atomicAdd(&S->lfreq2[257u + enc_len_idx(step)], 1u);
-                        atomicAdd(&S->dfreq2[enc_dist_idx((w >> 17) + 1u)], 1u);
+                        atomicAdd(&S->dfreq2[enc_dist_idx((mw >> 17) + 1u)], 1u);
                     } else {
-                        atomicAdd(&S->lfreq2[w & 0xFFu], 1u);
+                        atomicAdd(&S->lfreq2[mw & 0xFFu], 1u);
                     }
                 }
                 ntok += (uint32_t)__popcll(mask);
@@ -892,10 +878,11 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
                 e -= 64u;
             }
         }
-#pragma unroll
-        for (uint32_t k = 0; k <= ENC_TSEG; ++k) mw[k] = mw[ENC_TSEG + k];
-        const uint32_t done = (seg + ENC_TSEG) * 64u;   // (may lie behind the piece: everything below clamps to pend)
-        const bool last_seg = seg + ENC_TSEG >= nseg;
+        m_a = m_c;
+        m_b = m_d;
+        m_c = m_e;
+        const uint32_t done = (seg + 2u) * 64u;   // (may lie one segment behind the piece: everything below clamps to pend)
+        const bool last_seg = seg + 2u >= nseg;
         // a sub-block closes after block_tokens tokens, optionally not before it spans min_sub_span bytes of input (or holds
         // twice the tokens): literal-dense data cuts a block, with a full tree construction, every 4 KiB -- the random-walk
         // class spends half of its encode time building trees, but those small blocks are also where its ratio comes from
