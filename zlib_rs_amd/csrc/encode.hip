@@ -111,14 +111,13 @@ static __device__ __forceinline__ uint32_t enc_dist_idx(uint32_t dist) {
     return d < 2u ? d : f;
 }
 static __device__ __forceinline__ void enc_dist_sym(uint32_t dist, uint32_t& idx, uint32_t& eb, uint32_t& ev) {
-    uint32_t d = dist - 1u;
-    if (d < 4u) { idx = d; eb = 0; ev = 0; }
-    else {
-        uint32_t k = 31u - (uint32_t)__clz(d);  // >= 2
-        eb = k - 1u;
-        idx = 2u * k + ((d >> eb) & 1u);
-        ev = d & ((1u << eb) - 1u);
-    }
+    // (branch-free: distances 1..4 are their own codes, then two codes per power of two)
+    const uint32_t d = dist - 1u;
+    const uint32_t k = 31u - (uint32_t)__clz(d | 2u);            // >= 1
+    eb = k - 1u;                                                 // d < 4: k = 1, no extra bits
+    const uint32_t f = 2u * k + ((d >> eb) & 1u);                // d in 2..3: f = d
+    idx = d < 2u ? d : f;
+    ev = d & ((1u << eb) - 1u);
 }
 static __device__ __forceinline__ uint32_t enc_lext(uint32_t idx) { return (idx < 8u || idx == 28u) ? 0u : (idx >> 2) - 1u; }
 static __device__ __forceinline__ uint32_t enc_dext(uint32_t idx) { return idx < 4u ? 0u : (idx >> 1) - 1u; }
