@@ -15,14 +15,19 @@
 // MI355X design: the symbol decode of one stream is serial in its bit position, so the batch supplies the
 // parallelism -- one 64-lane wave per stream -- and the work of a stream is split so that no HBM round
 // trip sits in a dependent chain:
-//   decode  (zmi_inflate_kernel)          Huffman decoding only.  64 lanes decode the tokens starting at 64
-//           consecutive bit positions speculatively, the real chain is walked with scalar lane reads, a wave
-//           scan places the outputs.  Literals go straight to their final place in HBM; a back-reference
-//           leaves a 3-byte record (length, distance) in the first bytes of the hole it will fill and sets a
-//           bit in a per-stream bitmap (1 bit per output byte).  No window is needed, so a wave holds only
-//           its lookup tables and a 1 KiB input chunk in LDS (~10 KiB, 15 streams per CU).
-//   resolve (zmi_inflate_resolve_kernel)  streams the output once through a 36 KiB LDS ring and fills the
-//           holes in order; every source lies in the ring (distance <= 32 KiB), so copies are LDS -> LDS.
+//   decode  (zmi_inflate_kernel)          Huffman decoding only, two ways.  Fast pass (while >= 4 KiB of input lie ahead):
+//           3.5 KiB of the block are staged in LDS and cut into 64 sub-sequences, one per lane, decoded serially by that
+//           lane; a prefix code resynchronises, so lanes started at a guess fall into step, lanes whose start is not the
+//           exit of the lane below walk again, and the consistent prefix is written (inf_fast_pass).  Token rounds
+//           (ends of streams, anything unusual): 64 lanes decode the tokens starting at 64 consecutive bit positions
+//           speculatively, the real chain is walked with scalar lane reads, a wave scan places the outputs.  Either way
+//           literals go straight to their final place in HBM; a back-reference leaves a 3-byte record (length,
+//           distance) in the first bytes of the hole it will fill and sets a bit in a per-stream bitmap (1 bit per
+//           output byte).  No window is needed, so a wave holds only its lookup tables and the staged input in LDS
+//           (9 KiB, 17 streams per CU).
+//   resolve (zmi_inflate_resolve_kernel)  streams the output once through a 6 KiB LDS ring and fills the holes in
+//           order; a source up to RES_NEAR bytes back lies in the ring (LDS -> LDS), one further back is read from
+//           HBM, where everything in front of the batch is final already (16 streams per CU).
 // Algorithmic HBM traffic: (1/ratio) B read + 1 B written per output byte; the two-pass split adds one more
 // read and write of the output plus the bitmap (1/8 B per byte).
 // The decode kernel has a second instantiation for streams that arrive in pieces (zmi_inflate_resume_dev): it can
