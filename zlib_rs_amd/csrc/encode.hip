@@ -11,14 +11,15 @@
 //   BitWriter / compress_block  zlib-rs/src/deflate.rs:907-1175
 //   header / trailer            zlib-rs/src/deflate.rs:1572-1601,2574-2627,2772-2789
 //
-// MI355X design: ONE WAVE PER 64 KiB PIECE of a shard (64-thread workgroups, ~9 KiB LDS, 16 waves resident per
+// MI355X design: ONE WAVE PER 64 KiB PIECE of a shard (64-thread workgroups, 6.7 KiB LDS, 23 waves resident per
 // CU), no workgroup barriers at all.  The batch supplies the parallelism (16 pieces x thousands of shards); the
 // pieces of a shard end byte aligned and are concatenated by zmi_compact_kernel.  Inside a piece the wave walks
-// 64 positions per step:
+// two segments of 64 positions per trip (independent until the last step: twice the shuffles in flight):
 //   * parse: every lane owns one position and knows its best match (from lz77.hip).  The greedy/lazy
-//     rule gives each position a local "next token" pointer; six rounds of wave-wide pointer doubling
-//     (ds_bpermute) turn the pointers into the 64-bit set of positions reachable from the segment's
-//     entry point -- the serial token walk of the CPU parse becomes log2(64) shuffles.
+//     rule (three positions deep) gives each position a local "next token" pointer; five rounds of pointer
+//     doubling per half wave (ds_bpermute) and two scalar joins turn the pointers into the 64-bit set of
+//     positions reachable from the segment's entry point -- the serial token walk of the CPU parse becomes
+//     log2(32) shuffles.
 //   * tokens are compacted with mbcnt and overwrite the match scratch in place (token index <=
 //     position index), histogrammed with LDS atomics.
 //   * blocks follow the data: after every sub-block of 4096 tokens an entropy test decides whether it joins the
