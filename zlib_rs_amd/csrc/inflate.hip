@@ -46,7 +46,7 @@ enum { DE_STORED_LEN = 1, DE_BLOCK_TYPE, DE_TOO_MANY_SYMS, DE_CODE_LENGTHS_SET, 
        DE_LITLEN_SET, DE_DIST_SET, DE_TOO_FAR_BACK, DE_HEADER_CHECK, DE_CODE };
 #define INF_CHUNK 1024u
 #define RES_RING 6144u               // resolve pass: output history kept in LDS: RES_NEAR + RES_SPAN + 258 + RES_BLK and slack; a
-                                     // multiple of RES_BLK; with the chunk tables 15.5 KiB per stream, ten streams per CU
+                                     // multiple of RES_BLK; with the chunk tables 7.75 KiB per stream, twenty streams per CU
 #define RES_NEAR 2560u               // resolve pass: a back-reference further than this reads its source from HBM (final there:
                                      // everything in front of the batch has been written back), a nearer one from the ring
 #define RES_BLK 1024u                // resolve pass: bytes staged per load step
@@ -1092,10 +1092,11 @@ static __device__ __forceinline__ uint32_t res_ld_final(const uint32_t* p) {
 #endif
 }
 #define RES_SHORT 16u
+#define RES_CW 32u          // bitmap words (of 64 output bytes) per chunk: 2 KiB of output; the chunk tables are 1.75 KiB
 struct ResChunk {
-    uint64_t cw[64];       // bitmap words of the chunk
-    uint32_t cex[64];      // holes in the chunk before word w
-    uint16_t list[1408];   // hole positions relative to the chunk (a hole is >= 3 bytes: <= 22 per word)
+    uint64_t cw[RES_CW];         // bitmap words of the chunk
+    uint32_t cex[RES_CW];        // holes in the chunk before word w
+    uint16_t list[22u * RES_CW]; // hole positions relative to the chunk (a hole is >= 3 bytes: <= 22 per word)
 };
 
 __global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, const uint64_t* __restrict__ out_off,
@@ -1126,17 +1127,16 @@ __global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, c
     bool any = false, have = false;
     uint4 pre;
     pre.x = pre.y = pre.z = pre.w = 0u;
-    for (uint32_t cbase = 0; cbase < nwords; cbase += 64u) {
+    for (uint32_t cbase = 0; cbase < nwords; cbase += RES_CW) {
         const uint32_t idx = cbase + lane;
-        const uint64_t v = idx < nwords ? bm[idx] : 0ull;
+        const uint64_t v = (lane < RES_CW && idx < nwords) ? bm[idx] : 0ull;
         const uint32_t pc = (uint32_t)__popcll(v);
         const uint32_t incl = zmi_wave_incl_scan(pc);
         const uint32_t total = zmi_readlane(incl, 63u);
         if (total == 0u) continue;
         const uint32_t chunk0 = (cbase << 6) + shift;
         zmi_wave_order();
-        C->cw[lane] = v;
-        C->cex[lane] = incl - pc;
+        if (lane < RES_CW) { C->cw[lane] = v; C->cex[lane] = incl - pc; }
         {
             uint64_t t = v;
             uint32_t k = incl - pc;
