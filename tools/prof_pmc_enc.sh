@@ -9,7 +9,7 @@ for d in ("a","b"):
     fs = glob.glob("$O/%s/*.db" % d)
     if not fs: print("no db", d); continue
     con = sqlite3.connect(fs[0]); cur = con.cursor()
-    for r in cur.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection where kernel_name like '%zmi_encode%' or kernel_name like '%zmi_lz77%' group by kernel_name, counter_name"):
+    for r in cur.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection where kernel_name like '%zmi_%' group by kernel_name, counter_name"):
         print(r[0].split('(')[0][:40], r[1], "%.4g" % r[2], r[3])
 PY
 tail -3 $O/b.log

@@ -572,10 +572,11 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                                                          uint32_t* __restrict__ check, int32_t* __restrict__ status,
                                                          uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ bm_off,
                                                          const uint32_t* __restrict__ out_hist,
-                                                         const uint32_t* __restrict__ in_bit, uint32_t* __restrict__ resume) {
+                                                         const uint32_t* __restrict__ in_bit, uint32_t* __restrict__ resume,
+                                                         const uint32_t* __restrict__ order) {
     InfShared* S = &g_inf_lds;
     const uint32_t lane = zmi_lane();
-    const uint32_t s = zmi_xcd_spread(blockIdx.x, gridDim.x);
+    const uint32_t s = order[blockIdx.x];   // longest streams first (zmi_inflate_order_kernel)
     InfBits B;
     B.src = in + in_off[s];
     B.n = in_len[s];
@@ -999,6 +1000,40 @@ __global__ void __launch_bounds__(256) zmi_inflate_clear_kernel(const uint32_t* 
     for (uint64_t i = threadIdx.x; i < w; i += 256u) bitmap[o + i] = 0ull;
 }
 
+// Workgroup -> stream, largest compressed size first.  A launch is a few rounds of streams per CU (16 384 streams on 256
+// CUs x 17), and a stream's decode time goes with its token count: a literal-dense 1 MiB stream alone on the chip takes
+// 50 ms, a launch of 16 384 mixed ones 110 -- dealt in arrival order, the launch ended with a few long streams running
+// on an empty chip.  Longest first is the classic remedy; the compressed size is the estimate that is free.  One
+// workgroup: bucket sort on the top 10 bits below the largest size (the order inside a bucket does not matter).
+__global__ void __launch_bounds__(1024) zmi_inflate_order_kernel(const uint32_t* __restrict__ in_len, uint32_t n, uint32_t* __restrict__ order) {
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t top;
+    const uint32_t t = threadIdx.x;
+    hist[t] = 0;
+    if (t == 0) top = 0;
+    __syncthreads();
+    uint32_t m = 0;
+    for (uint32_t i = t; i < n; i += 1024u) m = in_len[i] > m ? in_len[i] : m;
+    atomicMax(&top, m);
+    __syncthreads();
+    const uint32_t hi = top;
+    const uint32_t shift = hi >= 1024u ? 32u - (uint32_t)__clz(hi) - 10u : 0u;
+    for (uint32_t i = t; i < n; i += 1024u) atomicAdd(&hist[in_len[i] >> shift], 1u);
+    __syncthreads();
+    // start of bucket b in descending order = streams in the buckets above it: suffix sum by doubling
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t v = t + d < 1024u ? hist[t + d] : 0u;
+        __syncthreads();
+        hist[t] += v;
+        __syncthreads();
+    }
+    // hist[b] = streams in buckets >= b: bucket b ends there; fill it from its end downwards
+    for (uint32_t i = t; i < n; i += 1024u) {
+        const uint32_t b = in_len[i] >> shift;
+        order[atomicSub(&hist[b], 1u) - 1u] = i;
+    }
+}
+
 // ---- resolve pass: fill the back-reference holes of one stream, in order, inside an LDS ring ----
 // ring[x & RES_MASK] holds output byte x for x in [loaded - RES_RING, loaded).  Lines are staged from HBM
 // strictly in order (they carry the literals and the 3-byte records the decode pass left in the holes),
@@ -1103,12 +1138,13 @@ __global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, c
                                                                  const uint32_t* __restrict__ out_len,
                                                                  const uint64_t* __restrict__ bitmap,
                                                                  const uint64_t* __restrict__ bm_off,
-                                                                 const uint32_t* __restrict__ out_hist) {
+                                                                 const uint32_t* __restrict__ out_hist,
+                                                                 const uint32_t* __restrict__ order) {
     ZMI_DYN_SMEM(smem);
     uint8_t* ring = smem;
     ResChunk* C = (ResChunk*)(smem + RES_RING);
     const uint32_t lane = zmi_lane();
-    const uint32_t s = zmi_xcd_spread(blockIdx.x, gridDim.x);
+    const uint32_t s = order[blockIdx.x];   // the decode pass's order: longest streams first
     const uint64_t bmo = bm_off[s];
     const uint32_t n_real = out_len[s];
     if (bmo == ~0ull || n_real == 0u) return;
@@ -1320,23 +1356,25 @@ extern "C" int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off,
                                   uint32_t wrap, uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                                   uint32_t* d_out_len, uint32_t* d_in_used, uint32_t* d_check, int32_t* d_status,
                                   uint64_t* d_bitmap, uint64_t bitmap_words, uint64_t* d_bm_off, const uint32_t* d_out_hist,
-                                  const uint32_t* d_in_bit, uint32_t* d_resume, hipStream_t stream) {
+                                  const uint32_t* d_in_bit, uint32_t* d_resume, uint32_t* d_order, hipStream_t stream) {
     if (n_streams == 0) return 0;
+    ZMI_LAUNCH(zmi_inflate_order_kernel, dim3(1), dim3(1024), 0, stream, d_in_len, n_streams, d_order);
     ZMI_LAUNCH(zmi_inflate_plan_kernel, dim3(1), dim3(1024), 0, stream, d_out_cap, n_streams, bitmap_words, d_bm_off);
     ZMI_LAUNCH(zmi_inflate_clear_kernel, dim3(n_streams), dim3(256), 0, stream, d_out_cap, (const uint64_t*)d_bm_off, d_bitmap);
     if (d_resume)
         ZMI_LAUNCH(zmi_inflate_kernel<true>, dim3(n_streams), dim3(64), 0, stream, d_in, d_in_off, d_in_len, wrap, d_out, d_out_off,
-                   d_out_cap, d_out_len, d_in_used, d_check, d_status, d_bitmap, (const uint64_t*)d_bm_off, d_out_hist, d_in_bit, d_resume);
+                   d_out_cap, d_out_len, d_in_used, d_check, d_status, d_bitmap, (const uint64_t*)d_bm_off, d_out_hist, d_in_bit, d_resume,
+                   (const uint32_t*)d_order);
     else
         ZMI_LAUNCH(zmi_inflate_kernel<false>, dim3(n_streams), dim3(64), 0, stream, d_in, d_in_off, d_in_len, wrap, d_out, d_out_off,
                    d_out_cap, d_out_len, d_in_used, d_check, d_status, d_bitmap, (const uint64_t*)d_bm_off, d_out_hist,
-                   (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                   (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)d_order);
     return 0;
 }
 
 extern "C" int zmi_launch_inflate_resolve(uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_len, uint32_t n_streams,
                                           const uint64_t* d_bitmap, const uint64_t* d_bm_off, const uint32_t* d_out_hist,
-                                          hipStream_t stream) {
+                                          const uint32_t* d_order, hipStream_t stream) {
     if (n_streams == 0) return 0;
 #ifndef ZMI_EMU
     static bool attr_set = false;
@@ -1346,7 +1384,7 @@ extern "C" int zmi_launch_inflate_resolve(uint8_t* d_out, const uint64_t* d_out_
         attr_set = true;
     }
 #endif
-    ZMI_LAUNCH(zmi_inflate_resolve_kernel, dim3(n_streams), dim3(64), RES_RING + sizeof(ResChunk), stream, d_out, d_out_off, d_out_len, d_bitmap, d_bm_off, d_out_hist);
+    ZMI_LAUNCH(zmi_inflate_resolve_kernel, dim3(n_streams), dim3(64), RES_RING + sizeof(ResChunk), stream, d_out, d_out_off, d_out_len, d_bitmap, d_bm_off, d_out_hist, d_order);
     return 0;
 }
 

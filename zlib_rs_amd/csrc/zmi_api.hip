@@ -506,13 +506,14 @@ static int zmi_inflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     if (n == 0) return ZMI_E_OK;
     hipStream_t stream = (hipStream_t)stream_;
     ZMI_ON_DEVICE(c);
-    int rc = zmi_reserve(c->inf_tmp, (size_t)n * 24u);
+    int rc = zmi_reserve(c->inf_tmp, (size_t)n * 28u);
     if (rc) return rc;
     uint64_t* d_bm_off = (uint64_t*)c->inf_tmp.p;
     uint32_t* d_used = (uint32_t*)(d_bm_off + n);
     uint32_t* d_check = d_used + n;
     uint32_t* d_adler = d_check + n;
     uint32_t* d_crc = d_adler + n;
+    uint32_t* d_order = d_crc + n;   // workgroup -> stream: largest compressed size first (zmi_inflate_order_kernel)
     if (d_in_used) d_used = d_in_used;
     // bitmap scratch: 1 bit per byte of output capacity (+2 words per stream).  The capacities live on the
     // device, so the size comes from the context's limit; streams beyond it report Z_MEM_ERROR.
@@ -524,12 +525,12 @@ static int zmi_inflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
         zmi_scope_timer tm(c, ZMI_K_INFLATE, stream);
         int lrc = zmi_launch_inflate((const uint8_t*)d_in, d_in_off, d_in_len, n, (uint32_t)wrap, (uint8_t*)d_out, d_out_off, d_out_cap,
                                      d_out_len, d_used, d_check, d_status, (uint64_t*)c->inf_bm.p, bm_words, d_bm_off, d_out_hist, d_in_bit, d_resume,
-                                     stream);
+                                     d_order, stream);
         if (lrc) return zmi_fail(ZMI_E_HIP, "inflate launch setup", (hipError_t)lrc);
     }
     {
         zmi_scope_timer tm(c, ZMI_K_RESOLVE, stream);
-        int lrc = zmi_launch_inflate_resolve((uint8_t*)d_out, d_out_off, d_out_len, n, (const uint64_t*)c->inf_bm.p, d_bm_off, d_out_hist, stream);
+        int lrc = zmi_launch_inflate_resolve((uint8_t*)d_out, d_out_off, d_out_len, n, (const uint64_t*)c->inf_bm.p, d_bm_off, d_out_hist, d_order, stream);
         if (lrc) return zmi_fail(ZMI_E_HIP, "inflate resolve launch setup", (hipError_t)lrc);
     }
     if (wrap != ZMI_WRAP_RAW) {
