@@ -429,7 +429,8 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     if (const char* f5 = zmi_tune("ZMI_FAR5")) ep.far5 = (uint32_t)atoi(f5);
     ep.block_tokens = L.tok;
     ep.split_hdr_bits = 640u;
-    ep.min_sub_span = 5120u;   // literal-dense data: a sub-block of 4096 tokens is little more than 4 KiB of input, and a block of its own
+    ep.min_sub_span = L.tok >= 4096u ? 5120u : 0u;   // (levels 8 and 9 cut finer, 2048 tokens, and keep every block they can get)
+                               // literal-dense data: a sub-block of 4096 tokens is little more than 4 KiB of input, and a block of its own
                                // is a full tree construction; measured on the benchmark mix: 0 -> 103.3 ms encode at ratio 2.2635, 5120 ->
                                // 98.9 ms at 2.2567, 8192 -> 94.6 ms at 2.2440
     if (const char* ms = zmi_tune("ZMI_MIN_SUB_SPAN")) ep.min_sub_span = (uint32_t)atoi(ms);
