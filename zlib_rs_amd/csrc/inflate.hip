@@ -496,8 +496,9 @@ static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, co
 // One fast pass from bit P of the stream.  Returns the number of lanes committed (0: nothing done); *bits_used / *out_made
 // / *hit_eob describe what was committed.  All lanes call.
 static __device__ __forceinline__ uint32_t inf_fast_pass(InfShared* S, const uint8_t* src, uint64_t P, uint8_t* dst,
-                                                      uint32_t* bm32, uint32_t opos, uint32_t cap, uint32_t hist,
+                                                      uint32_t* bm32, uint32_t opos, uint32_t cap, uint32_t hist, uint32_t sub,
                                                       uint32_t* bits_used, uint32_t* out_made, uint32_t* hit_eob) {
+    // sub: bits per lane, 64 .. INF_SUB_BITS (wave-uniform; see the caller for how it is chosen)
     const uint32_t lane = zmi_lane();
     // stage the input: from the 16-byte line holding bit P, 4 KiB, four coalesced loads
     const uint32_t ib = (uint32_t)(P >> 3);
@@ -508,14 +509,16 @@ static __device__ __forceinline__ uint32_t inf_fast_pass(InfShared* S, const uin
     for (uint32_t k = 0; k < INF_FAST_BYTES / 1024u; ++k) *(uint4*)(S->fb + 16u * (lane + 64u * k)) = *(const uint4*)(line + 16u * (lane + 64u * k));
     zmi_wave_order();
     const uint32_t p_rel = (mis << 3) | ((uint32_t)P & 7u);
-    const uint32_t boundary = p_rel + (lane + 1u) * INF_SUB_BITS;
+    const uint32_t boundary = p_rel + (lane + 1u) * sub;
     // 1. sync.  A lane's first guess is not "my sub-sequence starts with a token" but the result of a short warm-up walk
     // through the tail of the sub-sequence below: after INF_WARM_BITS most walks are in step already, so the first full
     // walk is usually the right one and the restart round below has few (often no) lanes to fix.
-    uint32_t start = p_rel + lane * INF_SUB_BITS;
+    uint32_t start = p_rel + lane * sub;
     {
-        // (lane 0 rides along switched off: it must still hold a position inside the staged bytes, its reads happen)
-        const InfLane Wm = inf_lane_decode<false>(S, S->fb, lane != 0u ? start - INF_WARM_BITS : start, start, lane != 0u, nullptr, nullptr, 0u);
+        // (lane 0 rides along switched off: it must still hold a position inside the staged bytes, its reads happen; with
+        // short sub-sequences the lowest lanes warm up from the pass's own first bit, which is a true token start)
+        const uint32_t wfrom = start - p_rel > INF_WARM_BITS ? start - INF_WARM_BITS : p_rel;
+        const InfLane Wm = inf_lane_decode<false>(S, S->fb, wfrom, start, lane != 0u, nullptr, nullptr, 0u);
         if (lane != 0u && Wm.flags == 0u) start = Wm.exit;   // (a warm-up that ran into an invalid code or an end of block: keep the guess)
     }
     InfLane R = inf_lane_decode<false>(S, S->fb, start, boundary, true, nullptr, nullptr, 0u);
@@ -603,6 +606,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
     }
     uint32_t kind_found = wrap;  // resolved wrapper: 0 raw, 1 zlib, 2 gzip
     uint32_t fixed_ready = 0;
+    uint32_t last_blk_bits = 0;   // token bits of the block decoded last (0: none yet): sizes the fast passes of the next one
 
     // ---- wrapper header ----
     if (wrap == 3u) kind_found = (B.n >= 2u && inf_byte(B, 0) == 0x1Fu && inf_byte(B, 1) == 0x8Bu) ? 2u : 1u;
@@ -810,6 +814,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
         // and every lane on the chain stores its own token(s).
         {
             uint64_t P = 8ull * B.ipos - B.nbits;   // bit position of the next token
+            const uint64_t Pblk = P;                // ... and of the block's first one
             const uint64_t Pend = 8ull * B.n;
             const uint32_t* iw = (const uint32_t*)B.inbuf;
             bool eob = false;
@@ -818,8 +823,19 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                     // lane-serial fast pass while there are >= 4 KiB of input behind P (see inf_fast_pass); it commits only
                     // what is certain, everything unusual falls through to a token round below
                     if (Pend - P >= 8ull * (INF_FAST_BYTES + 32u)) {
+                        // Bits per lane.  A pass ends at the end of the block, and the lanes behind that point have worked
+                        // for nothing: streams of small blocks (drifting data: 4 KiB a block) spent every second pass
+                        // on a block's last few hundred bytes at the price of 3.5 KiB.  The block before is the estimate
+                        // of how much is left of this one; what is left is spread over all 64 lanes.
+                        uint32_t sub = INF_SUB_BITS;
+                        if (last_blk_bits != 0u) {
+                            const uint64_t done = P - Pblk;
+                            const uint32_t rest = done < (uint64_t)last_blk_bits ? last_blk_bits - (uint32_t)done : 0u;
+                            if (rest == 0u) sub = 256u;   // longer than the block before: feel the way forward
+                            else if (rest < 56u * INF_SUB_BITS) { sub = (rest + (rest >> 3) + 63u) >> 6; sub = sub < 64u ? 64u : (sub > INF_SUB_BITS ? INF_SUB_BITS : sub); }
+                        }
                         uint32_t fbits = 0, fout = 0, feob = 0;
-                        const uint32_t lanes = zmi_uniform(inf_fast_pass(S, B.src, P, dst, bm32, opos, cap, hist, &fbits, &fout, &feob));
+                        const uint32_t lanes = zmi_uniform(inf_fast_pass(S, B.src, P, dst, bm32, opos, cap, hist, sub, &fbits, &fout, &feob));
                         B.cbase = -(int32_t)(2u * INF_CHUNK);   // the pass staged its input over the token rounds' chunk
                         if (lanes != 0u) {
                             P += zmi_uniform(fbits);
@@ -909,6 +925,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                 P += pos;
                 if (rst != ZMI_OK) st = rst;
             }
+            if (eob) last_blk_bits = P - Pblk > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(P - Pblk);
             // hand the bit position back to the serial reader (block headers, stored blocks, trailer)
             B.ipos = (uint32_t)(P >> 3);
             B.hold = 0;
