@@ -54,7 +54,9 @@
 #define LZ_CTL 128u
 #define LZ_H4BITS 13
 #define LZ_H4SIZE (1u << LZ_H4BITS)
-#define LZ_C4RING 4096u   // positions; >= 4 tiles, the producer never runs further ahead of the oldest search
+#define LZ_C4RING 4096u   // positions: the tile being built ends at most this far past the oldest search (see `hold`)
+#define LZ_MAX_DIST (LZ_WSIZE - LZ_C4RING - LZ_T - 16u)   // 27 632: farthest back-reference; a producer's round keeps bytes
+                          // [0, (k + 2) * LZ_T + 16) resident while it builds tile k, which ends LZ_T + 16 below that
 #define LZ_SMEM (LZ_WSIZE + LZ_MIRROR + 2u * LZ_WSIZE + 2u * LZ_HSIZE + 2u * LZ_H4SIZE + 2u * LZ_C4RING + LZ_CTL)
 
 struct LzCtl {
@@ -273,13 +275,19 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
         uint32_t cpos = (wave + 1u) * LZ_T + 16u + lane * 16u;   // chunk that this wave's first round must make resident
         zmi_b16 cur = zmi_ld16(src + cpos, cpos < n ? n - cpos : 0u, aligned);
         uint32_t cached_min = 0u;
+        // How far the producers may run ahead of the oldest search: the window ring allows 32 KiB - max_dist, but the ring of
+        // probe answers (c4: LZ_C4RING positions) must not be overwritten before it is read either -- with a short max_dist
+        // (windowBits < 15, Z_RLE) the window alone would let tile q + 4096 be built while position q is still waiting.
+        // LZ_MAX_DIST is the distance at which both limits coincide: the tile being built ends at most LZ_C4RING positions
+        // past the oldest search.
+        const uint32_t hold = prm.max_dist > LZ_MAX_DIST ? prm.max_dist : LZ_MAX_DIST;
         for (uint32_t k = wave; k < ntiles; k += P) {
             const uint32_t npos = cpos + P * LZ_T;
             zmi_b16 nxt = zmi_ld16(src + npos, npos < n ? n - npos : 0u, aligned);  // for this wave's next tile
             const uint32_t E = (k + 2u) * LZ_T + 16u;  // bytes [0, E) must be resident after this round
             // ring throttle: byte E-1 lands on the slot of byte E-1-32768, which the oldest in-flight
             // search (position q) may still read while q - max_dist <= E-1-32768
-            while ((uint64_t)E + prm.max_dist > (uint64_t)cached_min + LZ_WSIZE) {
+            while ((uint64_t)E + hold > (uint64_t)cached_min + LZ_WSIZE) {
                 uint32_t v = 0xFFFFFFFFu;
                 if (lane < LZ_NW) v = lz_ld_acq(&ctl->wmin[lane]);
                 else if (lane == LZ_NW) v = lz_ld_acq(&ctl->next);
@@ -290,7 +298,7 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                     m = o < m ? o : m;
                 }
                 cached_min = m;
-                if ((uint64_t)E + prm.max_dist <= (uint64_t)m + LZ_WSIZE) break;
+                if ((uint64_t)E + hold <= (uint64_t)m + LZ_WSIZE) break;
                 lz_pause();
             }
             lz_store_chunk(win, cpos, cur);
@@ -447,8 +455,10 @@ extern "C" int zmi_launch_lz77(const uint8_t* d_data, const uint64_t* d_off, con
                                uint32_t n_shards, uint32_t* d_match, uint64_t match_stride, zmi_lz_params prm,
                                hipStream_t stream) {
     if (n_shards == 0) return 0;
-    // ring budget: 32 KiB = max_dist + 2 tiles of producer run-ahead + 2 tiles of slack for the searches in flight
-    if (prm.max_dist > LZ_WSIZE - 4u * LZ_T - 16u) prm.max_dist = LZ_WSIZE - 4u * LZ_T - 16u;
+    // ring budget: 32 KiB = max_dist + the tile being built + a tile of read-ahead + 3 tiles of slack for the searches in flight
+    // (one tile more than round 1: searchers spent a quarter of their time waiting for the producers, the producers 39 % of
+    // theirs waiting for the slowest search to release the ring -- 158.4 -> 148.9 ms for 1 KiB of reach, ratio -0.08 %)
+    if (prm.max_dist > LZ_MAX_DIST) prm.max_dist = LZ_MAX_DIST;
     if (prm.claim != 128u && prm.claim != 192u && prm.claim != 256u) prm.claim = 64u;
     // 152 KiB of LDS per workgroup, allocated statically in the product build (LZ_DYN: the emulator hands it out at launch)
 #ifdef ZMI_EMU

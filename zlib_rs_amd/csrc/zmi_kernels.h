@@ -14,7 +14,7 @@ struct zmi_lz_params {
     uint32_t max_chain;  // hash-chain links followed per position
     uint32_t nice_len;   // stop searching once a match this long is found
     uint32_t good_len;   // halve the remaining chain budget above this length
-    uint32_t max_dist;   // farthest back-reference (<= 32768 - 3*1024 - 16, ring-buffer constraint)
+    uint32_t max_dist;   // farthest back-reference (<= 32768 - 5*1024 - 16 = 27632, ring-buffer constraint: LZ_MAX_DIST in lz77.hip)
     uint32_t claim;      // positions a searcher wave claims at once (64, 128, 192 or 256)
     uint32_t hash6;      // 1: chain keyed by a 6-byte hash + one most-recent 4-byte probe; 0: 4-byte hash chain
     uint32_t producers;  // 1 or 2 hash-building waves per workgroup (2: the low levels, where one producer is the limit)
