@@ -13,7 +13,7 @@
  *              finishes (or 64 MiB are pending).  The input is compressed in 1 MiB segments, one
  *              workgroup each, that start byte aligned (the empty stored block of Z_SYNC_FLUSH,
  *              zlib-rs/src/deflate.rs:2733-2738) and keep the window: a segment matches into the
- *              28 KiB in front of it, like a preset dictionary (deflate.rs:499-564).  Across separate
+ *              27 KiB in front of it, like a preset dictionary (deflate.rs:499-564).  Across separate
  *              deflate() calls the last 32 KiB of input stay the window; only Z_FULL_FLUSH forgets them
  *              (deflate.rs:2739-2752).
  *   inflate()  decodes as far as the input it is given allows, so the output of a flushed packet is there when the call
