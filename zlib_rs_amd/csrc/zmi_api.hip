@@ -313,7 +313,7 @@ extern "C" int zmi_deflate_batch_dev(zmi_ctx* c, const void* d_in, const uint64_
 
 // The shards are consecutive segments of ONE raw deflate stream, contiguous in d_in (d_in_off[i+1] = d_in_off[i] +
 // d_in_len[i]).  Every segment starts byte aligned (the empty stored block of Z_SYNC_FLUSH,
-// zlib-rs/src/deflate.rs:2733-2738) and may match into the up to 28 KiB in front of it (window carry-over), so
+// zlib-rs/src/deflate.rs:2733-2738) and may match into the up to 27 KiB in front of it (window carry-over), so
 // splitting a stream costs no cold start; `finish` != 0 makes the last shard end the stream (BFINAL).
 extern "C" int zmi_deflate_chain_dev(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                      uint32_t n, uint32_t max_len, int level, int strategy, int finish, void* d_out,
