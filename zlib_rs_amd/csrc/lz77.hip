@@ -211,7 +211,7 @@ static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_
     else lz_build_tile_t<H6, false>(win, prev, head, head4, c4, tile, n, max_dist, ctl, producers);
 }
 
-template <bool H6>
+template <bool H6, bool DEEP>
 __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off,
                                                         const uint32_t* __restrict__ len, uint32_t first_shard,
                                                         uint32_t* __restrict__ match, uint64_t match_stride,
@@ -384,7 +384,8 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                 uint32_t cand = p - delta;
                 // a match this long ends the walk: nice_len, the end of the input -- and, for the short budgets, good_len
                 // (the reference quarters the remaining chain there, longest_match.rs:60-66: of a budget of 3 nothing is left)
-                const bool deep = prm.max_chain > 8u;
+                constexpr bool deep = DEEP;   // prm.max_chain > 8 (the launcher picks the instantiation): the short budgets never halve
+                                              // their chain, and the three instructions of that bookkeeping leave their loop
                 uint32_t stoplen = prm.nice_len < maxlen ? prm.nice_len : maxlen;
                 if (!deep && prm.good_len < stoplen) stoplen = prm.good_len;
                 const uint32_t goodlen = deep ? prm.good_len : 259u;
@@ -434,7 +435,7 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                     bdist = better ? p - cand : bdist;
                     if (better && l >= 16u) tail = lz_ring32(win, p + l - 3u);
                     // deep walks: a good match halves the remaining budget (goodlen = 259 for the short budgets: never)
-                    chain >>= (uint32_t)(better & (l >= goodlen));
+                    if (deep) chain >>= (uint32_t)(better & (l >= goodlen));
                     cand -= dn;
                     chain -= 1u;   // may wrap below zero after the halving: compared as signed
                     // (bitwise, not short-circuit: four compares and three ORs; as `||` the compiler built a branch per term)
@@ -466,12 +467,11 @@ extern "C" int zmi_launch_lz77(const uint8_t* d_data, const uint64_t* d_off, con
 #else
     const uint32_t LZ_DYN = 0u;
 #endif
-    if (prm.hash6) {
-        ZMI_LAUNCH(zmi_lz77_kernel_t<true>, dim3(n_shards), dim3(1024), LZ_DYN, stream, d_data, d_off, d_len, first_shard,
-                   d_match, match_stride, prm);
-    } else {
-        ZMI_LAUNCH(zmi_lz77_kernel_t<false>, dim3(n_shards), dim3(1024), LZ_DYN, stream, d_data, d_off, d_len, first_shard,
-                   d_match, match_stride, prm);
-    }
+    const bool deep = prm.max_chain > 8u;
+#define LZ_GO(H, D) ZMI_LAUNCH((zmi_lz77_kernel_t<H, D>), dim3(n_shards), dim3(1024), LZ_DYN, stream, d_data, d_off, d_len, first_shard, \
+                               d_match, match_stride, prm)
+    if (prm.hash6) { if (deep) LZ_GO(true, true); else LZ_GO(true, false); }
+    else { if (deep) LZ_GO(false, true); else LZ_GO(false, false); }
+#undef LZ_GO
     return 0;
 }
