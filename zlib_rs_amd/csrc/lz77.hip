@@ -65,13 +65,15 @@ struct LzCtl {
     uint32_t atok;   // two producers: the tile whose hash-head atomics may be issued next (keeps them in position order)
     uint32_t pad;
     uint32_t wmin[LZ_NW];  // per wave: lower bound of its oldest in-flight position
-    uint32_t stored[2];    // per producer wave: input bytes [.., stored) of its last chunk are in the ring
+    uint32_t stored[4];    // per producer wave: input bytes [.., stored) of its last chunk are in the ring
 };
 
 #ifdef ZMI_EMU
 static inline uint32_t lz_ld_acq(uint32_t* p) { return *p; }
 static inline void lz_st_rel(uint32_t* p, uint32_t v) { *p = v; }
 static inline void lz_pause() { emu::spin_yield(); }
+static inline void lz_pause_short() { emu::spin_yield(); }
+static inline void lz_st_relaxed(uint32_t* p, uint32_t v) { *p = v; }
 #else
 static __device__ __forceinline__ uint32_t lz_ld_acq(uint32_t* p) {
     return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -80,6 +82,10 @@ static __device__ __forceinline__ void lz_st_rel(uint32_t* p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 static __device__ __forceinline__ void lz_pause() { __builtin_amdgcn_s_sleep(4); }
+static __device__ __forceinline__ void lz_pause_short() { __builtin_amdgcn_s_sleep(1); }
+static __device__ __forceinline__ void lz_st_relaxed(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 #endif
 
 static __device__ __forceinline__ uint32_t lz_ring32(const uint8_t* win, uint32_t pos) {
@@ -163,9 +169,17 @@ static __device__ __forceinline__ void lz_build_tile_t(const uint8_t* win, uint1
         st[s] = h2 | (h42 << 16);
         if ((s & 7u) == 7u) zmi_sched_fence();   // eight steps' loads in flight at a time, not sixteen (registers)
     }
-    // two producers hash alternate tiles concurrently; the inserts themselves must happen in position order
+    // several producers hash different tiles concurrently; the inserts themselves must happen in position order.
+    // Everything between taking the token and passing it on is serial for the whole workgroup (1024 times per MiB): the
+    // hashes must be finished BEFORE the wait (left alone, the compiler sinks half of the arithmetic of the loop above
+    // below the spin loop to save registers: ~130 VALU instructions inside the critical section instead of ~50)
+#ifndef ZMI_EMU
+#pragma unroll
+    for (uint32_t s = 0; s < LZ_SUB; ++s) asm volatile("" : "+v"(st[s]));
+    asm volatile("" : "+v"(sibs));
+#endif
     if (producers > 1u) {
-        while (lz_ld_acq(&ctl->atok) != tile) lz_pause();
+        while (lz_ld_acq(&ctl->atok) != tile) lz_pause_short();
     }
     // table update: read the bucket's occupant, write this position.  The LDS runs a wave's instructions in order, so
     // the 64 reads of a step see the writes of the step before without any wait in between
@@ -183,7 +197,8 @@ static __device__ __forceinline__ void lz_build_tile_t(const uint8_t* win, uint1
         zmi_wave_order();  // steps are position-ordered
     }
     // once this store is visible the table updates above have been applied (in-order LDS)
-    if (producers > 1u && lane == 0) lz_st_rel(&ctl->atok, tile + 1u);
+    // (relaxed: the LDS runs a wave's instructions in order, so the token need not wait for the data of the reads above)
+    if (producers > 1u && lane == 0) lz_st_relaxed(&ctl->atok, tile + 1u);
     const bool near = tile * LZ_T < max_dist;   // only the first tiles of a shard can reach back before its start
 #pragma unroll
     for (uint32_t s = 0; s < LZ_SUB; ++s) {
@@ -254,11 +269,11 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
     if (ntiles == 0) return;
 
     for (uint32_t i = t; i < (LZ_HSIZE + LZ_H4SIZE) / 2u; i += 1024u) ((uint32_t*)head)[i] = 0u;   // head4 follows head
-    if (t == 0) { ctl->ready = 0u; ctl->next = hist; ctl->atok = 0u; ctl->stored[0] = 0u; ctl->stored[1] = 0u; }
+    if (t == 0) { ctl->ready = 0u; ctl->next = hist; ctl->atok = 0u; ctl->stored[0] = 0u; ctl->stored[1] = 0u; ctl->stored[2] = 0u; ctl->stored[3] = 0u; }
     if (t < LZ_NW) ctl->wmin[t] = 0xFFFFFFFFu;
     __syncthreads();
 
-    const uint32_t P = prm.producers > 1u ? 2u : 1u;
+    const uint32_t P = prm.producers < 1u ? 1u : (prm.producers > 4u ? 4u : prm.producers);
     if (wave < P) {
         // ---------------- producer(s) ----------------
         // Tile k is built by producer wave k mod P.  With P = 2 (the low levels, where the searchers outrun a single
@@ -306,7 +321,7 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
             if (P > 1u) {
                 if (lane == 0) lz_st_rel(&ctl->stored[wave], E);
                 // hashing tile k reads bytes up to (k+1)*T + 7: the chunk the other wave stored in its round k-1
-                if (k > 0u) while (lz_ld_acq(&ctl->stored[wave ^ 1u]) < (k + 1u) * LZ_T + 16u) lz_pause();
+                if (k > 0u) while (lz_ld_acq(&ctl->stored[(wave + P - 1u) % P]) < (k + 1u) * LZ_T + 16u) lz_pause();
             }
             lz_build_tile<H6>(win, prev, head, head4, c4, k, n, prm.max_dist, ctl, P);
             zmi_wave_sync();
@@ -338,6 +353,13 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
         }
         base0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)base0);
         if (base0 >= n) break;
+        if (prm.dbg == 1u) {   // measurement aid (ZMI_LZ_DBG=1 under ZMI_TUNING): the producers' pace alone -- the searchers claim, read
+                               // one byte and store a literal (profiles/r03_lz77_experiments.txt)
+            const uint32_t need = base0 + 64u < n ? base0 + 64u : n;
+            while (lz_ld_acq(&ctl->ready) < need) lz_pause();
+            if (base0 + lane < n) mout[base0 + lane] = win[(base0 + lane) & LZ_WMASK];
+            continue;
+        }
       for (uint32_t half = 0; half * 64u < prm.claim; ++half) {
         const uint32_t base = base0 + half * 64u;
         if (base >= n) break;

@@ -416,9 +416,14 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     lp.carry = chain_mode != 0u ? 1u : 0u;   // segments of one stream: a segment sees the window in front of it
     lp.dict_len = chain_mode != 0u ? dict_len : 0u;
     if (const char* cv = zmi_tune("ZMI_CARRY")) lp.carry = (chain_mode != 0u && atoi(cv)) ? 1u : 0u;
-    lp.producers = L.chain <= 8u ? 2u : 1u;   // short chains: 14 searcher waves outrun one producer wave (measured at budget 5:
-                                              // 227 ms with two producers, 273 ms with one)
-    if (const char* pv = zmi_tune("ZMI_PRODUCERS")) lp.producers = atoi(pv) > 1 ? 2u : 1u;
+    // hash-building waves: 1 for the deep chains (the searchers are the whole kernel there), 2 for the short ones (14 searcher
+    // waves outrun one producer: budget 5 measured 227 ms with two, 273 ms with one), 3 at level 1, whose searchers do so
+    // little per position that even two producers set the pace (97.1 -> 95.2 ms per 16 Ki shards; at level 3 a third
+    // producer already costs more as a missing searcher than it brings: 114.2 -> 120.5 ms)
+    lp.producers = L.chain > 8u ? 1u : (level == 1 ? 3u : 2u);
+    if (const char* pv = zmi_tune("ZMI_PRODUCERS")) lp.producers = (uint32_t)atoi(pv);
+    lp.dbg = 0u;
+    if (const char* dv = zmi_tune("ZMI_LZ_DBG")) lp.dbg = (uint32_t)atoi(dv);
     // short far matches are judged by the encoder, block by block, from the codes it just used (enc_far_limits); the
     // search reports every match of 4+ bytes
     lp.far4 = 32768u;

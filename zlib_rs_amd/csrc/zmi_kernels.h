@@ -17,7 +17,8 @@ struct zmi_lz_params {
     uint32_t max_dist;   // farthest back-reference (<= 32768 - 5*1024 - 16 = 27632, ring-buffer constraint: LZ_MAX_DIST in lz77.hip)
     uint32_t claim;      // positions a searcher wave claims at once (64, 128, 192 or 256)
     uint32_t hash6;      // 1: chain keyed by a 6-byte hash + one most-recent 4-byte probe; 0: 4-byte hash chain
-    uint32_t producers;  // 1 or 2 hash-building waves per workgroup (2: the low levels, where one producer is the limit)
+    uint32_t producers;  // 1..4 hash-building waves per workgroup (tile k is built by wave k mod producers)
+    uint32_t dbg;        // measurement aids, 0 in the product (1: producers' pace alone, see lz77.hip)
     uint32_t carry;      // 1: the shards are consecutive segments of one stream; a segment may match into the up to 27 KiB
                          // in front of it (window carry-over, what a preset dictionary is in deflate.rs:499-564)
     uint32_t dict_len;   // carry only: bytes in front of shard 0 that are history too (preset dictionary / earlier input)
