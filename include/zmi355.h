@@ -130,7 +130,12 @@ int zmi_inflate_batch_dict_dev(zmi_ctx* ctx, const void* d_in, const uint64_t* d
  * {byte, bit, output bytes, complete}: the start of the block the decode stopped in (status Z_BUF_ERROR, d_detail
  * 1 = more input / 2 = more room needed), or the first bit behind the final block (complete = 1, status Z_OK).
  * d_out_len[i] counts everything decoded including the valid part of the unfinished block; a later call that
- * starts at the checkpoint, with the output in front of it as history, reproduces those bytes and continues. */
+ * starts at the checkpoint, with the output in front of it as history, reproduces those bytes and continues.
+ * Stops on request (what inflate(Z_BLOCK) / inflate(Z_TREES) are built on, zlib-rs/src/inflate.rs:1276-1284,1323,1369,
+ * 1772): bits 8..23 of d_in_bit[i] = stop at the block boundary behind that many complete blocks (0: none), bit 24 = stop
+ * behind the header of the first block (code tables read, none of its data decoded).  Both report status Z_BUF_ERROR
+ * with d_detail 3; a boundary stop leaves the usual checkpoint, a header stop leaves {byte, bit of the first bit behind
+ * the header, output bytes, 2 | BFINAL << 2} in d_resume. */
 int zmi_inflate_resume_dev(zmi_ctx* ctx, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                            const uint32_t* d_in_bit, uint32_t n_streams, void* d_out, const uint64_t* d_out_off,
                            const uint32_t* d_out_cap, const uint32_t* d_out_hist, uint32_t* d_out_len,

@@ -74,6 +74,15 @@ def test_streaming_entry_points():
     H.streaming_checks(lib, o.gen_shard(0, 40000) + o.gen_shard(3, 30000), syslib=C.CDLL("libz.so.1"))
 
 
+def test_inflate_block_and_trees_stops():
+    """inflate(Z_BLOCK) / inflate(Z_TREES): every call's return code, input left, output and data_type equal the system
+    zlib's (the reference's own tests: test-libz-rs-sys/src/inflate.rs:640-676, :2036-2078)"""
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    o = oracle_lib.load()
+    assert H.block_stop_checks(lib, C.CDLL("libz.so.1"), o.gen_shard(0, 40000) + o.gen_shard(3, 30000)) > 50
+
+
 def test_gz_file_api(tmp_path):
     """gzopen ... gzclose against Python's gzip module and the system's libz (libz-rs-sys/src/gz.rs)"""
     zmi_ctypes.load_emu()

@@ -69,6 +69,15 @@ def test_streaming_entry_points_on_gpu():
     H.streaming_checks(lib, o.gen_shard(0, 400000) + o.gen_shard(3, 300000), syslib=C.CDLL("libz.so.1"))
 
 
+def test_inflate_block_and_trees_stops_on_gpu():
+    """inflate(Z_BLOCK) / inflate(Z_TREES) on the device decode's block and header stops: call by call the system zlib's
+    return code, input left, output and data_type"""
+    from zlib_rs_amd import _build
+    lib = H.bind(C.CDLL(_build.ABI_LIB))
+    o = oracle_lib.load(rebuild=False)
+    assert H.block_stop_checks(lib, C.CDLL("libz.so.1"), o.gen_shard(0, 400000) + o.gen_shard(3, 300000)) > 50
+
+
 def test_streaming_inflate_large_in_small_chunks_on_gpu():
     """24 MiB through inflate() in 64 KiB pieces with a 256 KiB output buffer (the zpipe.c loop): bit-exact, and the
     host state stays small -- the decode restarts at block checkpoints instead of buffering the stream"""

@@ -1301,3 +1301,66 @@ def handback_checks(lib, o, tmpdir, size=150000):
         fh.write(gzip.compress(second, 6))
     assert _gz_read_all(lib, path, chunk=1000) == bytes(size) + data + second
     assert _gz_read_all(lib, path, chunk=1 << 20) == bytes(size) + data + second
+
+
+def block_stop_checks(lib, syslib, data):
+    """inflate(Z_BLOCK) / inflate(Z_TREES): the calls of the reference's tests (test-libz-rs-sys/src/inflate.rs:640-676 runs every
+    stream through a Z_TREES loop, :2036-2078 logs avail_in / avail_out / data_type after every Z_BLOCK call and compares the
+    log with zlib-ng's).  Here the same log is compared with the system zlib's, call by call: return code, input left,
+    output produced and data_type (unused bits | 64 last block | 128 at a block boundary | 256 behind a block header,
+    zlib-rs/src/inflate.rs:1856-1873)."""
+    import zlib
+    Z_BLOCK, Z_TREES = 5, 6
+    bind(syslib)
+    streams = []
+    for level, wbits in ((6, 15), (1, 31), (9, -15), (0, 15), (6, -15)):
+        co = zlib.compressobj(level, zlib.DEFLATED, wbits)
+        streams.append((wbits, co.compress(data[:30000]) + co.flush(zlib.Z_SYNC_FLUSH) + co.compress(data[30000:]) + co.flush()))
+    co = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+    streams.append((-15, co.compress(data[:5000]) + co.flush()))
+    own = deflate_stream(lib, data, level=6, wbits=15)            # this library's own stream: many blocks, byte-aligned pieces
+    streams.append((15, own))
+    streams.append((15, zlib.compress(b"")))
+    n_calls = 0
+    for wbits, comp in streams:
+        for flush in (Z_BLOCK, Z_TREES):
+            logs = []
+            for L in (syslib, lib):
+                strm = ZStream()
+                assert L.inflateInit2_(C.byref(strm), wbits, L.zlibVersion(), C.sizeof(ZStream)) == Z_OK
+                src = C.create_string_buffer(comp + b"TAIL", len(comp) + 4)
+                out = C.create_string_buffer(len(data) + 1024)
+                strm.next_in, strm.avail_in = C.addressof(src), len(comp) + 4
+                got = bytearray()
+                log = []
+                for _ in range(100000):
+                    strm.next_out, strm.avail_out = C.addressof(out), len(out)
+                    rc = L.inflate(C.byref(strm), flush)
+                    got += out.raw[:len(out) - strm.avail_out]
+                    log.append((rc, strm.avail_in, len(out) - strm.avail_out, strm.data_type))
+                    # (a call that only moves from one stop to the next without input or output is Z_BUF_ERROR: not fatal)
+                    if rc not in (Z_OK, Z_BUF_ERROR) or (rc == Z_BUF_ERROR and len(log) > 1 and log[-2][0] == Z_BUF_ERROR):
+                        break
+                assert rc == Z_STREAM_END and bytes(got) == data[:len(got)] and strm.avail_in == 4, (wbits, flush, rc, strm.avail_in)
+                assert L.inflateEnd(C.byref(strm)) == Z_OK
+                logs.append(log)
+            assert logs[0] == logs[1], (wbits, flush, [(i, a, b) for i, (a, b) in enumerate(zip(*logs)) if a != b][:3], len(logs[0]), len(logs[1]))
+            n_calls += len(logs[0])
+    # a small output buffer: the stop is reported by the call that hands out the block's last byte
+    wbits, comp = streams[0]
+    strm = ZStream()
+    assert lib.inflateInit2_(C.byref(strm), wbits, lib.zlibVersion(), C.sizeof(ZStream)) == Z_OK
+    src = C.create_string_buffer(comp, len(comp))
+    out = C.create_string_buffer(777)
+    strm.next_in, strm.avail_in = C.addressof(src), len(comp)
+    got, stops = bytearray(), 0
+    for _ in range(100000):
+        strm.next_out, strm.avail_out = C.addressof(out), len(out)
+        rc = lib.inflate(C.byref(strm), Z_BLOCK)
+        got += out.raw[:len(out) - strm.avail_out]
+        stops += (strm.data_type & 128) != 0
+        if rc not in (Z_OK, Z_BUF_ERROR):
+            break
+    assert rc == Z_STREAM_END and bytes(got) == data and stops >= 3, (rc, len(got), stops)
+    assert lib.inflateEnd(C.byref(strm)) == Z_OK
+    return n_calls

@@ -39,6 +39,7 @@
 #define ZMI_TRAILER_SHORT (-1005)     // gzip: CRC present, ISIZE cut off   -> data error if CRC wrong, else buf error
 #define ZMI_LENGTH_MISMATCH (-1003)   // gzip: ISIZE wrong                  -> data error either way
 #define ZMI_NEED_OUTPUT (-1006)       // output capacity exhausted          -> Z_BUF_ERROR (detail 2)
+#define ZMI_BLOCK_STOP (-1007)        // resumable decode: stopped where the caller asked (in_bit flags) -> Z_BUF_ERROR (detail 3)
 // data errors by cause: -3000 - k, reported as Z_DATA_ERROR with detail 16 + k (k indexes the reference's messages,
 // zlib-rs/src/inflate.rs: the strings passed to State::bad); plain ZMI_DATA_ERROR stays "cause not recorded"
 #define ZMI_DERR(k) (-3000 - (int32_t)(k))
@@ -646,8 +647,17 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
         }
     }
 
+    // RESUME, what inflate(Z_BLOCK) / inflate(Z_TREES) need (zlib-rs/src/inflate.rs:1276-1284,1323,1369,1772): in_bit[s] bits
+    // 8..23 = stop at the boundary behind that many complete blocks (0: no limit), bit 24 = stop behind the header of the
+    // first block (its tables are built, nothing of its data is decoded): resume = {byte, bit of the first bit behind the
+    // header, output position, 2 | last-block flag << 2}, status ZMI_BLOCK_STOP either way
+    uint32_t max_blocks = 0, blocks_done = 0;
+    bool hdr_stop = false;
     if (RESUME) {
-        const uint32_t sb = in_bit ? (in_bit[s] & 7u) : 0u;
+        const uint32_t ibw = in_bit ? in_bit[s] : 0u;
+        const uint32_t sb = ibw & 7u;
+        max_blocks = (ibw >> 8) & 0xFFFFu;
+        hdr_stop = ((ibw >> 24) & 1u) != 0u;
         if (lane == 0) { S->rs[0] = 0; S->rs[1] = sb; S->rs[2] = 0; S->rs[3] = 0; }
         if (sb) {
             inf_refill(B);
@@ -664,6 +674,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             const uint64_t at = 8ull * B.ipos - B.nbits;
             S->rs[0] = (uint32_t)(at >> 3); S->rs[1] = (uint32_t)at & 7u; S->rs[2] = opos;
         }
+        if (RESUME && max_blocks != 0u && blocks_done >= max_blocks) { st = ZMI_BLOCK_STOP; break; }
         if (B.nbits < 3u) { st = ZMI_BUF_ERROR; break; }
         last = inf_peek(B, 1);
         uint32_t type = (inf_peek(B, 3) >> 1);
@@ -679,11 +690,17 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             uint32_t nl = inf_byte(B, B.ipos + 2u) | ((uint32_t)inf_byte(B, B.ipos + 3u) << 8);
             B.ipos += 4u;
             if ((l ^ 0xFFFFu) != nl) { st = ZMI_DERR(DE_STORED_LEN); break; }   // "invalid stored block lengths"
+            if (RESUME && hdr_stop) {
+                if (lane == 0) { S->rs[0] = B.ipos; S->rs[1] = 0u; S->rs[2] = opos; S->rs[3] = 2u | (last << 2); }
+                st = ZMI_BLOCK_STOP;
+                break;
+            }
             if (B.ipos + l > B.n) { st = ZMI_BUF_ERROR; break; }
             if (opos + l > cap) { st = ZMI_NEED_OUTPUT; break; }
             for (uint32_t i = lane; i < l; i += 64u) dst[opos + i] = B.src[B.ipos + i];
             opos += l;
             B.ipos += l;
+            ++blocks_done;
             continue;
         }
         if (type == 3u) { st = ZMI_DERR(DE_BLOCK_TYPE); break; }  // "invalid block type"
@@ -806,6 +823,14 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             if (zmi_uniform(inf_build(S, 2u, ndist, S->dtab, INF_DROOT, INF_DSIZE))) { st = ZMI_DERR(DE_DIST_SET); break; }  // "invalid distances set"
         }
 
+        if (RESUME && hdr_stop) {   // behind the block type bits (fixed codes) or the transmitted code lengths (dynamic)
+            if (lane == 0) {
+                const uint64_t at = 8ull * B.ipos - B.nbits;
+                S->rs[0] = (uint32_t)(at >> 3); S->rs[1] = (uint32_t)at & 7u; S->rs[2] = opos; S->rs[3] = 2u | (last << 2);
+            }
+            st = ZMI_BLOCK_STOP;
+            break;
+        }
         // ---- symbol rounds ----
         // Lane i decodes, speculatively, the complete tokens (literal, end-of-block, or length + distance with
         // their extra bits: at most 48 bits) that would start at bits P + i and P + 64 + i: two windows per round,
@@ -925,7 +950,7 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                 P += pos;
                 if (rst != ZMI_OK) st = rst;
             }
-            if (eob) last_blk_bits = P - Pblk > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(P - Pblk);
+            if (eob) { last_blk_bits = P - Pblk > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(P - Pblk); ++blocks_done; }
             // hand the bit position back to the serial reader (block headers, stored blocks, trailer)
             B.ipos = (uint32_t)(P >> 3);
             B.hold = 0;
@@ -1355,6 +1380,7 @@ __global__ void __launch_bounds__(256) zmi_inflate_verify_kernel(const uint8_t* 
     int32_t st = status[s];
     int32_t det = 0;
     if (st == ZMI_NEED_OUTPUT) { st = ZMI_BUF_ERROR; det = 2; }
+    else if (st == ZMI_BLOCK_STOP) { st = ZMI_BUF_ERROR; det = 3; }
     else if (st <= ZMI_DERR(1)) { det = 16 + (-3000 - st); st = ZMI_DATA_ERROR; }   // the cause travels in detail
     else if (st == ZMI_BUF_ERROR) det = 1;
     else if (st == ZMI_OK || st == ZMI_TRAILER_SHORT || st == ZMI_LENGTH_MISMATCH) {

@@ -47,7 +47,10 @@
 // 1.5 chain steps (lcet10.txt, budget 4: 2.791 -> 2.827; budget 3 then equals the old budget 4).  The price: no 16-bit
 // LDS atomics, so an insert is a plain read + write; the 64 positions of one step that fall into the same bucket all
 // see the bucket's previous occupant (they lose each other as predecessors -- only distances below 64 are affected, a
-// few bits per match) and one of them becomes the new head.
+// few bits per match) and the HIGHEST lane -- the most recent position -- becomes the new head: gfx950 applies the lanes
+// of one ds_write_b16 to the same address in lane order (tools/lds_winner.hip, profiles/r03_lds_winner.txt: contiguous and
+// strided groups of 2..64 lanes, always the highest lane's value stays), which is also what the CPU emulator of the tests
+// does, so the compressed bytes are defined by the algorithm, not by the schedule.
 #define LZ_HBITS 14
 #define LZ_HSIZE (1u << LZ_HBITS)
 #define LZ_MIRROR 32u

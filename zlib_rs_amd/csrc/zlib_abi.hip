@@ -188,9 +188,14 @@ struct AbiLease {
 bool abi_device_present() { AbiLease l; return l.ctx != nullptr; }
 // The HIP runtime multiplexes a process's streams onto 4 hardware queues unless told otherwise (GPU_MAX_HW_QUEUES): with
 // the default, four concurrent zlib streams is where the scaling stopped (measured: 1.9x at 2 threads, 3.3x at 4 and at
-// 8).  Ask for 16 when the library is loaded -- only if the host has not decided, and it only takes effect when the
-// runtime has not been initialised yet by someone else.
-__attribute__((constructor)) void abi_ask_for_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// 8; with 16 queues 6.4x at 8 and 11.2x at 16 threads).  A drop-in libz does not edit its host's environment on its own:
+// an application that drives many streams from many threads exports GPU_MAX_HW_QUEUES=16 itself, or
+// asks this library to with ZMI_HW_QUEUES=<n> -- acted on once, at load, only if GPU_MAX_HW_QUEUES is not set, and it
+// only takes effect when the HIP runtime has not been initialised yet.
+__attribute__((constructor)) void abi_hw_queues_on_request() {
+    const char* want = getenv("ZMI_HW_QUEUES");
+    if (want && atoi(want) > 0) (void)setenv("GPU_MAX_HW_QUEUES", want, 0);
+}
 // Device buffers of one call.  They come from a small pool that outlives the call: hipMalloc / hipFree cost far more than
 // the kernels of a small compress2() (hipFree also waits for the device), and a caller that compresses many small buffers
 // repeats the same sizes.  The pool is touched under g_mu for the moment of taking / returning a buffer; buffers above kPoolKeep are
@@ -198,7 +203,10 @@ __attribute__((constructor)) void abi_ask_for_hw_queues() { (void)setenv("GPU_MA
 struct PoolSlot { void* p = nullptr; size_t cap = 0; };   // a parked (idle) device buffer
 constexpr int kPoolSlots = 192;
 constexpr size_t kPoolKeep = (size_t)256 << 20;
+constexpr size_t kPoolBudget = (size_t)2 << 30;   // parked bytes in total: a process that merely links this libz never sits on
+                                                  // more idle HBM than this, whatever sizes it has compressed in its life
 PoolSlot g_pool[kPoolSlots];
+size_t g_pool_bytes = 0;
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -210,6 +218,8 @@ struct DevBuf {
     ~DevBuf() {
         if (!p) return;
         void* drop = p;
+        void* evicted[kPoolSlots];
+        int n_evicted = 0;
         if (cap <= kPoolKeep) {
             std::lock_guard<std::mutex> lk(g_mu);
             int at = -1;
@@ -218,9 +228,26 @@ struct DevBuf {
             if (at < 0)                                   // pool full: the smallest parked buffer makes room if this one is larger
                 for (int i = 0; i < kPoolSlots; ++i)
                     if (g_pool[i].cap < cap && (at < 0 || g_pool[i].cap < g_pool[at].cap)) at = i;
-            if (at >= 0) { drop = g_pool[at].p; g_pool[at].p = p; g_pool[at].cap = cap; }
+            if (at >= 0) {
+                drop = g_pool[at].p;
+                g_pool_bytes -= g_pool[at].p ? g_pool[at].cap : 0;
+                g_pool[at].p = p; g_pool[at].cap = cap;
+                g_pool_bytes += cap;
+                // over the byte budget: the largest parked buffers go back to the driver (never the one just parked --
+                // the next call most likely wants exactly that size again)
+                while (g_pool_bytes > kPoolBudget) {
+                    int big = -1;
+                    for (int i = 0; i < kPoolSlots; ++i)
+                        if (i != at && g_pool[i].p && (big < 0 || g_pool[i].cap > g_pool[big].cap)) big = i;
+                    if (big < 0) break;
+                    evicted[n_evicted++] = g_pool[big].p;
+                    g_pool_bytes -= g_pool[big].cap;
+                    g_pool[big].p = nullptr; g_pool[big].cap = 0;
+                }
+            }
         }
         if (drop) (void)hipFree(drop);
+        for (int i = 0; i < n_evicted; ++i) (void)hipFree(evicted[i]);
     }
     bool alloc(size_t n) {
         if (n == 0) n = 16;
@@ -229,7 +256,7 @@ struct DevBuf {
             int fit = -1;
             for (int i = 0; i < kPoolSlots; ++i)           // smallest parked buffer that is large enough
                 if (g_pool[i].p && g_pool[i].cap >= n && (fit < 0 || g_pool[i].cap < g_pool[fit].cap)) fit = i;
-            if (fit >= 0) { p = g_pool[fit].p; cap = g_pool[fit].cap; g_pool[fit].p = nullptr; g_pool[fit].cap = 0; return true; }
+            if (fit >= 0) { p = g_pool[fit].p; cap = g_pool[fit].cap; g_pool_bytes -= cap; g_pool[fit].p = nullptr; g_pool[fit].cap = 0; return true; }
         }
         const size_t want = n + n / 4 + 256;               // some room for the next, slightly larger, call
         if (hipMalloc(&p, want) == hipSuccess) { cap = want; return true; }
@@ -289,7 +316,7 @@ int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_
     // (the reference's bound for a finished stream) does not cover for very short incompressible segments (11 bytes: 13 bytes
     // of fixed-Huffman block + marker = 17 > bound 16)
     const uint64_t stride = zmi_deflate_bound(max_len, ZMI_WRAP_RAW) + 16u;
-    DevBuf d_in, d_off, d_len, d_out, d_olen, d_st, d_slab, d_soff;
+    DevBuf d_in, d_off, d_len, d_out, d_olen, d_st, d_slab, d_soff, d_sum;   // (all in front of the Sync guard: destroyed after it)
     if (!d_in.alloc(base + n + 16) || !d_off.alloc(nseg * 8) || !d_len.alloc(nseg * 4) || !d_out.alloc((size_t)nseg * stride) ||
         !d_olen.alloc(nseg * 4) || !d_st.alloc(nseg * 4) || !d_slab.alloc((size_t)nseg * stride) || !d_soff.alloc(((size_t)nseg + 1) * 8))
         return Z_MEM_ERROR;
@@ -303,7 +330,6 @@ int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_
                                      finish ? 1 : 0, (uint32_t)hist_len, (uint32_t)wbits, d_out.p, stride, (uint32_t*)d_olen.p,
                                      (int32_t*)d_st.p, hs) != 0)
         return Z_MEM_ERROR;
-    DevBuf d_sum;
     if (check && wrap != 0) {
         if (!d_sum.alloc((size_t)nseg * 8)) return Z_MEM_ERROR;
         if (zmi_checksum_batch_dev(c, d_in.p, (const uint64_t*)d_off.p, (const uint32_t*)d_len.p, nseg, wrap == 1 ? 1 : 2,
@@ -443,6 +469,13 @@ struct InflateState {
     uint32_t primed = 0;           // bits at the front of `in` that came from inflatePrime
     std::vector<uint8_t> dict;     // the preset dictionary (inflateGetDictionary shows it in front of the output)
     uint8_t* back_window = nullptr;   // inflateBack: the caller's window
+    // inflate(Z_BLOCK) / inflate(Z_TREES) (inflate.rs:1276-1284,1323,1369,1772,1856-1873): the device decode stops at the
+    // next block boundary / behind the next block header; the call that reaches the stop reports it in data_type
+    int stop_state = 0;            // 0 none, 1 at a block boundary (the reference's Mode::Type), 2 behind a block header (Len_ / CopyBlock)
+    bool stop_reported = false;    // a call has returned with the stop in data_type: the next one moves on
+    bool hdr_seen = false;         // Z_TREES: the header of the block at the checkpoint has been reported
+    uint32_t stop_bits = 0;        // unused bits of the last byte consumed at the stop
+    bool hdr_last = false;         // the block whose header was reported is the final one
 };
 
 // length of the gzip header at the start of `in` (inflate.rs:1063-1275): 0 while it is incomplete, -1 with *err
@@ -652,7 +685,7 @@ size_t take_limit() { return abi_limit("ZMI_ABI_TAKE", (size_t)256 << 20); }
 
 // Decode what is buffered, from the checkpoint.  Queues every new byte, moves the checkpoint to the last block
 // boundary reached, and changes the mode when the final block ended or the data is invalid.
-int inflate_attempt(InflateState* s) {
+int inflate_attempt(InflateState* s, int stop_mode = 0) {   // stop_mode 1: decode one block, 2: only the next block header
     AbiLease lease;
     zmi_ctx* c = lease.ctx;
     if (!c) return Z_MEM_ERROR;
@@ -664,11 +697,22 @@ int inflate_attempt(InflateState* s) {
         if (s->tmp.size() < cap) s->tmp.resize(cap);
         uint32_t olen = 0, used = 0, res[4] = {0, 0, 0, 0};
         int32_t st = 0, det = 0;
-        if (zmi_inflate_resume(c, s->in.data(), (uint32_t)take, s->sbit, s->hist.data(), (uint32_t)s->hist.size(), s->tmp.data(),
+        const uint32_t in_bit = s->sbit | (stop_mode == 1 ? (1u << 8) : 0u) | (stop_mode == 2 ? (1u << 24) : 0u);
+        if (zmi_inflate_resume(c, s->in.data(), (uint32_t)take, in_bit, s->hist.data(), (uint32_t)s->hist.size(), s->tmp.data(),
                                (uint32_t)cap, &olen, &st, &det, &used, res) != 0)
             return Z_MEM_ERROR;
         if (st == Z_MEM_ERROR) return Z_MEM_ERROR;
         const size_t eff = olen < cap ? olen : cap;
+        if (st == Z_BUF_ERROR && det == 3 && (res[3] & 2u)) {   // behind the block header: nothing decoded, the checkpoint stays
+            s->hdr_seen = true;
+            s->hdr_last = ((res[3] >> 2) & 1u) != 0u;
+            s->stop_state = 2;
+            s->stop_reported = false;
+            s->stop_bits = res[1] ? 8u - res[1] : 0u;
+            s->stop = (size_t)res[0] + (res[1] ? 1u : 0u);   // bytes of `in` the reference has consumed by now
+            s->tried = (size_t)-1;
+            return Z_OK;
+        }
         if (st == Z_BUF_ERROR && det == 2 && res[2] == 0) {   // one block that is larger than the room: more room
             if (cap >= 0xE0000000ull) return Z_MEM_ERROR;
             cap *= 2;
@@ -679,6 +723,7 @@ int inflate_attempt(InflateState* s) {
             s->total += eff - s->pend;
         }
         if (st == Z_OK) {   // the final block ended `used` bytes in
+            if (stop_mode) { s->stop_state = 1; s->stop_reported = false; s->stop_bits = res[1] ? 8u - res[1] : 0u; s->hdr_seen = false; }
             s->in.erase(s->in.begin(), s->in.begin() + (used < s->in.size() ? used : s->in.size()));
             s->sbit = 0;
             s->primed = 0;
@@ -710,6 +755,12 @@ int inflate_attempt(InflateState* s) {
         s->sbit = res[1];
         s->stop = used > res[0] ? used - res[0] : 0;
         if (take > res[0]) take -= res[0]; else take = 0;
+        if (det == 3) {   // the block boundary the caller asked for
+            s->stop_state = 1; s->stop_reported = false; s->stop_bits = s->sbit ? 8u - s->sbit : 0u; s->hdr_seen = false;
+            s->stop = s->sbit ? 1u : 0u;
+            s->tried = (size_t)-1;
+            return Z_OK;
+        }
         const bool more_buffered = take < s->in.size();
         if (det == 2 || more_buffered) {
             if (s->out.size() - s->out_pos > kQueueLimit) { s->tried = (size_t)-1; return Z_OK; }   // let the caller drain first
@@ -728,7 +779,7 @@ int inflate_attempt(InflateState* s) {
 }
 
 // header / blocks / trailer.  Returns Z_OK, Z_NEED_DICT or Z_MEM_ERROR.
-int inflate_run(z_streamp strm, InflateState* s) {
+int inflate_run(z_streamp strm, InflateState* s, int stop_mode = 0) {
     for (;;) {
         switch (s->mode) {
         case IM_HEAD: {
@@ -747,6 +798,7 @@ int inflate_run(z_streamp strm, InflateState* s) {
                 s->check = 0;
                 strm->adler = 0;
                 s->mode = IM_BLOCKS;
+                if (stop_mode) { s->stop_state = 1; s->stop_reported = false; s->stop_bits = 0; s->stop = 0; return Z_OK; }   // Mode::Type behind the header
                 break;
             }
             if (s->gzhead) s->gzhead->done = -1;   // not a gzip stream (inflate.rs:1024-1028)
@@ -768,6 +820,7 @@ int inflate_run(z_streamp strm, InflateState* s) {
             s->in.erase(s->in.begin(), s->in.begin() + 2);
             strm->adler = 1;
             s->mode = IM_BLOCKS;
+            if (stop_mode) { s->stop_state = 1; s->stop_reported = false; s->stop_bits = 0; s->stop = 0; return Z_OK; }   // Mode::Type behind the header
             break;
         }
         case IM_DICT:
@@ -777,9 +830,9 @@ int inflate_run(z_streamp strm, InflateState* s) {
         case IM_BLOCKS: {
             if (s->in.empty() || s->tried == s->in.size()) return Z_OK;
             if (s->out.size() - s->out_pos > queue_limit()) return Z_OK;
-            const int rc = inflate_attempt(s);
+            const int rc = inflate_attempt(s, stop_mode == 2 && s->hdr_seen ? 1 : stop_mode);
             if (rc != Z_OK) return rc;
-            if (s->mode == IM_BLOCKS) return Z_OK;
+            if (s->mode == IM_BLOCKS || s->stop_state) return Z_OK;   // (a stop behind the final block comes before its trailer)
             break;
         }
         case IM_TRAILER: {
@@ -1166,11 +1219,17 @@ int inflateInit2_(z_streamp strm, int windowBits, const char* version, int strea
 int inflateInit_(z_streamp strm, const char* version, int stream_size) { return inflateInit2_(strm, MAX_WBITS, version, stream_size); }
 int inflate(z_streamp strm, int flush) {
     // Every call takes all of avail_in and decodes as far as the buffered input allows ("provides as much output as
-    // possible", lib.rs:637): Z_BLOCK / Z_TREES are accepted and behave like Z_NO_FLUSH (no stop at block ends).
+    // possible", lib.rs:637).  Z_BLOCK stops at the next block boundary (also right behind a zlib / gzip header), Z_TREES
+    // also behind the next block header; data_type reports the stop (inflate.rs:1276-1284,1323,1369,1772,1856-1873).
     ZMI_ABI_TRY
     InflateState* s = istate(strm);
     if (!s || s->back_window || !strm->next_out || (strm->avail_in != 0 && !strm->next_in)) return Z_STREAM_ERROR;
     if (s->bias) { strm->total_in += (uLong)s->bias; s->bias = 0; }
+    const int stop_mode = flush == Z_BLOCK ? 1 : (flush == Z_TREES ? 2 : 0);
+    // a stop that an earlier call has reported is left behind (the reference: Mode::Type -> TypeDo on entry); one that was
+    // reached while the caller's buffer was full is reported by the call that drains the queue
+    if (s->stop_state && (s->stop_reported || !stop_mode)) { s->stop_state = 0; s->stop_reported = false; }
+    if (!stop_mode) s->hdr_seen = false;
     const uInt in0 = strm->avail_in, out0 = strm->avail_out;
     uInt taken = 0;
     // Bytes can only be handed back to the caller in the call that took them (next_in still points behind them).  So no
@@ -1190,7 +1249,9 @@ int inflate(z_streamp strm, int flush) {
     // the caller's input is taken a piece at a time, and only while the decoder can use it: what a pause hands back (and
     // the next call copies again) stays bounded, however much the caller offers
     const size_t kAbsorb = abi_limit("ZMI_ABI_ABSORB", (size_t)16 << 20);
+    bool stopped_now = false;
     for (;;) {
+        if (s->stop_state) { inflate_drain(strm, s); break; }   // a pending stop: only the queue is handed out
         const bool paused = s->mode == IM_BLOCKS && s->out.size() - s->out_pos > queue_limit();
         const bool wants_input = s->mode != IM_BLOCKS || s->in.empty() || s->tried == s->in.size();
         if (s->mode != IM_DONE && s->mode != IM_BAD && strm->avail_in && !paused && wants_input) {
@@ -1201,9 +1262,17 @@ int inflate(z_streamp strm, int flush) {
             s->in_sync = false;
         }
         const int was = s->mode;
-        const int rc = inflate_run(strm, s);
+        const int rc = inflate_run(strm, s, stop_mode);
         if (rc == Z_NEED_DICT) { hand_back(0); return Z_NEED_DICT; }
         if (rc != Z_OK) { strm->msg = zError(rc); return rc; }
+        if (s->stop_state) {
+            // the reference has consumed the input up to the byte that holds the last bit in front of the stop: the rest of
+            // this call's take goes back (s->stop = bytes of `in` up to there)
+            hand_back(s->stop);
+            stopped_now = true;
+            inflate_drain(strm, s);
+            break;
+        }
         if (s->mode == IM_DONE && was != IM_DONE && !s->in.empty()) {
             hand_back(0);   // bytes behind the end of the stream belong to the caller
             s->in.clear();
@@ -1215,14 +1284,27 @@ int inflate(z_streamp strm, int flush) {
         const bool undecoded = s->mode == IM_BLOCKS && !s->in.empty() && s->tried != s->in.size();
         if (!undecoded && strm->avail_in == 0) break;
     }
+    (void)stopped_now;
     // paused (output queued beyond the limit, or the caller's buffer is full) with input the decoder has not reached:
     // `stop` is how far it read (its bit reader runs a few bytes ahead, hence the margin)
-    if (s->mode == IM_BLOCKS && s->tried != s->in.size()) hand_back(s->stop > 64 ? s->stop - 64 : 0);
+    if (!s->stop_state && s->mode == IM_BLOCKS && s->tried != s->in.size()) hand_back(s->stop > 64 ? s->stop - 64 : 0);
     const bool drained = s->out_pos >= s->out.size();
-    // data_type as the reference reports it (inflate.rs:2440-2448): unused bits of the last byte, +64 in the last
-    // block, +128 right behind a block
-    const bool at_boundary = s->mode == IM_BLOCKS && s->pend == 0 && s->in.size() <= (s->sbit ? 1u : 0u) && s->form >= 0;
-    strm->data_type = (int)((s->sbit && s->mode == IM_BLOCKS ? 8u - s->sbit : 0u) + (s->last_block ? 64 : 0) + (at_boundary ? 128 : 0));
+    // data_type as the reference reports it (inflate.rs:1856-1873): unused bits of the last byte, +64 in the last
+    // block, +128 right behind a block (or a wrapper header), +256 behind a block header
+    if (s->stop_state && drained) {
+        s->stop_reported = true;
+        const bool lastb = s->stop_state == 2 ? s->hdr_last : s->last_block != 0;
+        strm->data_type = (int)(s->stop_bits + (lastb ? 64u : 0u) + (s->stop_state == 1 ? 128u : 256u));
+    } else {
+        const bool at_boundary = !s->stop_state && s->mode == IM_BLOCKS && s->pend == 0 && s->in.size() <= (s->sbit ? 1u : 0u) && s->form >= 0;
+        strm->data_type = (int)((s->sbit && s->mode == IM_BLOCKS ? 8u - s->sbit : 0u) + (s->last_block ? 64 : 0) + (at_boundary ? 128 : 0));
+    }
+    if (s->stop_state) {   // (the trailer behind a final block is looked at by the next call)
+        // (no progress is Z_BUF_ERROR also at a stop, as in the reference: inflate.rs:2450-2456 -- e.g. the boundary behind
+        // an empty stored block whose header the call before has reported)
+        if (in0 == strm->avail_in && out0 == strm->avail_out) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; }
+        return Z_OK;
+    }
     if (s->mode == IM_TRAILER && s->check_seen && drained && s->verify && s->check != s->want_check) {
         inf_bad(s, "incorrect data check");   // a gzip trailer that ends behind a wrong CRC is an error already
         strm->msg = s->errmsg;

@@ -958,7 +958,7 @@ extern "C" int zmi_inflate_resume(zmi_ctx* c, const uint8_t* in, uint32_t in_len
                                   int32_t* detail, uint32_t* in_used, uint32_t* resume) {
     if (!c || (!in && in_len) || (!hist && hist_len) || (!out && out_cap) || !out_len || !status || !detail || !in_used || !resume)
         return zmi_fail(ZMI_E_ARG, "null argument");
-    if (in_len > 0xFFFFFF00u || out_cap > 0xFFFF0000u || in_bit > 7u) return zmi_fail(ZMI_E_ARG, "stream too large for one call");
+    if (in_len > 0xFFFFFF00u || out_cap > 0xFFFF0000u || (in_bit & 0xFE0000F8u) != 0u) return zmi_fail(ZMI_E_ARG, "stream too large for one call");
     ZMI_ON_DEVICE(c);
     if (hist_len > 32768u) { hist += hist_len - 32768u; hist_len = 32768u; }
     const size_t base = ((size_t)hist_len + 1023u) & ~(size_t)1023u;   // the output region stays aligned; the history ends where it starts
