@@ -136,3 +136,39 @@ def large_stream_checks(inflate_fn, o, deflate_fn=None, size=1 << 17):
     for c, s_ in zip(cuts, st):
         assert int(s_) == _want(o, good[:c], len(d), 1)[0], c
     return n
+
+
+def jump_resolve_checks(e, o, big=False):
+    """the resolve pass for few streams (csrc/resolve_jump.hip: pointer jumping over all output bytes) against the serial
+    one-wave-per-stream pass, on the same compressed streams: runs that feed on themselves (dist < len), a 300 KB run of
+    one byte (the deepest pointer chains there are), every data class, history (resumable decode with 32 KiB in front),
+    and a corrupt stream (both passes must leave the same prefix and report the same code).  ZMI_INF_JUMP=1 / 0 force the
+    pass (read under ZMI_TUNING)."""
+    import zlib
+    os.environ["ZMI_TUNING"] = "1"
+    n = 400000 if big else 70000
+    blobs = [b"a" * (300000 if big else 40000), b"ab" * 30000, b"abc" * 20000 + bytes(range(256)) * 40, o.gen_shard(0, n), o.gen_shard(3, n),
+             o.gen_shard(5, n // 2), o.gen_shard(7, n)]
+    comp = [zlib.compress(b, 6) for b in blobs]
+    bad = bytearray(comp[3]); bad[len(bad) // 2] ^= 0x55
+    comp.append(bytes(bad)); blobs.append(None)
+    res = {}
+    try:
+        for mode in ("1", "0"):
+            os.environ["ZMI_INF_JUMP"] = mode
+            outs, st = e.inflate(comp, [len(b) if b is not None else n for b in blobs], wrap=1)
+            one, st1 = e.inflate(comp[:1], [len(blobs[0])], wrap=1)
+            # history: the second half of a raw stream decoded with the first half's output in front of it
+            raw = zlib.compressobj(6, zlib.DEFLATED, -15)
+            a = raw.compress(blobs[3][:n // 2]) + raw.flush(zlib.Z_SYNC_FLUSH)
+            b2 = raw.compress(blobs[3][n // 2:]) + raw.flush()
+            tail, s2, d2, used, ck = e.inflate_resume(b2, 0, blobs[3][:n // 2][-32768:], cap=n)
+            res[mode] = (outs, st, one, st1, tail, s2)
+    finally:
+        os.environ.pop("ZMI_INF_JUMP", None)
+    assert res["1"] == res["0"]
+    outs, st, one, st1, tail, s2 = res["1"]
+    for b, got, s_ in zip(blobs[:-1], outs, st):
+        assert s_ == 0 and got == b
+    assert st[-1] != 0 and one == [blobs[0]] and st1 == [0] and s2 == 0 and tail == blobs[3][n // 2:]
+    return len(comp)

@@ -8,6 +8,7 @@ import zlib
 import pytest
 
 import oracle_lib
+import parity_checks
 import zmi_ctypes
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -381,3 +382,10 @@ def test_inflate_large_streams_fast_pass(eng, o):
     """the lane-serial fast pass of the decode kernel (inflate.hip inf_fast_pass) only runs on streams with >= 4 KiB left"""
     import parity_checks
     assert parity_checks.large_stream_checks(eng.inflate, o, lambda blobs, lvl, wrap: eng.deflate(blobs, level=lvl, wrap=wrap)) > 60
+
+
+def test_jump_resolve_equals_serial_resolve():
+    """few streams: back-references resolved by pointer jumping (resolve_jump.hip) -- byte for byte the serial pass's output"""
+    e = zmi_ctypes.Engine(zmi_ctypes.load_emu())
+    assert parity_checks.jump_resolve_checks(e, oracle_lib.load()) == 8
+    e.close()

@@ -434,3 +434,14 @@ def test_inflate_large_streams_fast_pass_on_gpu(engine):
     n = parity_checks.large_stream_checks(_inflate_fn(engine), o, lambda blobs, lvl, wrap: _deflate(engine, blobs, level=lvl, wrap=wrap),
                                           size=1 << 19)
     assert n > 60
+
+
+def test_jump_resolve_equals_serial_resolve_on_gpu():
+    """few streams: back-references resolved by pointer jumping on the whole chip (csrc/resolve_jump.hip) -- byte for byte
+    the output of the one-wave-per-stream pass, incl. a 300 KB run of one byte, history and a corrupt stream"""
+    import oracle_lib
+    import parity_checks
+    import zmi_ctypes
+    eng = zmi_ctypes.Engine(zmi_ctypes.load_product())
+    assert parity_checks.jump_resolve_checks(eng, oracle_lib.load(rebuild=False), big=True) == 8
+    eng.close()

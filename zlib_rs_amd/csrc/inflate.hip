@@ -437,6 +437,9 @@ static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, co
     // are done ride along with their updates switched off.
     while (__ballot(go)) {
         const uint32_t wi = pos >> 5, sh = pos & 31u;
+#ifdef ZMI_EMU_DEBUG
+        if (wi > 1100u) { fprintf(stderr, "lane %u wave %u pos %u start %u boundary %u active %d\n", zmi_lane(), zmi_wave(), pos, start, boundary, (int)active); abort(); }
+#endif
         const uint32_t d0 = fw[wi], d1 = fw[wi + 1u], d2 = fw[wi + 2u];
         const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
         uint32_t e = S->ltab[lo & ((1u << INF_LROOT) - 1u)];
@@ -561,14 +564,184 @@ static __device__ __forceinline__ uint32_t inf_fast_pass(InfShared* S, const uin
     return commit;
 }
 
+
+// ---- one stream on several waves (the NW = INF_MW instantiations: launches of a few streams) --------------------------
+// A stream alone on the chip is one wave alone on a CU: every LDS round trip of its token steps is exposed, a 1 MiB text
+// stream took 9.5 ms to decode (round 2).  The fast pass above is already a set of independent sub-sequence walks that
+// are stitched together afterwards, so it extends across waves as it stands: wave w of the workgroup takes the 64
+// sub-sequences behind those of wave w - 1 (its own 4 KiB of staged input, the block's tables shared), the waves walk
+// concurrently, and the stitch runs over 64 x nact lanes -- inside a wave as before, between waves through LDS: the lane 0
+// of wave w has to start where lane 63 of wave w - 1 ended, and a wave commits only if every wave below it committed all
+// its lanes.  Wave 0 is the stream's master (headers, table construction, token rounds, everything the single-wave kernel
+// does); the other waves sleep at a workgroup barrier until it posts a pass.  A pass covers at most the rest of the block
+// (the tables change behind an end-of-block), so the gain is bounded by the block size: 8 waves x 3.5 KiB = 28 KiB of
+// compressed data, more than the ~20 KiB of a 16 383-symbol zlib block.
+#define INF_MW 8u
+#define INF_MW_ROUNDS 4u   // cross-wave fix-up rounds (a wave whose lane 0 started at a wrong guess restarts it and re-stitches)
+struct InfMulti {
+    __attribute__((aligned(16))) uint8_t fb[INF_MW - 1u][INF_FAST_BYTES];
+    uint32_t cmd;            // 1: a pass is posted, 2: the stream is done (helpers leave)
+    uint32_t nact, sub;      // waves taking part, bits per lane
+    uint32_t Plo, Phi;       // bit position of the pass in the stream
+    uint32_t opos, cap, hist;
+    uint32_t start0[INF_MW];   // per wave, bits relative to P: where its lane 0 started ...
+    uint32_t exit63[INF_MW];   // ... where its lane 63 ended,
+    uint32_t good[INF_MW];     // how many of its leading lanes are consistent with its lane 0,
+    uint32_t stopped[INF_MW];  // whether one of them hit an end of block / an invalid code,
+    uint32_t nsum[INF_MW];     // output bytes of the lanes it would commit,
+    uint32_t cut[INF_MW];      // first of those lanes that must not be committed (64: none)
+    uint32_t res_lanes, res_bits, res_out, res_eob;
+};
+__shared__ InfMulti g_inf_mw;
+
+// one pass, executed by ALL waves of the workgroup between the barrier that posts it and the one that ends it
+static __device__ __noinline__ void inf_pass_mw(const uint8_t* src, uint8_t* dst, uint32_t* bm32) {
+    InfShared* S = &g_inf_lds;
+    InfMulti* M = &g_inf_mw;
+    const uint32_t lane = zmi_lane(), wave = zmi_uniform(zmi_wave());
+    const uint32_t nact = zmi_uniform(M->nact), sub = zmi_uniform(M->sub);
+    const uint64_t P = ((uint64_t)zmi_uniform(M->Phi) << 32) | zmi_uniform(M->Plo);
+    const uint32_t opos = zmi_uniform(M->opos), cap = zmi_uniform(M->cap), hist = zmi_uniform(M->hist);
+    const bool act = wave < nact;
+    uint8_t* fb = wave == 0u ? S->fb : M->fb[wave - 1u];
+    const uint32_t span = 64u * sub;                 // bits per wave
+    const uint32_t org = wave * span;                // this wave's first bit, relative to P
+    uint32_t p_rel = 0, start = 0, boundary = 0, good = 0;
+    uint64_t stopm = 0;
+    InfLane R;
+    R.exit = 0; R.nout = 0; R.need = 0; R.flags = 0;
+    if (act) {
+        // stage 4 KiB: wave 0 from the 16-byte line holding bit P, the others 32 bytes earlier -- their lane 0 is a guess
+        // like any other lane's and warms up through the bits below the wave's first one
+        const uint64_t Pw = P + org;
+        const uint32_t back = wave ? 32u : 0u;
+        const uint32_t ib = (uint32_t)(Pw >> 3) - back;
+        const uint32_t mis = (uint32_t)((uintptr_t)(src + ib) & 15u);
+        const uint8_t* line = src + ib - mis;
+        zmi_wave_order();
+#pragma unroll
+        for (uint32_t k = 0; k < INF_FAST_BYTES / 1024u; ++k) *(uint4*)(fb + 16u * (lane + 64u * k)) = *(const uint4*)(line + 16u * (lane + 64u * k));
+        zmi_wave_order();
+        p_rel = ((mis + back) << 3) | ((uint32_t)Pw & 7u);
+        boundary = p_rel + (lane + 1u) * sub;
+        start = p_rel + lane * sub;
+        {
+            const bool warm = lane != 0u || wave != 0u;
+            const uint32_t wfrom = (wave != 0u || start - p_rel > INF_WARM_BITS) ? start - INF_WARM_BITS : p_rel;
+            const InfLane Wm = inf_lane_decode<false>(S, fb, wfrom, start, warm, nullptr, nullptr, 0u);
+            if (warm && Wm.flags == 0u) start = Wm.exit;
+        }
+        R = inf_lane_decode<false>(S, fb, start, boundary, true, nullptr, nullptr, 0u);
+    }
+    for (uint32_t g = 0;; ++g) {
+        if (act) {
+            // inside the wave, as inf_fast_pass: a lane restarts where the lane below ended until a prefix is consistent
+            for (uint32_t it = 0;; ++it) {
+                const uint32_t below_exit = (uint32_t)__shfl_up((int)R.exit, 1u);
+                const bool wrong = lane != 0u && below_exit != start;
+                stopm = __ballot(R.flags != 0u);
+                const uint64_t wrongm = __ballot(wrong);
+                const uint32_t first_wrong = wrongm ? (uint32_t)__ffsll((unsigned long long)wrongm) - 1u : 64u;
+                const uint32_t first_stop = stopm ? (uint32_t)__ffsll((unsigned long long)stopm) : 64u;   // index + 1
+                good = first_wrong < first_stop ? first_wrong : first_stop;
+                if (first_stop <= first_wrong || first_wrong >= 64u || it == 5u) break;
+                if (wrong) start = below_exit;
+                const InfLane N = inf_lane_decode<false>(S, fb, start, boundary, wrong, nullptr, nullptr, 0u);
+                if (wrong) R = N;
+            }
+            const uint32_t s0 = zmi_readlane(start, 0u), e63 = zmi_readlane(R.exit, 63u);
+            if (lane == 0u) {
+                M->start0[wave] = s0 - p_rel + org;
+                M->exit63[wave] = e63 - p_rel + org;
+                M->good[wave] = good;
+                M->stopped[wave] = (stopm & (good >= 64u ? ~0ull : ((1ull << good) - 1ull))) != 0ull ? 1u : 0u;
+            }
+        }
+        __syncthreads();
+        if (g + 1u == INF_MW_ROUNDS) break;
+        // between the waves: lane 0 of wave w belongs where lane 63 of wave w - 1 ended
+        if (act && wave != 0u) {
+            const uint32_t want = zmi_uniform(M->exit63[wave - 1u]), have = zmi_uniform(M->start0[wave]);
+            // (a wave below that stopped early -- end of block, invalid code -- ended in front of this wave's bits: nothing to link to)
+            if (want != have && want >= org && want < org + 64u) {
+                const bool l0 = lane == 0u;
+                if (l0) start = want - org + p_rel;
+                const InfLane N = inf_lane_decode<false>(S, fb, start, boundary, l0, nullptr, nullptr, 0u);
+                if (l0) R = N;
+            }
+        }
+        __syncthreads();   // (this round's values have been read before the next round overwrites them)
+    }
+    // what every wave commits: the chain runs through the waves as long as each one is complete and linked to the one below
+    uint32_t commit_of[INF_MW];
+    {
+        bool alive = true;
+#pragma unroll
+        for (uint32_t w = 0; w < INF_MW; ++w) {
+            commit_of[w] = 0u;
+            if (w < nact) {
+                const bool linked = w == 0u || zmi_uniform(M->start0[w]) == zmi_uniform(M->exit63[w - 1u]);
+                const uint32_t gw = zmi_uniform(M->good[w]);
+                commit_of[w] = (alive && linked) ? gw : 0u;
+                alive = alive && linked && gw == 64u && zmi_uniform(M->stopped[w]) == 0u;
+            }
+        }
+    }
+    uint32_t commit = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < INF_MW; ++w) commit = w == wave ? commit_of[w] : commit;
+    // output offsets, and the first lane that cannot be committed (invalid code, output full, reaches behind the history:
+    // those are left to the token rounds, which report them with the reference's codes)
+    const uint32_t nout = lane < commit ? R.nout : 0u;
+    const uint32_t incl = zmi_wave_incl_scan(nout);
+    if (lane == 63u) M->nsum[wave] = incl;
+    __syncthreads();
+    uint32_t wbase = opos;
+#pragma unroll
+    for (uint32_t w = 0; w < INF_MW; ++w) wbase += (w < wave && w < nact) ? zmi_uniform(M->nsum[w]) : 0u;
+    const uint32_t base = wbase + incl - nout;
+    const bool bad = lane < commit && ((R.flags & 1u) != 0u || base + nout > cap || R.need > base + hist);
+    const uint64_t badm = __ballot(bad);
+    if (lane == 0u) M->cut[wave] = badm ? (uint32_t)__ffsll((unsigned long long)badm) - 1u : 64u;
+    __syncthreads();
+    uint32_t fc = 0, total_lanes = 0, last_wave = 0;
+    {
+        bool open = true;
+#pragma unroll
+        for (uint32_t w = 0; w < INF_MW; ++w) {
+            uint32_t c = 0u;
+            if (w < nact && open) {
+                const uint32_t cu = zmi_uniform(M->cut[w]);
+                c = cu < commit_of[w] ? cu : commit_of[w];
+                if (c < 64u || cu < 64u) open = false;   // a wave that does not commit all 64 lanes ends the pass
+            }
+            if (c != 0u) last_wave = w;
+            total_lanes += c;
+            fc = w == wave ? c : fc;
+        }
+    }
+    if (fc != 0u) (void)inf_lane_decode<true>(S, fb, start, boundary, lane < fc, dst, bm32, base);
+    if (total_lanes != 0u && wave == last_wave) {
+        const uint32_t k = fc - 1u;
+        const uint32_t bits = zmi_readlane(R.exit, k) - p_rel + org, outm = wbase - opos + zmi_readlane(incl, k),
+                       eobf = (zmi_readlane(R.flags, k) >> 1) & 1u;
+        if (lane == 0u) { M->res_bits = bits; M->res_out = outm; M->res_eob = eobf; }
+    }
+#ifdef ZMI_EMU_DEBUG
+    if (wave == 0u && lane == 0u) fprintf(stderr, "pass nact %u sub %u lanes %u\n", nact, sub, total_lanes);
+#endif
+    if (wave == 0u && lane == 0u) M->res_lanes = total_lanes;
+    __syncthreads();
+}
+
 // wrap: 0 raw, 1 zlib, 2 gzip, 3 auto (zlib or gzip by magic)
 // RESUME (raw streams only; the streaming ABI's resumable inflate, zlib-rs/src/inflate.rs:288-320 keeps the same
 // facts in its Mode / BitReader / Window): stream s starts at bit in_bit[s] (0..7) of its first byte, and
 // resume[4s..4s+3] receives {byte, bit, output position, complete} of the start of the block the decode stopped
 // in -- or of the end of the final block.  Decoding the same input again from there, with the output in front of
 // that point as history, continues the stream.  A separate instantiation: the batch kernel's registers are full.
-template <bool RESUME>
-__global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
+template <bool RESUME, uint32_t NW>   // NW: waves per stream, 1 (the batch kernels) or INF_MW (launches of a few streams)
+__global__ void __launch_bounds__(64 * NW) zmi_inflate_kernel(const uint8_t* __restrict__ in, const uint64_t* __restrict__ in_off,
                                                          const uint32_t* __restrict__ in_len, uint32_t wrap,
                                                          uint8_t* out, const uint64_t* __restrict__ out_off,
                                                          const uint32_t* __restrict__ out_cap,
@@ -603,7 +776,15 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
             out_len[s] = 0; in_used[s] = 0; check[s] = 0; status[s] = ZMI_NO_SCRATCH;
             if (RESUME) { resume[4u * s] = 0; resume[4u * s + 1u] = in_bit ? (in_bit[s] & 7u) : 0u; resume[4u * s + 2u] = 0; resume[4u * s + 3u] = 0; }
         }
-        return;
+        return;   // (every wave of the workgroup: nothing has been posted yet)
+    }
+    if (NW > 1u && zmi_wave() != 0u) {
+        // helper waves: they take part in the fast passes the master (wave 0) posts and leave when it is done
+        for (;;) {
+            __syncthreads();
+            if (zmi_uniform(g_inf_mw.cmd) == 2u) return;
+            inf_pass_mw(B.src, dst, bm32);
+        }
     }
     uint32_t kind_found = wrap;  // resolved wrapper: 0 raw, 1 zlib, 2 gzip
     uint32_t fixed_ready = 0;
@@ -860,7 +1041,35 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
                             else if (rest < 56u * INF_SUB_BITS) { sub = (rest + (rest >> 3) + 63u) >> 6; sub = sub < 64u ? 64u : (sub > INF_SUB_BITS ? INF_SUB_BITS : sub); }
                         }
                         uint32_t fbits = 0, fout = 0, feob = 0;
-                        const uint32_t lanes = zmi_uniform(inf_fast_pass(S, B.src, P, dst, bm32, opos, cap, hist, sub, &fbits, &fout, &feob));
+                        uint32_t lanes;
+                        if (NW > 1u) {
+                            // how many waves: what the block before suggests is left of this one, spread over 64 lanes each; every
+                            // wave needs its 4 KiB (and the 32 bytes in front) inside the input
+                            uint32_t nact = NW;
+                            if (last_blk_bits != 0u) {
+                                const uint64_t done = P - Pblk;
+                                const uint32_t rest = done < (uint64_t)last_blk_bits ? last_blk_bits - (uint32_t)done : 0u;
+                                if (rest == 0u) { nact = 2u; sub = 256u; }
+                                else {
+                                    const uint32_t want = rest + (rest >> 3);
+                                    nact = (want + 64u * INF_SUB_BITS - 1u) / (64u * INF_SUB_BITS);
+                                    nact = nact < 1u ? 1u : (nact > NW ? NW : nact);
+                                    sub = (want + 64u * nact - 1u) / (64u * nact);
+                                    sub = sub < 64u ? 64u : (sub > INF_SUB_BITS ? INF_SUB_BITS : sub);
+                                }
+                            } else sub = INF_SUB_BITS;
+                            while (nact > 1u && Pend - P < (uint64_t)(nact - 1u) * 64u * sub + 8ull * (INF_FAST_BYTES + 32u)) --nact;
+                            if (lane == 0) {
+                                InfMulti* M = &g_inf_mw;
+                                M->cmd = 1u; M->nact = nact; M->sub = sub; M->Plo = (uint32_t)P; M->Phi = (uint32_t)(P >> 32);
+                                M->opos = opos; M->cap = cap; M->hist = hist;
+                            }
+                            __syncthreads();
+                            inf_pass_mw(B.src, dst, bm32);
+                            lanes = zmi_uniform(g_inf_mw.res_lanes);
+                            if (lanes != 0u) { fbits = zmi_uniform(g_inf_mw.res_bits); fout = zmi_uniform(g_inf_mw.res_out); feob = zmi_uniform(g_inf_mw.res_eob); }
+                        } else
+                        lanes = zmi_uniform(inf_fast_pass(S, B.src, P, dst, bm32, opos, cap, hist, sub, &fbits, &fout, &feob));
                         B.cbase = -(int32_t)(2u * INF_CHUNK);   // the pass staged its input over the token rounds' chunk
                         if (lanes != 0u) {
                             P += zmi_uniform(fbits);
@@ -1003,6 +1212,10 @@ __global__ void __launch_bounds__(64) zmi_inflate_kernel(const uint8_t* __restri
         if (RESUME) {
             resume[4u * s] = S->rs[0]; resume[4u * s + 1u] = S->rs[1]; resume[4u * s + 2u] = S->rs[2]; resume[4u * s + 3u] = S->rs[3];
         }
+    }
+    if (NW > 1u) {   // the helper waves leave with the master
+        if (lane == 0) g_inf_mw.cmd = 2u;
+        __syncthreads();
     }
 }
 
@@ -1406,14 +1619,15 @@ extern "C" int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off,
     ZMI_LAUNCH(zmi_inflate_order_kernel, dim3(1), dim3(1024), 0, stream, d_in_len, n_streams, d_order);
     ZMI_LAUNCH(zmi_inflate_plan_kernel, dim3(1), dim3(1024), 0, stream, d_out_cap, n_streams, bitmap_words, d_bm_off);
     ZMI_LAUNCH(zmi_inflate_clear_kernel, dim3(n_streams), dim3(256), 0, stream, d_out_cap, (const uint64_t*)d_bm_off, d_bitmap);
-    if (d_resume)
-        ZMI_LAUNCH(zmi_inflate_kernel<true>, dim3(n_streams), dim3(64), 0, stream, d_in, d_in_off, d_in_len, wrap, d_out, d_out_off,
-                   d_out_cap, d_out_len, d_in_used, d_check, d_status, d_bitmap, (const uint64_t*)d_bm_off, d_out_hist, d_in_bit, d_resume,
-                   (const uint32_t*)d_order);
-    else
-        ZMI_LAUNCH(zmi_inflate_kernel<false>, dim3(n_streams), dim3(64), 0, stream, d_in, d_in_off, d_in_len, wrap, d_out, d_out_off,
-                   d_out_cap, d_out_len, d_in_used, d_check, d_status, d_bitmap, (const uint64_t*)d_bm_off, d_out_hist,
-                   (const uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)d_order);
+    // a launch of a few streams gives every stream a workgroup of INF_MW waves (inf_pass_mw); thousands of streams fill the
+    // chip with one wave each
+    const bool mw = n_streams <= 16u;
+#define INF_GO(R, W, IB, RS) ZMI_LAUNCH((zmi_inflate_kernel<R, W>), dim3(n_streams), dim3(64u * W), 0, stream, d_in, d_in_off, d_in_len, wrap, d_out, \
+                                d_out_off, d_out_cap, d_out_len, d_in_used, d_check, d_status, d_bitmap, (const uint64_t*)d_bm_off, d_out_hist, IB, RS,  \
+                                (const uint32_t*)d_order)
+    if (d_resume) { if (mw) INF_GO(true, INF_MW, d_in_bit, d_resume); else INF_GO(true, 1u, d_in_bit, d_resume); }
+    else { if (mw) INF_GO(false, INF_MW, (const uint32_t*)nullptr, (uint32_t*)nullptr); else INF_GO(false, 1u, (const uint32_t*)nullptr, (uint32_t*)nullptr); }
+#undef INF_GO
     return 0;
 }
 

@@ -76,6 +76,7 @@ struct zmi_ctx {
     zmi_buf pieces;   // per shard x piece compressed length
     zmi_buf inf_tmp;  // in_used[n] check[n] adler[n] crc[n] bm_off[n] (u64)
     zmi_buf inf_bm;   // inflate: 1 bit per output byte of the batch (where back-references start)
+    zmi_buf inf_ptr;  // inflate of few streams: 4 B per output byte, the pointers of the jump resolve (resolve_jump.hip)
     zmi_buf st_in, st_out, st_meta;  // zmi_inflate_resume: staging of one host stream (kept across calls)
     // host-buffer batches (zmi_deflate_batch): two slots cycle through copy-in / kernels / copy-out on three streams
     struct hb_slot { zmi_buf in, out, meta; hipEvent_t in_done, k_done, out_done; } hb[2];
@@ -120,6 +121,7 @@ extern "C" int zmi_ctx_destroy(zmi_ctx* c) {
     if (c->pieces.p) (void)hipFree(c->pieces.p);
     if (c->inf_tmp.p) (void)hipFree(c->inf_tmp.p);
     if (c->inf_bm.p) (void)hipFree(c->inf_bm.p);
+    if (c->inf_ptr.p) (void)hipFree(c->inf_ptr.p);
     if (c->st_in.p) (void)hipFree(c->st_in.p);
     if (c->st_out.p) (void)hipFree(c->st_out.p);
     if (c->st_meta.p) (void)hipFree(c->st_meta.p);
@@ -536,9 +538,24 @@ static int zmi_inflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
                                      d_order, stream);
         if (lrc) return zmi_fail(ZMI_E_HIP, "inflate launch setup", (hipError_t)lrc);
     }
+    // The resolve pass.  Thousands of streams: one wave per stream fills its holes in order.  A handful of streams would leave
+    // the chip empty that way (a 1 MiB stream alone: 8 ms): their back-references are resolved by pointer jumping over all
+    // output bytes at once (resolve_jump.hip), which costs 4 B of scratch per byte of capacity.
+    // (below 256 KiB of capacity the serial pass takes less than the jump pass's two dozen launches)
+    bool jump = n <= 16u && out_limit <= (1ull << 30) && out_limit >= (256ull << 10);
+    if (const char* jv = zmi_tune("ZMI_INF_JUMP")) jump = atoi(jv) != 0 && out_limit <= (1ull << 30);
+    if (jump && zmi_reserve(c->inf_ptr, (size_t)bm_words * 256u + 512u) != 0) jump = false;   // (no room: the serial pass needs none)
     {
         zmi_scope_timer tm(c, ZMI_K_RESOLVE, stream);
-        int lrc = zmi_launch_inflate_resolve((uint8_t*)d_out, d_out_off, d_out_len, n, (const uint64_t*)c->inf_bm.p, d_bm_off, d_out_hist, d_order, stream);
+        int lrc;
+        if (jump) {
+            uint32_t rounds = 2u;
+            while (rounds < 34u && (1ull << (rounds - 1u)) < out_limit) ++rounds;   // ceil(log2(capacity)) + 1
+            lrc = zmi_launch_resolve_jump((uint8_t*)d_out, d_out_off, d_out_len, n, (const uint64_t*)c->inf_bm.p, d_bm_off, (int32_t*)c->inf_ptr.p,
+                                          bm_words * 64ull, rounds, (uint32_t*)((uint8_t*)c->inf_ptr.p + (size_t)bm_words * 256u), stream);
+        } else {
+            lrc = zmi_launch_inflate_resolve((uint8_t*)d_out, d_out_off, d_out_len, n, (const uint64_t*)c->inf_bm.p, d_bm_off, d_out_hist, d_order, stream);
+        }
         if (lrc) return zmi_fail(ZMI_E_HIP, "inflate resolve launch setup", (hipError_t)lrc);
     }
     if (wrap != ZMI_WRAP_RAW) {
