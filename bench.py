@@ -14,7 +14,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement).  Besides the co
   levels         configs[3]: level 1 and level 9, GiB/s + ratio + the oracle's ratio at the same level
   pcie_inclusive host buffers in, host buffers out (never `value`)
   stream_abi     configs[0]: one ~15.74 MB stream through deflate() / inflate() of the drop-in library, one thread
-  stitch         N > 1 only: slab packing + the point-to-point slab exchange (outside the timed region)
+  stitch         slab packing over all slots (+ the point-to-point slab exchange at N > 1), outside the timed region, with the memory plan
+  real_data      lcet10.txt / paper-100k.pdf / fireworks.jpg tiled to 1 MiB at levels 1 / 6 / 9: gpu, oracle and system-zlib ratios
   cpu_baseline   the oracle's level-6 restatement on the host cores (N = 1 only)
 """
 import argparse
@@ -128,6 +129,7 @@ def main():
     ap.add_argument("--scratch-gib", type=float, default=float(os.environ.get("ZMI_BENCH_SCRATCH_GIB", 70)),
                     help="device scratch of the engine (one launch group of the deflate pipeline): 70 GiB = 16384 shards per launch")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-stitch", action="store_true", help="skip the slab packing / exchange leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the inflate / levels / PCIe legs (profiling runs)")
     args = ap.parse_args()
 
@@ -195,10 +197,15 @@ def main():
         offs, stitched_total = zdist.stitch_offsets(table)
         dist.all_reduce(csum)
         assert stitched_total == int(csum.item())
-        try:
-            stitch_obj = stitch_leg(e, zdist, dist, torch, out, olen, table, dev)
-        except Exception as ex:  # noqa: BLE001  (the exchange is outside the timed region: report, do not lose the line)
-            stitch_obj = {"error": repr(ex)[:300]}
+    else:
+        table = olen.reshape(1, -1)
+    if not args.no_stitch:
+        # (no try / except: a stitch that cannot run is a failed run, not a footnote -- the memory plan below says why beforehand)
+        plan = memory_plan(torch, world, S, B, stride, args.scratch_gib, float(table[rank].to(torch.int64).sum().item()) / GIB + 0.1,
+                           0.5 * max(0, world - 1))
+        stitch_obj = stitch_leg(e, zdist, dist, torch, out, olen, table, dev)
+        stitch_obj["memory_plan"] = plan
+        torch.cuda.empty_cache()
     comp_total = int(csum.item())
     raw_total = S * B * world
     ratio = raw_total / comp_total
@@ -309,7 +316,10 @@ def main():
                         cap[:small].contiguous(), wrap=WRAP_GZIP, out_len=blen, status=bst)
         torch.cuda.synchronize()
         small_s = time.perf_counter() - ti
-        assert int((bst[:small] != 0).sum().item()) == 0 and torch.equal(back[:small * B], data[:small * B])
+        assert int((bst[:small] != 0).sum().item()) == 0
+        for t0_ in range(0, small, M):   # (stream i holds member i % M)
+            cnt_ = min(M, small - t0_)
+            assert torch.equal(back[t0_ * B:(t0_ + cnt_) * B], data[:cnt_ * B])
         inflate_obj["small_launch"] = {"streams": small, "value": small * B / GIB / small_s, "unit": "GiB/s of output", "ms": small_s * 1e3}
         del d_members
         # ---- configs[3]: level 1 and level 9 ----
@@ -372,12 +382,13 @@ def main():
             pcie_obj = {"error": repr(ex)[:200]}
     del back
 
-    stream_obj = None
+    stream_obj = real_obj = None
     if extras:
         try:
             stream_obj = stream_abi_leg(args.level)
         except Exception as ex:  # noqa: BLE001
             stream_obj = {"error": repr(ex)[:200]}
+        real_obj = real_data_leg(e, torch, dev, B)
 
     if rank == 0:
         value = raw_total * args.steps / GIB / elapsed
@@ -390,7 +401,7 @@ def main():
         # (tools/prof_final.sh), recorded per launch in profiles/ and scaled to this run's launch size -- a replayed
         # figure, not measured in this run: traffic_source names the file it comes from
         traffic, traffic_source = None, None
-        for name in ("r02_traffic.json", "r01_traffic.json"):
+        for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", name)))
                 k = tj.get("zmi_lz77_kernel") or tj.get("zmi_lz77_kernel_t")
@@ -427,6 +438,8 @@ def main():
             line["pcie_inclusive"] = pcie_obj
         if stream_obj is not None:
             line["stream_abi"] = stream_obj
+        if real_obj is not None:
+            line["real_data"] = real_obj
         if stitch_obj is not None:
             line["stitch"] = stitch_obj
         if world == 1 and not args.no_cpu:
@@ -470,11 +483,61 @@ def stream_abi_leg(level):
             "note": "one stream = 16 segments of 1 MiB on the device: a plumbing check, not a throughput configuration"}
 
 
+def real_data_leg(e, torch, dev, B):
+    """the three real fixtures of the reference's test data (lcet10.txt, paper-100k.pdf, fireworks.jpg; xz-packed
+    under tests/golden/fixtures), each tiled to one 1 MiB shard, at levels 1 / 6 / 9: ratio of this engine, of the oracle
+    (the reference's algorithm) and of the system zlib on the same bytes, with a device round trip of every stream."""
+    import lzma
+    import zlib
+    from zlib_rs_amd.engine import WRAP_ZLIB
+    o = _oracle()
+    d = os.path.join(ROOT, "tests", "golden", "fixtures")
+    names = ("lcet10.txt", "paper-100k.pdf", "fireworks.jpg")
+    blobs = []
+    for name in names:
+        raw = lzma.decompress(open(os.path.join(d, name + ".xz"), "rb").read())
+        blobs.append((raw * (B // len(raw) + 1))[:B])
+    n = len(blobs)
+    data = torch.frombuffer(bytearray(b"".join(blobs)), dtype=torch.uint8).to(dev)
+    off = torch.arange(n, dtype=torch.int64, device=dev) * B
+    ln = torch.full((n,), B, dtype=torch.int32, device=dev)
+    back = torch.empty(n * B, dtype=torch.uint8, device=dev)
+    cap = torch.full((n,), B, dtype=torch.int32, device=dev)
+    res = {"shard_bytes": B, "note": "each fixture tiled to one 1 MiB shard; gpu / oracle (reference algorithm, CPU) / system zlib ratios"}
+    for lvl in (1, 6, 9):
+        out, olen, st = e.deflate_batch(data, off, ln, B, level=lvl, wrap=WRAP_ZLIB)
+        torch.cuda.synchronize()
+        assert int((st != 0).sum().item()) == 0
+        blen, bst = e.inflate_batch(out, torch.arange(n, dtype=torch.int64, device=dev) * out.stride(0), olen, back, off, cap, wrap=WRAP_ZLIB)
+        torch.cuda.synchronize()
+        assert int((bst != 0).sum().item()) == 0 and torch.equal(back, data), "real-data round trip failed at level %d" % lvl
+        hl = olen.cpu().numpy()
+        for i, name in enumerate(names):
+            rc, oc = o.deflate(blobs[i], lvl, 1)
+            g, orc, z = B / float(hl[i]), B / float(len(oc)), B / float(len(zlib.compress(blobs[i], lvl)))
+            res.setdefault(name, {})["L%d" % lvl] = {"gpu": round(g, 4), "oracle": round(orc, 4), "system_zlib": round(z, 4), "gpu_over_oracle": round(g / orc, 4)}
+    return res
+
+
+def memory_plan(torch, world, S, B, stride, scratch_gib, slab_gib, staging_gib):
+    """what one rank holds while the stitch runs; fails loudly above 90 % of the device (a silent OOM inside the stitch would
+    cost the whole line)"""
+    total = torch.cuda.get_device_properties(torch.cuda.current_device()).total_memory / GIB
+    plan = {"input_GiB": S * B / GIB, "slots_GiB": S * stride / GIB, "scratch_GiB": scratch_gib, "slab_GiB": slab_gib,
+            "exchange_staging_GiB": staging_gib, "hbm_total_GiB": total}
+    plan["sum_GiB"] = plan["input_GiB"] + plan["slots_GiB"] + plan["scratch_GiB"] + plan["slab_GiB"] + plan["exchange_staging_GiB"]
+    plan["frac_of_hbm"] = plan["sum_GiB"] / total
+    if plan["frac_of_hbm"] > 0.90:
+        raise RuntimeError("memory plan of the stitch exceeds 90 %% of the device: %s" % json.dumps(plan))
+    return plan
+
+
 def stitch_leg(e, zdist, dist, torch, out, olen, table, dev):
     """N > 1, after the timed region: pack this rank's slots into a dense slab, then the point-to-point slab exchange in
-    1 GiB rounds with reused staging (the stitched file of 8 x 29 GiB does not fit one GPU: a real job streams it to its
+    512 MiB rounds with reused staging (the stitched file of 8 x 29 GiB does not fit one GPU: a real job streams it to its
     consumer round by round; here the received chunks are checksummed and dropped).  Returns the measured rates."""
-    world, rank = dist.get_world_size(), dist.get_rank()
+    solo = not (dist.is_available() and dist.is_initialized())
+    world, rank = (1, 0) if solo else (dist.get_world_size(), dist.get_rank())
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     slab, so = e.pack_slab(out, olen)
@@ -482,6 +545,17 @@ def stitch_leg(e, zdist, dist, torch, out, olen, table, dev):
     pack_s = time.perf_counter() - t0
     slab_bytes = [int(x) for x in table.to(torch.int64).sum(1)]
     assert int(so[-1].item()) == slab_bytes[rank]
+    if solo:
+        # one GPU: the pack kernel over all slots (the exchange has no peer); the slab is checked against the size table
+        # and a sample of its members is inflated by Python's zlib
+        import zlib
+        hl = olen.cpu().numpy()
+        hso = so.cpu().numpy()
+        for i in (0, len(hl) // 2, len(hl) - 1):
+            member = bytes(slab[int(hso[i]):int(hso[i]) + int(hl[i])].cpu().numpy())
+            assert len(zlib.decompress(member)) > 0
+        return {"pack_GB_s": slab_bytes[0] / 1e9 / pack_s, "slab_bytes": slab_bytes[0], "slots": int(olen.numel()),
+                "exchange": "none (one GPU): zmi_pack_slab_dev over all slots, three members of the slab inflated on the host"}
     seen = [0]
 
     def consume(peer, lo, view):
@@ -490,13 +564,13 @@ def stitch_leg(e, zdist, dist, torch, out, olen, table, dev):
     dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    got = zdist.exchange_slabs_streaming(slab, slab_bytes, chunk_bytes=1 << 30, consume=consume, mode="allgather")
+    got = zdist.exchange_slabs_streaming(slab, slab_bytes, chunk_bytes=1 << 29, consume=consume, mode="allgather")
     torch.cuda.synchronize()
     dist.barrier()
     ex_s = zdist.max_over_ranks(time.perf_counter() - t0, dev)
     assert got == seen[0] == sum(slab_bytes) - slab_bytes[rank]
     return {"pack_GB_s": slab_bytes[rank] / 1e9 / pack_s, "slab_bytes": slab_bytes[rank],
-            "exchange": "all-gather of the slabs by direct grouped send/recv (one P2P pair per peer per 1 GiB round, no ring), staging reused",
+            "exchange": "all-gather of the slabs by direct grouped send/recv (one P2P pair per peer per 512 MiB round, no ring), staging reused",
             "exchange_s": ex_s, "received_GB_per_rank": got / 1e9, "exchange_GB_s_per_rank": got / 1e9 / ex_s if ex_s > 0 else None}
 
 
