@@ -66,6 +66,7 @@ struct zmi_timer {
 };
 enum { ZMI_K_CHECKSUM = 0, ZMI_K_LZ77 = 1, ZMI_K_ENCODE = 2, ZMI_K_INFLATE = 3, ZMI_K_VERIFY = 4, ZMI_K_GEN = 5, ZMI_K_RESOLVE = 6, ZMI_K_PACK = 7 };
 
+#define ZMI_HB_SLOTS 3   // host-buffer pipelines: chunks in flight (staging in, on the device, staging out)
 struct zmi_ctx {
     bool timing = false;
     std::vector<zmi_timer> timers;
@@ -79,7 +80,9 @@ struct zmi_ctx {
     zmi_buf inf_ptr;  // inflate of few streams: 4 B per output byte, the pointers of the jump resolve (resolve_jump.hip)
     zmi_buf st_in, st_out, st_meta;  // zmi_inflate_resume: staging of one host stream (kept across calls)
     // host-buffer batches (zmi_deflate_batch): two slots cycle through copy-in / kernels / copy-out on three streams
-    struct hb_slot { zmi_buf in, out, meta; hipEvent_t in_done, k_done, out_done; } hb[2];
+    struct hb_slot { zmi_buf in, out, meta; hipEvent_t in_done, k_done, out_done; } hb[ZMI_HB_SLOTS];
+    zmi_buf hb_slab[ZMI_HB_SLOTS];                              // device: the chunk's compressed streams packed densely (what travels back)
+    zmi_buf hb_pin_in[ZMI_HB_SLOTS], hb_pin_out[ZMI_HB_SLOTS], hb_pin_meta[ZMI_HB_SLOTS];   // pinned host staging of the two slots
     hipStream_t hs_in = nullptr, hs_k = nullptr, hs_out = nullptr;
     bool hb_live = false;
     uint64_t inflate_out_limit = 0;  // output bytes one inflate batch may cover; 0 = scratch_limit
@@ -131,6 +134,12 @@ extern "C" int zmi_ctx_destroy(zmi_ctx* c) {
             if (sl.out.p) (void)hipFree(sl.out.p);
             if (sl.meta.p) (void)hipFree(sl.meta.p);
             (void)hipEventDestroy(sl.in_done); (void)hipEventDestroy(sl.k_done); (void)hipEventDestroy(sl.out_done);
+        }
+        for (int k = 0; k < ZMI_HB_SLOTS; ++k) {
+            if (c->hb_slab[k].p) (void)hipFree(c->hb_slab[k].p);
+            if (c->hb_pin_in[k].p) (void)hipHostFree(c->hb_pin_in[k].p);
+            if (c->hb_pin_out[k].p) (void)hipHostFree(c->hb_pin_out[k].p);
+            if (c->hb_pin_meta[k].p) (void)hipHostFree(c->hb_pin_meta[k].p);
         }
         (void)hipStreamDestroy(c->hs_in); (void)hipStreamDestroy(c->hs_k); (void)hipStreamDestroy(c->hs_out);
     }
@@ -676,12 +685,60 @@ static int zmi_deflate_batch_simple(zmi_ctx* c, const uint8_t* in, const uint64_
 }
 
 
-// Host buffers, pipelined.  The batch is cut into chunks of consecutive shards; chunk k is copied in on one stream,
-// compressed on a second and copied out on a third, with two device slots: while chunk k is being compressed, chunk
-// k+1 arrives and chunk k-1 leaves (PCIe is full duplex).  A chunk's compressed streams keep their out_stride layout and
-// leave in ONE copy of the whole slot -- as many bytes as came in, instead of a length round trip and a copy per shard.
-// Issue order per iteration is in(k), kernels(k), out(k-1): also with pageable host memory, where the "async" copies
-// hold the calling thread, the copy of one chunk runs beside the kernels of another.
+// ---- host buffers, pipelined ----
+// A caller that hands over host memory pays PCIe both ways (the reference's own caller loop:
+// test-libz-rs-sys/examples/blogpost-compress.rs:43-122 -- every real zlib-rs user lives on this path).  Pageable memory is
+// the trap: hipMemcpy of pageable memory is the runtime's single-threaded bounce through a small pinned buffer (measured
+// round 2: 12-14 GiB/s end to end, with the kernels idle half of the time).  So the batch is cut into chunks that cycle
+// through three slots, and per chunk
+//   stage in   a few host threads copy the caller's shards into the slot's PINNED staging buffer (memcpy in parallel),
+//   H2D        one DMA copy of the whole chunk (stream hs_in),
+//   kernels    deflate + zmi_pack_slab_dev: the chunk's compressed streams as one dense slab (stream hs_k),
+//   D2H        the slab -- not the compress_bound-strided slots: 0.44 bytes per input byte instead of 1.125 -- into the
+//              slot's pinned output staging (stream hs_out),
+//   stage out  the host threads scatter the streams to the caller's out + i * out_stride.
+// Per chunk the host thread stages chunk k in, hands chunk k-2 out (the slot chunk k is about to use), issues chunk k's
+// copies and kernels and chunk k-1's slab copy: the device works on chunks k-1 and k while the host copies.
+#include <thread>
+#include <atomic>
+static unsigned zmi_host_threads() {
+    unsigned t = std::thread::hardware_concurrency() / 2u;
+    if (const char* e = zmi_tune("ZMI_HOST_THREADS")) { if (atoi(e) > 0) t = (unsigned)atoi(e); }
+    return t < 1u ? 1u : (t > 8u ? 8u : t);
+}
+struct zmi_copy_job { void* dst; const void* src; size_t n; };
+// the jobs' bytes split evenly over T threads (the calling thread is one of them)
+static void zmi_parallel_copy(const std::vector<zmi_copy_job>& jobs, unsigned T) {
+    size_t total = 0;
+    for (const zmi_copy_job& j : jobs) total += j.n;
+    if (total == 0) return;
+    if (T <= 1u || total < ((size_t)4 << 20)) { for (const zmi_copy_job& j : jobs) if (j.n) memcpy(j.dst, j.src, j.n); return; }
+    const size_t per = (total + T - 1u) / T;
+    auto work = [&](unsigned t) {
+        size_t lo = (size_t)t * per, hi = lo + per < total ? lo + per : total, at = 0;
+        for (const zmi_copy_job& j : jobs) {
+            const size_t a = at, b = at + j.n;
+            at = b;
+            if (b <= lo || a >= hi) continue;
+            const size_t f = a > lo ? a : lo, l = b < hi ? b : hi;
+            memcpy((uint8_t*)j.dst + (f - a), (const uint8_t*)j.src + (f - a), l - f);
+        }
+    };
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (std::thread& x : th) x.join();
+}
+static int zmi_reserve_pinned(zmi_buf& b, size_t bytes) {
+    if (bytes <= b.cap) return 0;
+    if (b.p) { (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+    const size_t want = (bytes + 0xFFFFFull) & ~(size_t)0xFFFFFull;
+    hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
+    if (e != hipSuccess) { b.p = nullptr; return zmi_fail(ZMI_E_NOMEM, "hipHostMalloc(staging)", e); }
+    b.cap = want;
+    return 0;
+}
+
 extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
                                  int level, int strategy, int wrap, uint8_t* out, uint64_t out_stride, uint32_t* out_len,
                                  int32_t* status) {
@@ -692,10 +749,11 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         if (in_len[i] > max_len) max_len = in_len[i];
     if (out_stride % 16u || out_stride < zmi_deflate_bound(max_len, wrap))
         return zmi_fail(ZMI_E_ARG, "out_stride must be a multiple of 16 and >= zmi_deflate_bound(max_len)");
-    // A chunk must fill the chip by itself: one workgroup per shard on 256 CUs wants >= 1024 shards per launch (measured:
-    // 128-shard chunks made the kernels, not PCIe, the bottleneck).  ZMI_HOST_CHUNK (bytes) overrides both bounds (tests).
-    uint64_t budget = 256ull << 20;
-    uint32_t min_count = 1024u;
+    // A chunk should fill the chip by itself: one workgroup per shard on 256 CUs wants a few hundred shards per launch (measured:
+    // 128-shard chunks made the kernels, not PCIe, the bottleneck; 512 shards of 1 MiB run within 10 % of the per-shard time of
+    // the largest launches).  ZMI_HOST_CHUNK (bytes) overrides both bounds (tests).
+    uint64_t budget = 512ull << 20;
+    uint32_t min_count = 384u;
     if (const char* e = zmi_tune("ZMI_HOST_CHUNK")) { if (atoll(e) > 0) { budget = (uint64_t)atoll(e); min_count = 1u; } }
     struct chunk { uint32_t first, count; uint64_t bytes; std::vector<uint64_t> doff; };
     std::vector<chunk> chunks;
@@ -712,7 +770,7 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         chunks.push_back(std::move(ck));
     }
     const char* pl = zmi_tune("ZMI_HOST_PIPELINE");   // 0: the plain copy-in / kernels / copy-out sequence
-    if (chunks.size() < 3 || (pl && !atoi(pl)))   // two chunks overlap too little to pay for the whole-slot copies
+    if (chunks.size() < 2 || (pl && !atoi(pl)))
         return zmi_deflate_batch_simple(c, in, in_off, in_len, n, level, strategy, wrap, out, out_stride, out_len, status);
     ZMI_ON_DEVICE(c);
     {
@@ -722,65 +780,135 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     uint64_t max_bytes = 0;
     uint32_t max_count = 0;
     for (const chunk& ck : chunks) { if (ck.bytes > max_bytes) max_bytes = ck.bytes; if (ck.count > max_count) max_count = ck.count; }
-    for (auto& sl : c->hb) {
+    // slab bound: every stream at most out_stride, but never more than the reference's bound for its own length
+    uint64_t max_slab = 0;
+    for (const chunk& ck : chunks) {
+        uint64_t sb = 0;
+        for (uint32_t i = 0; i < ck.count; ++i) sb += zmi_deflate_bound(in_len[ck.first + i], wrap) + 16u;
+        if (sb > max_slab) max_slab = sb;
+    }
+    // meta (device and pinned twin): doff u64[count] | in_len u32[count] | out_len u32[count] | status i32[count] | soff u64[count + 1]
+    const size_t meta_bytes = (size_t)max_count * 28u + 64u;
+    for (int k = 0; k < ZMI_HB_SLOTS; ++k) {
+        zmi_ctx::hb_slot& sl = c->hb[k];
         int rc = zmi_reserve(sl.in, (size_t)max_bytes + 64u);
         if (!rc) rc = zmi_reserve(sl.out, (size_t)max_count * out_stride + 64u);
-        if (!rc) rc = zmi_reserve(sl.meta, (size_t)max_count * 24u);   // off u64 | len u32 | out_len u32 | status i32
+        if (!rc) rc = zmi_reserve(sl.meta, meta_bytes);
+        if (!rc) rc = zmi_reserve(c->hb_slab[k], (size_t)max_slab + 64u);
+        if (!rc) rc = zmi_reserve_pinned(c->hb_pin_in[k], (size_t)max_bytes + 64u);
+        if (!rc) rc = zmi_reserve_pinned(c->hb_pin_out[k], (size_t)max_slab + 64u);
+        if (!rc) rc = zmi_reserve_pinned(c->hb_pin_meta[k], meta_bytes);
         if (rc) return rc;
     }
+    const unsigned T = zmi_host_threads();
     const size_t K = chunks.size();
-    auto meta_off = [&](zmi_ctx::hb_slot& sl) { return (uint64_t*)sl.meta.p; };
-    auto meta_len = [&](zmi_ctx::hb_slot& sl) { return (uint32_t*)((uint8_t*)sl.meta.p + (size_t)max_count * 8u); };
-    auto meta_olen = [&](zmi_ctx::hb_slot& sl) { return (uint32_t*)((uint8_t*)sl.meta.p + (size_t)max_count * 12u); };
-    auto meta_st = [&](zmi_ctx::hb_slot& sl) { return (int32_t*)((uint8_t*)sl.meta.p + (size_t)max_count * 16u); };
-    auto issue_in = [&](size_t k) -> int {
+    auto m_doff = [&](void* base) { return (uint64_t*)base; };
+    auto m_len = [&](void* base) { return (uint32_t*)((uint8_t*)base + (size_t)max_count * 8u); };
+    auto m_olen = [&](void* base) { return (uint32_t*)((uint8_t*)base + (size_t)max_count * 12u); };
+    auto m_st = [&](void* base) { return (int32_t*)((uint8_t*)base + (size_t)max_count * 16u); };
+    auto m_soff = [&](void* base) { return (uint64_t*)((uint8_t*)base + (size_t)max_count * 20u + 8u - ((size_t)max_count * 20u) % 8u); };
+    std::vector<hipEvent_t> sizes_done(ZMI_HB_SLOTS), slab_done(ZMI_HB_SLOTS);
+    for (int k = 0; k < ZMI_HB_SLOTS; ++k) {
+        ZMI_HIP(hipEventCreateWithFlags(&sizes_done[k], hipEventDisableTiming));
+        ZMI_HIP(hipEventCreateWithFlags(&slab_done[k], hipEventDisableTiming));
+    }
+    struct ev_guard { std::vector<hipEvent_t>& a; std::vector<hipEvent_t>& b; ~ev_guard() { for (hipEvent_t e : a) (void)hipEventDestroy(e); for (hipEvent_t e : b) (void)hipEventDestroy(e); } } evg{sizes_done, slab_done};
+    auto stage_in = [&](size_t k) -> int {   // host threads: caller memory -> pinned staging (the slot's previous H2D has finished)
         chunk& ck = chunks[k];
-        zmi_ctx::hb_slot& sl = c->hb[k & 1u];
-        if (k >= 2) ZMI_HIP(hipStreamWaitEvent(c->hs_in, sl.k_done, 0));   // the kernels of chunk k-2 have read this slot
-        for (uint32_t i = 0; i < ck.count;) {   // shards that lie back to back on both sides travel in one copy
-            const uint32_t g = ck.first + i;
-            uint32_t j = i;
-            uint64_t bytes = in_len[g];
-            while (j + 1 < ck.count && in_off[ck.first + j + 1] == in_off[ck.first + j] + in_len[ck.first + j] &&
-                   ck.doff[j + 1] == ck.doff[j] + in_len[ck.first + j] && bytes < (1ull << 30))
-                bytes += in_len[ck.first + ++j];
-            if (bytes) ZMI_HIP(hipMemcpyAsync((uint8_t*)sl.in.p + ck.doff[i], in + in_off[g], bytes, hipMemcpyHostToDevice, c->hs_in));
-            i = j + 1;
-        }
-        ZMI_HIP(hipMemcpyAsync(meta_off(sl), ck.doff.data(), (size_t)ck.count * 8u, hipMemcpyHostToDevice, c->hs_in));
-        ZMI_HIP(hipMemcpyAsync(meta_len(sl), in_len + ck.first, (size_t)ck.count * 4u, hipMemcpyHostToDevice, c->hs_in));
-        ZMI_HIP(hipEventRecord(sl.in_done, c->hs_in));
+        const int sl = (int)(k % ZMI_HB_SLOTS);
+        if (k >= ZMI_HB_SLOTS) ZMI_HIP(hipEventSynchronize(c->hb[sl].in_done));
+        std::vector<zmi_copy_job> jobs;
+        jobs.reserve(ck.count);
+        uint8_t* pin = (uint8_t*)c->hb_pin_in[sl].p;
+        for (uint32_t i = 0; i < ck.count; ++i) jobs.push_back({pin + ck.doff[i], in + in_off[ck.first + i], in_len[ck.first + i]});
+        zmi_parallel_copy(jobs, T);
+        memcpy(m_doff(c->hb_pin_meta[sl].p), ck.doff.data(), (size_t)ck.count * 8u);
+        memcpy(m_len(c->hb_pin_meta[sl].p), in_len + ck.first, (size_t)ck.count * 4u);
         return 0;
     };
-    auto issue_k = [&](size_t k) -> int {
+    auto issue_dev = [&](size_t k) -> int {   // H2D, kernels, pack, sizes back
         chunk& ck = chunks[k];
-        zmi_ctx::hb_slot& sl = c->hb[k & 1u];
+        const int s2 = (int)(k % ZMI_HB_SLOTS);
+        zmi_ctx::hb_slot& sl = c->hb[s2];
+        if (k >= ZMI_HB_SLOTS) ZMI_HIP(hipStreamWaitEvent(c->hs_in, sl.k_done, 0));   // the kernels of the chunk that had this slot have read it
+        ZMI_HIP(hipMemcpyAsync(sl.in.p, c->hb_pin_in[s2].p, (size_t)ck.bytes, hipMemcpyHostToDevice, c->hs_in));
+        ZMI_HIP(hipMemcpyAsync(sl.meta.p, c->hb_pin_meta[s2].p, (size_t)max_count * 12u, hipMemcpyHostToDevice, c->hs_in));
+        ZMI_HIP(hipEventRecord(sl.in_done, c->hs_in));
         ZMI_HIP(hipStreamWaitEvent(c->hs_k, sl.in_done, 0));
-        if (k >= 2) ZMI_HIP(hipStreamWaitEvent(c->hs_k, sl.out_done, 0));   // the output of chunk k-2 has left this slot
-        int rc = zmi_deflate_batch_dev(c, sl.in.p, meta_off(sl), meta_len(sl), ck.count, max_len, level, strategy, wrap, sl.out.p,
-                                       out_stride, meta_olen(sl), meta_st(sl), c->hs_k);
+        if (k >= ZMI_HB_SLOTS) ZMI_HIP(hipStreamWaitEvent(c->hs_k, slab_done[s2], 0));   // ... and its slab has left the device
+        int rc = zmi_deflate_batch_dev(c, sl.in.p, m_doff(sl.meta.p), m_len(sl.meta.p), ck.count, max_len, level, strategy, wrap, sl.out.p,
+                                       out_stride, m_olen(sl.meta.p), m_st(sl.meta.p), c->hs_k);
+        if (!rc) rc = zmi_pack_slab_dev(c, sl.out.p, out_stride, m_olen(sl.meta.p), ck.count, c->hb_slab[s2].p, c->hb_slab[s2].cap,
+                                        m_soff(sl.meta.p), c->hs_k);
         if (rc) return rc;
         ZMI_HIP(hipEventRecord(sl.k_done, c->hs_k));
-        return 0;
-    };
-    auto issue_out = [&](size_t k) -> int {
-        chunk& ck = chunks[k];
-        zmi_ctx::hb_slot& sl = c->hb[k & 1u];
         ZMI_HIP(hipStreamWaitEvent(c->hs_out, sl.k_done, 0));
-        ZMI_HIP(hipMemcpyAsync(out + (uint64_t)ck.first * out_stride, sl.out.p, (size_t)ck.count * out_stride, hipMemcpyDeviceToHost, c->hs_out));
-        ZMI_HIP(hipMemcpyAsync(out_len + ck.first, meta_olen(sl), (size_t)ck.count * 4u, hipMemcpyDeviceToHost, c->hs_out));
-        ZMI_HIP(hipMemcpyAsync(status + ck.first, meta_st(sl), (size_t)ck.count * 4u, hipMemcpyDeviceToHost, c->hs_out));
-        ZMI_HIP(hipEventRecord(sl.out_done, c->hs_out));
+        // out_len | status | slab offsets travel first: the host needs the slab's size to copy exactly that
+        ZMI_HIP(hipMemcpyAsync((uint8_t*)c->hb_pin_meta[s2].p + (size_t)max_count * 12u, (uint8_t*)sl.meta.p + (size_t)max_count * 12u,
+                               meta_bytes - (size_t)max_count * 12u, hipMemcpyDeviceToHost, c->hs_out));
+        ZMI_HIP(hipEventRecord(sizes_done[s2], c->hs_out));
         return 0;
     };
+    auto issue_slab = [&](size_t k) -> int {   // D2H of exactly the slab
+        chunk& ck = chunks[k];
+        const int s2 = (int)(k % ZMI_HB_SLOTS);
+        ZMI_HIP(hipEventSynchronize(sizes_done[s2]));
+        const uint64_t total = m_soff(c->hb_pin_meta[s2].p)[ck.count];
+        if (total > c->hb_slab[s2].cap) return zmi_fail(ZMI_E_HIP, "slab larger than its bound");
+        if (total) ZMI_HIP(hipMemcpyAsync(c->hb_pin_out[s2].p, c->hb_slab[s2].p, (size_t)total, hipMemcpyDeviceToHost, c->hs_out));
+        ZMI_HIP(hipEventRecord(slab_done[s2], c->hs_out));
+        return 0;
+    };
+    auto stage_out = [&](size_t k) -> int {   // host threads: pinned slab -> the caller's slots
+        chunk& ck = chunks[k];
+        const int s2 = (int)(k % ZMI_HB_SLOTS);
+        ZMI_HIP(hipEventSynchronize(slab_done[s2]));
+        const uint8_t* pm = (const uint8_t*)c->hb_pin_meta[s2].p;
+        const uint32_t* ol = m_olen((void*)pm);
+        const uint64_t* so = m_soff((void*)pm);
+        memcpy(out_len + ck.first, ol, (size_t)ck.count * 4u);
+        memcpy(status + ck.first, m_st((void*)pm), (size_t)ck.count * 4u);
+        std::vector<zmi_copy_job> jobs;
+        jobs.reserve(ck.count);
+        const uint8_t* pin = (const uint8_t*)c->hb_pin_out[s2].p;
+        for (uint32_t i = 0; i < ck.count; ++i)
+            if (m_st((void*)pm)[i] == 0 && ol[i] <= out_stride) jobs.push_back({out + (uint64_t)(ck.first + i) * out_stride, pin + so[i], ol[i]});
+        zmi_parallel_copy(jobs, T);
+        return 0;
+    };
+    // Two host threads.  The caller's thread stages chunks in and issues their device work as soon as their slot is free;
+    // a second thread follows the results: it waits for a chunk's sizes, issues the copy of exactly its slab, and scatters
+    // it.  (One thread doing both waited for results between two issues, and the device idled a third of the time: 18 GiB/s.)
+    std::atomic<int> issued{0}, finished{0}, failed{0};
+    const int dev_id = c->device;
+    const unsigned T_in = T > 1u ? T - T / 3u : 1u, T_out = T > 2u ? T / 3u : 1u;
+    auto consumer = [&]() {
+        (void)hipSetDevice(dev_id);
+        for (size_t k = 0; k < K; ++k) {
+            while (issued.load(std::memory_order_acquire) <= (int)k) {
+                if (failed.load(std::memory_order_acquire)) return;
+                std::this_thread::yield();
+            }
+            int r = issue_slab(k);
+            if (!r) r = stage_out(k);
+            if (r) { failed.store(r, std::memory_order_release); return; }
+            finished.store((int)k + 1, std::memory_order_release);
+        }
+    };
+    (void)T_in; (void)T_out;
+    std::thread follower(consumer);
     int rc = 0;
     for (size_t k = 0; k < K && !rc; ++k) {
-        rc = issue_in(k);
-        if (!rc) rc = issue_k(k);
-        if (!rc && k >= 1) rc = issue_out(k - 1);
+        while (finished.load(std::memory_order_acquire) + ZMI_HB_SLOTS <= (int)k && !failed.load(std::memory_order_acquire)) std::this_thread::yield();   // slot free
+        if (failed.load(std::memory_order_acquire)) break;
+        rc = stage_in(k);
+        if (!rc) rc = issue_dev(k);
+        if (!rc) issued.store((int)k + 1, std::memory_order_release);
     }
-    if (!rc) rc = issue_out(K - 1);
-    // nothing of this call may still be in flight when it returns (the host vectors above are sources of copies)
+    if (rc) failed.store(rc, std::memory_order_release);
+    follower.join();
+    if (!rc) rc = failed.load();
+    // nothing of this call may still be in flight when it returns
     (void)hipStreamSynchronize(c->hs_in);
     (void)hipStreamSynchronize(c->hs_k);
     (void)hipStreamSynchronize(c->hs_out);
