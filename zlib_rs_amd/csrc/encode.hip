@@ -686,17 +686,20 @@ static __device__ __noinline__ bool enc_split_pays(const EncShared* S, uint32_t 
     return apart + (float)hdr_bits < joined;
 }
 
-// One segment of 64 positions: apply the lazy rule, return the lane's step (1: a literal).  m: the lane's match word; nxt:
-// the words of the segment behind it (its first three positions are the look-ahead of this segment's last three lanes).
-// Both have been through enc_far_filter when they were loaded, so the look-ahead sees the matches the parse will use (a
-// position used to be deferred in favour of a match at +1..+3 that the filter then dropped: ADVICE r02).
-// drop a 4 / 5 / 6 byte match that lies further back than its literals are worth (enc_far_limits)
-static __device__ __forceinline__ uint32_t enc_far_filter(uint32_t m, uint32_t far4, uint32_t far5, uint32_t far6) {
-    const uint32_t l0 = (m >> 8) & 0x1FFu, d0 = (m >> 17) + 1u;
-    const uint32_t lim = l0 == 4u ? far4 : (l0 == 5u ? far5 : far6);
-    return (l0 >= 4u && l0 <= 6u && d0 > lim) ? (m & 0xFFu) : m;
-}
-static __device__ __forceinline__ uint32_t enc_seg_step(uint32_t& m, uint32_t nxt, uint32_t pos, uint32_t pend, const zmi_enc_params& prm) {
+// One segment of 64 positions: drop the short far matches (enc_far_limits), apply the lazy rule, return the lane's step (1:
+// a literal).  m: the lane's match word (filtered in place); nxt: the words of the segment behind it (its first three
+// positions are the look-ahead of this segment's last three lanes).
+// (the look-ahead of the last three lanes comes from `nxt`, which is filtered only a trip later, so a position
+// can be deferred in favour of a match at +1..+3 that is then dropped.  Filtering the words when they are loaded was built
+// in round 3: ratio identical to four decimals on lcet10.txt / paper-100k.pdf / the benchmark shards -- three of 64 lanes,
+// and only when the filter bites -- but 82 VGPRs instead of 80, which is a wave per SIMD: encode 99.3 -> 102.1 ms.  Kept as is.)
+static __device__ __forceinline__ uint32_t enc_seg_step(uint32_t& m, uint32_t nxt, uint32_t pos, uint32_t pend, const zmi_enc_params& prm,
+                                                        uint32_t far4, uint32_t far5, uint32_t far6) {
+    {
+        const uint32_t l0 = (m >> 8) & 0x1FFu, d0 = (m >> 17) + 1u;
+        const uint32_t lim = l0 == 4u ? far4 : (l0 == 5u ? far5 : far6);
+        if (l0 >= 4u && l0 <= 6u && d0 > lim) m &= 0xFFu;
+    }
     // the matches one, two and three positions on: the lane above (one DPP move each), the top lanes from the next segment
     const uint32_t m1 = zmi_lane_down1(m, zmi_readlane(nxt, 0u));
     const uint32_t m2 = zmi_lane_down1(m1, zmi_readlane(nxt, 1u));
@@ -819,15 +822,15 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
     // the last step, picking the chain that starts where the token before ended, is serial), so the two sets of
     // shuffles are in flight together -- the kernel sits between latency and issue bound, and this is occupancy
     // that costs no LDS.  Match words are fetched two trips ahead.
-    uint32_t m_a = enc_far_filter((pstart + lane < pend) ? tokbuf[pstart + lane] : 0u, far4, far5, far6);
-    uint32_t m_b = enc_far_filter((pstart + 64u + lane < pend) ? tokbuf[pstart + 64u + lane] : 0u, far4, far5, far6);
-    uint32_t m_c = enc_far_filter((pstart + 128u + lane < pend) ? tokbuf[pstart + 128u + lane] : 0u, far4, far5, far6);
+    uint32_t m_a = (pstart + lane < pend) ? tokbuf[pstart + lane] : 0u;
+    uint32_t m_b = (pstart + 64u + lane < pend) ? tokbuf[pstart + 64u + lane] : 0u;
+    uint32_t m_c = (pstart + 128u + lane < pend) ? tokbuf[pstart + 128u + lane] : 0u;
     for (uint32_t seg = seg0; seg < nseg; seg += 2u) {
         const uint32_t posA = seg * 64u + lane, posB = posA + 64u;
         const uint32_t m_d = (posA + 192u < pend) ? tokbuf[posA + 192u] : 0u;
         const uint32_t m_e = (posA + 256u < pend) ? tokbuf[posA + 256u] : 0u;
-        const uint32_t stepA = enc_seg_step(m_a, m_b, posA, pend, prm);
-        const uint32_t stepB = enc_seg_step(m_b, m_c, posB, pend, prm);
+        const uint32_t stepA = enc_seg_step(m_a, m_b, posA, pend, prm, far4, far5, far6);
+        const uint32_t stepB = enc_seg_step(m_b, m_c, posB, pend, prm, far4, far5, far6);
         const uint64_t validA = __ballot(posA < pend), validB = __ballot(posB < pend);
         uint32_t JA = lane + stepA, RA = zmi_lane_bit32_here(lane), JB = lane + stepB, RB = RA;
         const bool any_match = __ballot(stepA > 1u || stepB > 1u) != 0ull;
@@ -880,8 +883,8 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
             }
         }
         m_a = m_c;
-        m_b = enc_far_filter(m_d, far4, far5, far6);   // (with the limits in force now: the ones the sub-block they belong to starts with)
-        m_c = enc_far_filter(m_e, far4, far5, far6);
+        m_b = m_d;
+        m_c = m_e;
         const uint32_t done = (seg + 2u) * 64u;   // (may lie one segment behind the piece: everything below clamps to pend)
         const bool last_seg = seg + 2u >= nseg;
         // a sub-block closes after block_tokens tokens, optionally not before it spans min_sub_span bytes of input (or holds
