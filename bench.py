@@ -477,10 +477,32 @@ def stream_abi_leg(level):
     rc, ocomp = o.deflate(data, level, 2)
     to = time.perf_counter() - t0
     assert o.inflate(comp, len(data), 2)[1] == data          # the oracle reads the GPU's stream
+    # the same bytes as a stream of the CPU oracle (the reference's algorithm: blocks of 16 383 symbols, no flush points --
+    # what an unmodified caller's inflate() meets most often), through inflate() and through one uncompress2()-style call
+    t0 = time.perf_counter()
+    rc2, back2, unused2 = H.inflate_stream(lib, ocomp, 31, chunk_in=1 << 22, chunk_out=1 << 22)
+    ti2 = time.perf_counter() - t0
+    assert rc2 == 1 and back2 == data and unused2 == 0, "stream ABI inflate of the oracle's stream failed"
+    import zlib
+    zc = zlib.compress(data, level)
+    dst = C.create_string_buffer(len(data))
+    dl = C.c_ulong(len(data))
+    lib.uncompress(dst, C.byref(dl), zc, len(zc))
+    dl = C.c_ulong(len(data))
+    t0 = time.perf_counter()
+    rc3 = lib.uncompress(dst, C.byref(dl), zc, len(zc))
+    tu = time.perf_counter() - t0
+    assert rc3 == 0 and dl.value == len(data) and dst.raw[:len(data)] == data
+    t0 = time.perf_counter()
+    zlib.decompress(zc)
+    tz = time.perf_counter() - t0
     return {"input_bytes": len(data), "path": "deflateInit2_(level, gzip) + deflate() in 4 MiB chunks + inflate() back, one thread, host buffers",
             "deflate_GiB_s": len(data) / GIB / td, "inflate_GiB_s": len(data) / GIB / ti, "ratio": len(data) / float(len(comp)),
+            "inflate_of_cpu_made_stream_GiB_s": len(data) / GIB / ti2, "uncompress_of_zlib_stream_GiB_s": len(data) / GIB / tu,
+            "system_zlib_inflate_single_thread_GiB_s": len(data) / GIB / tz,
             "oracle_single_thread_GiB_s": len(data) / GIB / to, "oracle_ratio": len(data) / float(len(ocomp)),
-            "note": "one stream = 16 segments of 1 MiB on the device: a plumbing check, not a throughput configuration"}
+            "note": "one stream: deflate = 16 segments of 1 MiB on the device; inflate = one workgroup of 8 waves (a pass covers at most "
+                    "one deflate block: this engine's own streams cut a block every few KiB of drifting data, the CPU's every 16 383 symbols)"}
 
 
 def real_data_leg(e, torch, dev, B):
