@@ -6,6 +6,7 @@ cd "$(dirname "$0")/.."
 make -s -C tests/emu libzmi355_emu_asan.so
 ASAN=$(gcc -print-file-name=libasan.so)
 export ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0
+export ZMI_NO_ALLOC_FAULTS=1
 LD_PRELOAD=$ASAN python - <<'PY'
 import ctypes as C, json, os, sys, tempfile, zlib
 sys.path.insert(0, "tests")

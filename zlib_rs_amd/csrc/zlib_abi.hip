@@ -287,8 +287,9 @@ size_t segment_bytes() {  // 1 MiB segments; ZMI_ABI_SEGMENT (bytes, multiple of
 // returns 0 or a negative zlib code
 // wrap 1 / 2: *check receives the Adler-32 / CRC-32 of the n bytes (per segment on the GPU, where the data is;
 // stitched with the combine algebra, crc32/combine.rs, adler32 combine lib.rs:372)
+template <class OutVec>
 int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_t hist_len, int level, int strategy, bool finish,
-                         std::vector<uint8_t>& out, int wrap = 0, uint32_t* check = nullptr, size_t* last_at = nullptr,
+                         OutVec& out, int wrap = 0, uint32_t* check = nullptr, size_t* last_at = nullptr,
                          int wbits = 15) {
     if (check) *check = wrap == 1 ? 1u : 0u;
     if (last_at) *last_at = out.size();
@@ -367,7 +368,8 @@ int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_
 
 // one-stream inflate on the GPU.  status: zlib code (0 = complete), detail 1 = need input, 2 = need output.
 // dict / dict_len: preset dictionary (at most its last 32 KiB matter), placed directly in front of the output.
-int gpu_inflate_stream(const uint8_t* in, size_t n, int wrap, std::vector<uint8_t>& out, size_t cap, uint32_t* in_used,
+template <class OutVec>
+int gpu_inflate_stream(const uint8_t* in, size_t n, int wrap, OutVec& out, size_t cap, uint32_t* in_used,
                        int32_t* status, int32_t* detail, const uint8_t* dict = nullptr, size_t dict_len = 0) {
     AbiLease lease;
     zmi_ctx* c = lease.ctx;
@@ -410,23 +412,56 @@ int gpu_inflate_stream(const uint8_t* in, size_t n, int wrap, std::vector<uint8_
 
 enum { KIND_DEFLATE = 0x5A44, KIND_INFLATE = 0x5A49 };
 
+// Every buffer a stream owns comes from the stream's zalloc and goes back through its zfree, as the reference's whole
+// arena does (zlib-rs/src/deflate.rs:252-439, zlib-rs/src/allocate.rs:200-222): a caller that counts or limits its
+// allocations (the reference's own tests do: mem_setup / mem_limit in test-libz-rs-sys) sees all host memory of the
+// stream.  (Device memory is the GPU's: it has no zalloc.)  A failed zalloc surfaces as std::bad_alloc, which every entry
+// point turns into Z_MEM_ERROR.
+struct ZCalls { alloc_func za = nullptr; free_func zf = nullptr; voidpf op = nullptr; };
+template <class T>
+struct ZAlloc {
+    using value_type = T;
+    using propagate_on_container_copy_assignment = std::false_type;   // a copied state keeps the allocator of ITS stream
+    using propagate_on_container_move_assignment = std::false_type;
+    using propagate_on_container_swap = std::false_type;
+    ZCalls c;
+    ZAlloc() = default;
+    explicit ZAlloc(const ZCalls& cc) : c(cc) {}
+    template <class U> ZAlloc(const ZAlloc<U>& o) : c(o.c) {}
+    T* allocate(size_t n) {
+        const size_t bytes = n * sizeof(T);
+        void* p;
+        if (!c.za) p = malloc(bytes ? bytes : 1);
+        else if (bytes <= 0xFFFFFFFFull) p = c.za(c.op, (uInt)(bytes ? bytes : 1), 1u);   // zalloc(opaque, items, size): 32-bit counts
+        else p = c.za(c.op, (uInt)((bytes + 65535u) >> 16), 65536u);
+        if (!p) throw std::bad_alloc();
+        return (T*)p;
+    }
+    void deallocate(T* p, size_t) { if (c.zf) c.zf(c.op, p); else free(p); }
+    template <class U> bool operator==(const ZAlloc<U>& o) const { return c.za == o.c.za && c.zf == o.c.zf && c.op == o.c.op; }
+    template <class U> bool operator!=(const ZAlloc<U>& o) const { return !(*this == o); }
+};
+using Bytes = std::vector<uint8_t, ZAlloc<uint8_t>>;
+
 struct DeflateState {
+    ZCalls zc;                     // the stream's allocator: every Bytes member below allocates through it
+    explicit DeflateState(const ZCalls& z) : zc(z), in(ZAlloc<uint8_t>(z)), pending(ZAlloc<uint8_t>(z)), hist(ZAlloc<uint8_t>(z)), last_seg(ZAlloc<uint8_t>(z)) {}
     int kind = KIND_DEFLATE;
     int level = 6, strategy = 0, wrap = 1, wbits = 15;
     bool header_done = false, finished = false, trailer_done = false;
-    std::vector<uint8_t> in;       // input not yet compressed
-    std::vector<uint8_t> pending;  // compressed bytes not yet handed to the caller
+    Bytes in;       // input not yet compressed
+    Bytes pending;  // compressed bytes not yet handed to the caller
     size_t pending_pos = 0;
     uint32_t adler = 1, crc = 0;
     uint64_t total_len = 0;
     int last_flush = -2;
-    std::vector<uint8_t> hist;     // the up to 32 KiB the stream has in front of `in`: earlier input or the preset dictionary
+    Bytes hist;     // the up to 32 KiB the stream has in front of `in`: earlier input or the preset dictionary
     bool dict_set = false;         // zlib wrapper: header announces the dictionary (FDICT + DICTID)
     uint32_t dictid = 0;
     gz_headerp gzhead = nullptr;   // deflateSetHeader: read when the header is written, as the reference does
     uint32_t prime_val = 0;        // deflatePrime: bits (< 8) waiting in front of the next compressed data
     int prime_bits = 0;
-    std::vector<uint8_t> last_seg; // compressed bytes of the most recent segment (deflateUsed decodes them on demand)
+    Bytes last_seg; // compressed bytes of the most recent segment (deflateUsed decodes them on demand)
     bool last_seg_final = false;
     int used_bits = 0;             // deflateUsed: 0 = no flush yet, -1 = not computed for last_seg yet
 };
@@ -436,20 +471,23 @@ struct DeflateState {
 // equivalent facts in Mode / BitReader / Window (zlib-rs/src/inflate.rs:288-320).
 enum { IM_HEAD = 0, IM_DICT, IM_BLOCKS, IM_TRAILER, IM_DONE, IM_BAD };
 struct InflateState {
+    ZCalls zc;
+    explicit InflateState(const ZCalls& z) : zc(z), in(ZAlloc<uint8_t>(z)), hist(ZAlloc<uint8_t>(z)), out(ZAlloc<uint8_t>(z)), tmp(ZAlloc<uint8_t>(z)),
+                                             window(ZAlloc<uint8_t>(z)), dict(ZAlloc<uint8_t>(z)) {}
     int kind = KIND_INFLATE;
     int wrap = 1, wbits = 15;
     int hdr_wbits = 0;             // windowBits 0: the window size the zlib header announces
     int mode = IM_HEAD;
     int form = -1;                 // wrapper found: 0 raw, 1 zlib, 2 gzip (-1: no header seen yet)
-    std::vector<uint8_t> in;       // input from the checkpoint on; the next block starts at bit `sbit` of in[0]
+    Bytes in;       // input from the checkpoint on; the next block starts at bit `sbit` of in[0]
     uint32_t sbit = 0;
     size_t tried = (size_t)-1;     // in.size() at the last decode attempt
     size_t stop = 0;               // how far into `in` the decoder got (inflateSync searches from there)
-    std::vector<uint8_t> hist;     // the up to 32 KiB of output in front of the checkpoint; starts as the preset dictionary
+    Bytes hist;     // the up to 32 KiB of output in front of the checkpoint; starts as the preset dictionary
     size_t pend = 0;               // decoded bytes behind the checkpoint that are already queued
-    std::vector<uint8_t> out;      // decoded bytes not yet handed to the caller
+    Bytes out;      // decoded bytes not yet handed to the caller
     size_t out_pos = 0;
-    std::vector<uint8_t> tmp;      // decode target of one attempt
+    Bytes tmp;      // decode target of one attempt
     uint32_t check = 1;            // Adler-32 / CRC-32 of the bytes handed to the caller
     uint32_t want_check = 0;       // trailer values, compared when the last byte has been handed out
     uint32_t want_len = 0;
@@ -461,13 +499,13 @@ struct InflateState {
     bool have_dict = false;
     uint32_t dictid = 0;
     gz_headerp gzhead = nullptr;   // inflateGetHeader
-    std::vector<uint8_t> window;   // the last 32 KiB handed to the caller (inflateGetDictionary)
+    Bytes window;   // the last 32 KiB handed to the caller (inflateGetDictionary)
     uint64_t bias = 0;             // buffered bytes inflateSync reported as not yet consumed
     int sync_have = 0;             // inflateSync: marker bytes matched so far
     bool in_sync = false;
     int last_block = 0;
     uint32_t primed = 0;           // bits at the front of `in` that came from inflatePrime
-    std::vector<uint8_t> dict;     // the preset dictionary (inflateGetDictionary shows it in front of the output)
+    Bytes dict;     // the preset dictionary (inflateGetDictionary shows it in front of the output)
     uint8_t* back_window = nullptr;   // inflateBack: the caller's window
     // inflate(Z_BLOCK) / inflate(Z_TREES) (inflate.rs:1276-1284,1323,1369,1772,1856-1873): the device decode stops at the
     // next block boundary / behind the next block header; the call that reaches the stop reports it in data_type
@@ -480,7 +518,8 @@ struct InflateState {
 
 // length of the gzip header at the start of `in` (inflate.rs:1063-1275): 0 while it is incomplete, -1 with *err
 // set when it is invalid; fills *h (may be null) once the header is complete
-long gzip_header_len(const std::vector<uint8_t>& in, gz_header* h, bool verify, const char** err) {
+template <class InVec>
+long gzip_header_len(const InVec& in, gz_header* h, bool verify, const char** err) {
     if (in.size() < 10) return 0;
     if (in[2] != 8) { *err = "unknown compression method"; return -1; }
     const uint8_t flg = in[3];
@@ -538,7 +577,7 @@ T* alloc_state(z_streamp strm) {
     if (!strm->zalloc || !strm->zfree) { strm->zalloc = default_zalloc; strm->zfree = default_zfree; strm->opaque = nullptr; }
     void* mem = strm->zalloc(strm->opaque, 1, (uInt)sizeof(T));
     if (!mem) return nullptr;
-    return new (mem) T();
+    return new (mem) T(ZCalls{strm->zalloc, strm->zfree, strm->opaque});
 }
 template <typename T>
 void free_state(z_streamp strm, T* st) {
@@ -641,7 +680,8 @@ int compress_buffered(DeflateState* s, bool finish, bool full_flush = false) {
     }
     return Z_OK;
 }
-size_t drain(z_streamp strm, std::vector<uint8_t>& buf, size_t& pos) {
+template <class Vec>
+size_t drain(z_streamp strm, Vec& buf, size_t& pos) {
     size_t n = buf.size() - pos;
     if (n > strm->avail_out) n = strm->avail_out;
     if (n) {
@@ -983,8 +1023,9 @@ int deflateReset(z_streamp strm) {
     DeflateState* s = dstate(strm);
     if (!s) return Z_STREAM_ERROR;
     int level = s->level, strategy = s->strategy, wrap = s->wrap, wbits = s->wbits;
+    const ZCalls zc = s->zc;
     s->~DeflateState();
-    new (s) DeflateState();
+    new (s) DeflateState(zc);
     s->level = level; s->strategy = strategy; s->wrap = wrap; s->wbits = wbits;
     strm->total_in = strm->total_out = 0;
     strm->msg = nullptr;
@@ -1118,7 +1159,7 @@ int deflateUsed(z_streamp strm, int* bits) {
 int deflateGetDictionary(z_streamp strm, Bytef* dictionary, uInt* dictLength) {   // deflate.rs: the current window
     DeflateState* s = dstate(strm);
     if (!s) return Z_STREAM_ERROR;
-    std::vector<uint8_t> w(s->hist);
+    std::vector<uint8_t> w(s->hist.begin(), s->hist.end());
     w.insert(w.end(), s->in.begin(), s->in.end());
     if (w.size() > 32768u) w.erase(w.begin(), w.end() - 32768);
     if (dictionary && !w.empty()) memcpy(dictionary, w.data(), w.size());
@@ -1138,7 +1179,7 @@ int deflateCopy(z_streamp dest, z_streamp source) {   // deflate.rs: a deep copy
     *dest = *source;
     DeflateState* d = alloc_state<DeflateState>(dest);
     if (!d) { dest->state = nullptr; return Z_MEM_ERROR; }
-    *d = *s;
+    { const ZCalls own = d->zc; *d = *s; d->zc = own; }   // (the buffers are copied into dest's allocator, which stays dest's)
     dest->state = (internal_state*)d;
     return Z_OK;
     ZMI_ABI_CATCH(Z_MEM_ERROR)
@@ -1152,7 +1193,7 @@ int compress2_z(Bytef* dest, z_size_t* destLen, const Bytef* source, z_size_t so
     if (!dest || !destLen || (!source && sourceLen)) return Z_STREAM_ERROR;
     if (level == Z_DEFAULT_COMPRESSION) level = 6;
     if (level < 0 || level > 9) return Z_STREAM_ERROR;
-    DeflateState s;
+    DeflateState s{ZCalls{}};   // (compress2 has no z_stream: malloc / free, as the reference's own)
     s.level = level;
     s.in.assign(source, source + sourceLen);
     int rc = compress_buffered(&s, true);
@@ -1188,8 +1229,9 @@ static int parse_window_bits(int windowBits, int* wrap, int* wb) {   // inflate.
 static void inflate_reset_state(z_streamp strm, InflateState* s) {
     const int wrap = s->wrap, wb = s->wbits;
     uint8_t* bw = s->back_window;
+    const ZCalls zc = s->zc;
     s->~InflateState();
-    new (s) InflateState();
+    new (s) InflateState(zc);
     s->wrap = wrap; s->wbits = wb; s->back_window = bw;
     strm->total_in = strm->total_out = 0;
     strm->msg = nullptr;
@@ -1366,7 +1408,7 @@ int inflateGetDictionary(z_streamp strm, Bytef* dictionary, uInt* dictLength) { 
     InflateState* s = istate(strm);
     if (!s) return Z_STREAM_ERROR;
     // what the stream has produced up to the caller's read position, preceded by the preset dictionary
-    std::vector<uint8_t> w(s->dict);
+    std::vector<uint8_t> w(s->dict.begin(), s->dict.end());
     w.insert(w.end(), s->window.begin(), s->window.end());
     if (w.size() > 32768u) w.erase(w.begin(), w.end() - 32768);
     if (dictionary && !w.empty()) memcpy(dictionary, w.data(), w.size());
@@ -1388,9 +1430,9 @@ int inflateCopy(z_streamp dest, z_streamp source) {
     *dest = *source;
     InflateState* d = alloc_state<InflateState>(dest);
     if (!d) { dest->state = nullptr; return Z_MEM_ERROR; }
-    std::vector<uint8_t> scratch;
+    Bytes scratch(s->tmp.get_allocator());
     scratch.swap(s->tmp);   // the decode target of the last attempt is no state: not copied
-    *d = *s;
+    { const ZCalls own = d->zc; *d = *s; d->zc = own; }
     scratch.swap(s->tmp);
     dest->state = (internal_state*)d;
     return Z_OK;
