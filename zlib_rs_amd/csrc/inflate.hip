@@ -87,6 +87,9 @@ struct InfShared {
             uint32_t cnt[16];
             uint32_t offs[16];
             uint32_t fcode[16];   // first canonical code of every length
+            uint16_t gid[288];    // second-level tables (inf_build): the run a long code belongs to (bit 15: it starts the run),
+            uint16_t goff[288];   // ... a run's table offset
+            uint8_t gsb[288];     // ... and index bits
             __attribute__((aligned(16))) uint8_t inbuf[INF_CHUNK + 32];  // staged compressed input (one coalesced load per KiB)
         };
         // a fast pass needs none of those (only the tables) and reloads the chunk behind itself: its staged input lies over
@@ -94,6 +97,8 @@ struct InfShared {
         __attribute__((aligned(16))) uint8_t fb[INF_FAST_BYTES];
     };
 };
+
+static_assert(sizeof(InfShared) <= 9152u, "the decode kernel's LDS per stream (17 streams per CU)");
 
 // One per workgroup, at file scope: a function that is not inlined reaches it by name, as LDS (through a pointer argument
 // it would be a generic pointer -- a 64-bit add and a null check in front of every access)
@@ -264,48 +269,62 @@ static __device__ __noinline__ uint32_t inf_build(InfShared* S_, uint32_t kind, 
     zmi_wave_sync();
     if (maxl <= root) return 0u;
 
-    // codes longer than the root, in canonical order: second-level tables
-    uint32_t k = zmi_uniform(S->offs[root + 1u]);
-    uint32_t curlen = root + 1u;
-    uint32_t code = zmi_uniform(S->fcode[root + 1u]);   // canonical code of the current symbol (MSB-first)
-    uint32_t used = rsize;   // next free sub-table slot
-    uint32_t sub_prefix = 0xFFFFFFFFu, sub_off = 0, sub_bits = 0;
-    for (; k < ncoded; ++k) {
-        const uint32_t sym = zmi_uniform(S->sorted[k]);
-        const uint32_t l = zmi_uniform(S->lens[sym]);
-        code <<= (l - curlen);
-        curlen = l;
-        const uint32_t ent = inf_entry(kind, sym, l);
-        const uint32_t rev = __brev(code) >> (32u - l);  // LSB-first bit pattern
-        const uint32_t prefix = rev & (rsize - 1u);
-        if (prefix != sub_prefix) {
-            // new sub-table: the codes sharing this root prefix are contiguous in canonical
-            // order; the longest of them sizes the table
-            uint32_t last = l;
-            {
-                uint32_t c = code, cl = l;
-                for (uint32_t k2 = k + 1u; k2 < ncoded; ++k2) {
-                    uint32_t l2 = zmi_uniform(S->lens[zmi_uniform(S->sorted[k2])]);
-                    c = (c + 1u) << (l2 - cl);
-                    cl = l2;
-                    if ((c >> (cl - root)) != (code >> (l - root))) break;
-                    last = l2;
-                }
-            }
-            sub_prefix = prefix;
-            sub_bits = last - root;
-            sub_off = used;
-            used += 1u << sub_bits;
-            if (used > cap) return 2u;
-            for (uint32_t j = lane; j < (1u << sub_bits); j += 64u) tab[sub_off + j] = INF_ENTRY(0, INF_OP_BAD, 0);
-            if (lane == 0) tab[prefix] = INF_ENTRY(sub_off, INF_OP_LINK | sub_bits, root);
-            zmi_wave_sync();
+    // Codes longer than the root: second-level tables, lane-parallel.  In canonical order (length, then symbol -- the order
+    // of S->sorted) the codes that share their first `root` bits are neighbours and their lengths do not decrease, so a
+    // sub-table is a run of that order, sized by the run's LAST code.  Three sweeps over the at most 286 long codes:
+    // runs (a code starts one when its prefix differs from its neighbour's; the code in front of it closes the run before
+    // and sizes it), offsets (a scan over the runs' sizes), entries.  (Until round 3 this was a serial walk with a
+    // look-ahead per run: 75-200 K cycles per block on data with many long codes -- the record and random-walk classes of
+    // the benchmark spent a quarter to a half of their decode time here.)
+    const uint32_t k0 = zmi_uniform(S->offs[root + 1u]);
+    const uint32_t nlong = ncoded - k0;
+    uint32_t ngroups = 0, carry_p = 0xFFFFFFFFu, carry_l = 0;
+    for (uint32_t base = 0; base < nlong; base += 64u) {
+        const bool in = base + lane < nlong;
+        const uint32_t k = k0 + base + lane;
+        const uint32_t sym = in ? S->sorted[k] : 0u;
+        const uint32_t l = in ? S->lens[sym] : 16u;
+        const uint32_t code = in ? S->fcode[l] + (k - S->offs[l]) : 0u;          // canonical, MSB first
+        const uint32_t pfx = in ? code >> (l - root) : 0xFFFFFFFEu;
+        const uint32_t up_p = zmi_lane_up1(pfx), up_l = zmi_lane_up1(l);
+        const uint32_t before_p = lane == 0u ? carry_p : up_p, before_l = lane == 0u ? carry_l : up_l;
+        const bool first = in && pfx != before_p;
+        const uint64_t fm = __ballot(first);
+        const uint32_t gid = ngroups + zmi_mbcnt(fm) + (first ? 1u : 0u) - 1u;     // the run this code belongs to
+        if (in) S->gid[base + lane] = (uint16_t)(gid | (first ? 0x8000u : 0u));
+        if (first && gid != 0u) S->gsb[gid - 1u] = (uint8_t)(before_l - root);     // the code in front closed the run before
+        ngroups += (uint32_t)__popcll((unsigned long long)fm);
+        carry_p = zmi_readlane(pfx, 63u);
+        carry_l = zmi_readlane(l, 63u);
+    }
+    if (lane == 0) S->gsb[ngroups - 1u] = (uint8_t)(maxl - root);                  // the last run ends with the longest code
+    zmi_wave_sync();
+    uint32_t used = rsize;
+    for (uint32_t base = 0; base < ngroups; base += 64u) {
+        const uint32_t g = base + lane;
+        const uint32_t size = g < ngroups ? 1u << S->gsb[g] : 0u;
+        const uint32_t incl = zmi_wave_incl_scan(size);
+        if (g < ngroups) S->goff[g] = (uint16_t)(used + incl - size);
+        used += zmi_readlane(incl, 63u);
+    }
+    if (used > cap) return 2u;
+    for (uint32_t j = rsize + lane; j < used; j += 64u) tab[j] = INF_ENTRY(0, INF_OP_BAD, 0);
+    zmi_wave_sync();
+    for (uint32_t base = 0; base < nlong; base += 64u) {
+        if (base + lane < nlong) {
+            const uint32_t k = k0 + base + lane;
+            const uint32_t sym = S->sorted[k];
+            const uint32_t l = S->lens[sym];
+            const uint32_t code = S->fcode[l] + (k - S->offs[l]);
+            const uint32_t rev = __brev(code) >> (32u - l);                        // LSB-first bit pattern
+            const uint32_t gw = S->gid[base + lane];
+            const uint32_t g = gw & 0x7FFFu;
+            const uint32_t sb = S->gsb[g], off = S->goff[g];
+            if (gw & 0x8000u) tab[rev & (rsize - 1u)] = INF_ENTRY(off, INF_OP_LINK | sb, root);
+            const uint32_t ent = inf_entry(kind, sym, l);
+            const uint32_t sl = l - root, srev = rev >> root;
+            for (uint32_t j = 0; j < (1u << (sb - sl)); ++j) tab[off + srev + (j << sl)] = ent;
         }
-        const uint32_t sl = l - root;            // bits of this code inside the sub-table
-        const uint32_t srev = rev >> root;
-        const uint32_t nrep = 1u << (sub_bits - sl);
-        for (uint32_t j = lane; j < nrep; j += 64u) tab[sub_off + srev + (j << sl)] = ent;
-        code += 1u;
     }
     zmi_wave_sync();
     return 0u;
