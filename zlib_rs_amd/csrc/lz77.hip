@@ -192,7 +192,8 @@ static __device__ __forceinline__ void lz_build_tile_t(const uint8_t* win, uint1
         uint16_t* hp = (uint16_t*)((uint8_t*)head + (st[s] & 0xFFFFu));
         uint16_t* h4p = (uint16_t*)((uint8_t*)head4 + (st[s] >> 16));
         const bool in6 = full || p + (H6 ? 6u : 4u) <= n, in4 = H6 && (full || p + 4u <= n);
-        const uint32_t old = in6 ? *hp : 0u, old4 = in4 ? *h4p : 0u;
+        // (a position without its bytes -- last tile only -- gets distance 0: no link)
+        const uint32_t old = in6 ? *hp : ((p + 1u) & 0xFFFFu), old4 = in4 ? *h4p : ((p + 1u) & 0xFFFFu);
         zmi_wave_order();   // all 64 reads of the step, then its writes (one instruction each on the hardware)
         if (in6) *hp = (uint16_t)(p + 1u);
         if (in4) *h4p = (uint16_t)(p + 1u);
@@ -202,22 +203,18 @@ static __device__ __forceinline__ void lz_build_tile_t(const uint8_t* win, uint1
     // once this store is visible the table updates above have been applied (in-order LDS)
     // (relaxed: the LDS runs a wave's instructions in order, so the token need not wait for the data of the reads above)
     if (producers > 1u && lane == 0) lz_st_relaxed(&ctl->atok, tile + 1u);
-    const bool near = tile * LZ_T < max_dist;   // only the first tiles of a shard can reach back before its start
+    // The links are stored RAW: the distance to the bucket's previous occupant modulo 2^16, whatever it is -- a bucket never
+    // written gives p + 1, a stale one anything.  Whether a link is alive (1 <= distance <= min(max_dist, position)) is the
+    // searchers' question, asked once per position and folded into the walk's distance test: here it was three instructions
+    // per position and table, and the producers' instruction stream is what the low levels run at.
+    (void)max_dist;
 #pragma unroll
     for (uint32_t s = 0; s < LZ_SUB; ++s) {
         const uint32_t p = p0 + s * 64u;
-        // head values are positions + 1 modulo 2^16 (0: never written -- its "distance" p + 1 is out of range while
-        // p < 2^16, later it is a stale entry like any other): alive if 1 <= distance <= min(max_dist, p)
-        const uint32_t lim = near ? (p < max_dist ? p : max_dist) : max_dist;
-        uint32_t d = (p + 1u - (st[s] & 0xFFFFu)) & 0xFFFFu;
-        uint32_t delta = d - 1u < lim ? d : 0u;
+        const uint32_t d = (p + 1u - (st[s] & 0xFFFFu)) & 0xFFFFu;
         const uint32_t sb = (sibs >> (2u * s)) & 3u;
-        delta = (sb != 0u && sb <= lim) ? sb : delta;   // a sibling of the same step is the nearer predecessor
-        pt[s * 64u] = (uint16_t)delta;
-        if (H6) {
-            d = (p + 1u - (st[s] >> 16)) & 0xFFFFu;
-            ct[s * 64u] = (uint16_t)(d - 1u < lim ? d : 0u);
-        }
+        pt[s * 64u] = (uint16_t)(sb != 0u ? sb : d);   // a sibling of the same step is the nearer predecessor
+        if (H6) ct[s * 64u] = (uint16_t)((p + 1u - (st[s] >> 16)) & 0xFFFFu);
     }
 }
 
@@ -371,7 +368,7 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
 
         const uint32_t p = base + lane;
         uint32_t res = 0;
-        uint32_t mylo = 0, myhi = 0, my2 = 0, my3 = 0, maxlen = 0, delta = 0;
+        uint32_t mylo = 0, myhi = 0, my2 = 0, my3 = 0, maxlen = 0, delta = 0, lim = 0;
         uint32_t blen = 3u, bdist = 0u, tail = 0u;
         if (p < n) {
             lz_ring64(win, p, mylo, myhi);
@@ -379,14 +376,17 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
             res = mylo & 0xFFu;
             maxlen = n - p;
             if (maxlen > 258u) maxlen = 258u;
+            // links are raw (lz_build_tile): alive if 1 <= distance <= lim
+            lim = p < prm.max_dist ? p : prm.max_dist;
             delta = prev[p & LZ_WMASK];
+            delta = delta - 1u < lim ? delta : 0u;
             // H6: the most recent 4-byte match (no chain of its own) is looked at first, outside the chain loop and with an
             // 8-byte compare only: what it is for are the 4- and 5-byte matches the 6-byte chain cannot see; a longer match
             // is in the chain as well.  (Peeling a full-size step out of the loop was slower -- lanes without a probe idle
             // through it -- but this one is a third of a chain step and takes the probe bookkeeping out of every step.)
             if (H6) {
                 const uint32_t d4 = c4[p & (LZ_C4RING - 1u)];
-                if (d4 != 0u && d4 != delta && maxlen >= 4u) {
+                if (d4 - 1u < lim && d4 != delta && maxlen >= 4u) {
                     uint32_t a, b;
                     lz_ring64(win, p - d4, a, b);
                     const uint32_t c0 = zmi_ffbl(a ^ mylo), c1 = zmi_ffbl(b ^ myhi) | 32u;
@@ -464,7 +464,8 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                     cand -= dn;
                     chain -= 1u;   // may wrap below zero after the halving: compared as signed
                     // (bitwise, not short-circuit: four compares and three ORs; as `||` the compiler built a branch per term)
-                    const bool stop = (better & (l >= stoplen)) | (dn == 0u) | ((int32_t)chain <= 0) | (p - cand > prm.max_dist);
+                    // (p - cand > lim: the raw link led out of the window, in front of the shard, or nowhere)
+                    const bool stop = (better & (l >= stoplen)) | (dn == 0u) | ((int32_t)chain <= 0) | (p - cand > lim);
                     if (stop) break;
                 }
             }
