@@ -13,11 +13,12 @@
 //       head  16 Ki x u16: last position+1 (mod 2^16) per bucket of the 6-byte hash (the chain)
 //       head4 8 Ki x u16: last position+1 (mod 2^16) per bucket of the 4-byte hash (chain-less: one probe per position),
 //       c4    ring with the answer of that probe for the positions not searched yet
-//   * NO workgroup barrier in the steady state.  Wave 0 (levels 1-4: waves 0 and 1, alternating tiles) is the
-//     PRODUCER: it streams the shard from HBM (one coalesced 16 B/lane load per 1 KiB, issued a tile ahead),
-//     inserts 64 positions per step into the heads (LDS atomic-max; the returned old value is the chain
-//     predecessor) and publishes a `ready` frontier.  It is throttled only by the ring: it may not overwrite
-//     bytes that the oldest in-flight search can still reference.
+//   * NO workgroup barrier in the steady state.  Waves 0 .. P-1 (P = 1-3 by level, tile k built by wave k mod P) are the
+//     PRODUCERS: they stream the shard from HBM (one coalesced 16 B/lane load per 1 KiB, issued a tile ahead), hash 64
+//     positions per step, insert them into the 16-bit heads in position order (plain read + write: the read gives the
+//     chain predecessor; a token passed from tile to tile serialises the inserts of different producers) and publish a
+//     `ready` frontier.  They are throttled only by the ring: they may not overwrite bytes that the oldest in-flight
+//     search can still reference.
 //   * The other waves are SEARCHERS.  A searcher claims 64 consecutive positions (one per lane) from a shared
 //     LDS counter and walks the chains as a tight per-lane loop.  Every chain step issues ONE round of LDS reads
 //     (prev link of the candidate + its first 16 window bytes as five aligned dwords), so it costs one LDS
@@ -30,8 +31,10 @@
 //   * output: one u32 per position  lit | len<<8 | (dist-1)<<17  (len = 0: no match >= 4).
 //     The parse (greedy/lazy selection) happens in encode.hip, which sees the best match of every
 //     position, not just the visited ones.
-// Bound: VALU issue (5.5 instructions per input byte, pipes ~83 % busy at level 6), not HBM: algorithmic HBM
-// traffic is 1 B read + 4 B scratch written per input byte (measured: exactly that, profiles/r01_traffic.json).
+// Bound: instruction issue, not HBM and not LDS latency (6.9 VALU + SALU + LDS wave-instructions per
+// input byte at ~3.0 cycles each per SIMD, which is what the mix of 2- and 4-cycle instructions costs by the measured table
+// in profiles/r03_issue_probe.txt; two claims per wave in one loop -- more loads in flight -- made it slower).  HBM traffic
+// is 1 B read + 4 B scratch written per input byte (measured: exactly that, profiles/r03_traffic.json).
 #include "zmi_device.h"
 #include "zmi_kernels.h"
 
