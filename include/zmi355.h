@@ -183,6 +183,18 @@ int zmi_inflate_batch(zmi_ctx* ctx, const uint8_t* in, const uint64_t* in_off, c
 int zmi_inflate_resume(zmi_ctx* ctx, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist,
                        uint32_t hist_len, uint8_t* out, uint32_t out_cap, uint32_t* out_len, int32_t* status,
                        int32_t* detail, uint32_t* in_used, uint32_t* resume);
+/* The same call for a stream with flush points (Z_SYNC_FLUSH / Z_FULL_FLUSH markers 00 00 FF FF: pigz, this library's own
+ * deflate()): seg_start[0..nseg) are byte offsets into `in` proposed as restart points (seg_start[0] = 0, ascending; normally
+ * the byte behind every marker found).  The pieces are decoded side by side on the whole GPU and stitched; every cut is
+ * verified (the decode in front of it must end exactly there, on a block boundary), anything else falls back to the
+ * serial decode from that point -- results are those of zmi_inflate_resume on the same arguments, whatever seg_start
+ * holds.  *segments_used (may be NULL): how many pieces were decoded in parallel (0 = the serial path ran).
+ * Reference path it accelerates: zlib-rs/src/inflate.rs:1276 ff. (the Mode::Type block loop), restarted where
+ * zlib-rs/src/deflate.rs:2733-2744 (the empty stored block of a flush) made the stream restartable. */
+int zmi_inflate_split(zmi_ctx* ctx, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist,
+                      uint32_t hist_len, uint8_t* out, uint32_t out_cap, const uint32_t* seg_start, uint32_t nseg,
+                      uint32_t* out_len, int32_t* status, int32_t* detail, uint32_t* in_used, uint32_t* resume,
+                      uint32_t* segments_used);
 
 #ifdef __cplusplus
 }

@@ -172,3 +172,92 @@ def jump_resolve_checks(e, o, big=False):
         assert s_ == 0 and got == b
     assert st[-1] != 0 and one == [blobs[0]] and st1 == [0] and s2 == 0 and tail == blobs[3][n // 2:]
     return len(comp)
+
+
+def split_inflate_checks(e, o, big=False):
+    """zmi_inflate_split (one stream decoded as segments cut at its flush points, stitched by the pointer-jumping resolve)
+    against zmi_inflate_resume on the same arguments: identical output, status, detail, in_used and resume -- for true
+    markers, markers that are data (inside a stored block / proposed at random offsets), matches that reach across
+    the cuts into earlier segments and into the history, a final block inside a segment, a truncated tail, a corrupt
+    segment, too little room, and a segment that outgrows its decode region (a long run of one byte)."""
+    import zlib
+    import random
+    rng = random.Random(11)
+    n = 600000 if big else 90000
+    piece = 65536 if big else 9000
+
+    def flushed(data, step, level=6, finish=True, mode=zlib.Z_SYNC_FLUSH):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        out, cuts = b"", []
+        for i in range(0, len(data), step):
+            out += co.compress(data[i:i + step]) + co.flush(mode)
+            cuts.append(len(out))
+        if finish:
+            out += co.flush()
+        return out, cuts
+
+    def markers(buf):
+        seg, at = [0], 1
+        while True:
+            i = buf.find(b"\x00\x00\xff\xff", at)
+            if i < 0 or i + 4 >= len(buf):
+                break
+            seg.append(i + 4)
+            at = i + 4
+        return seg
+
+    cases = []
+    text = o.gen_shard(0, n)
+    mix = o.gen_shard(3, n // 2) + o.gen_shard(5, n // 2)
+    # 1. the plain case: every marker true, matches reach across the cuts (sync flush keeps the window)
+    comp, cuts = flushed(text, piece)
+    cases.append(("sync", comp, markers(comp), b"", len(text) + 100))
+    # 2. full flush points, no final block yet (need more input at the end), 3. tail cut in the middle of a block
+    comp2, _ = flushed(mix, piece, finish=False, mode=zlib.Z_FULL_FLUSH)
+    cases.append(("full-nofinish", comp2, markers(comp2), b"", len(mix) + 100))
+    cases.append(("truncated", comp[:len(comp) - 777], markers(comp[:len(comp) - 777]), b"", len(text) + 100))
+    # 4. markers that are data: a stored (level 0) part that holds the four bytes many times, between compressed parts
+    fake = (b"\x00\x00\xff\xff" + bytes(range(97, 123)) * 40) * 30
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    a = co.compress(text[:piece * 2]) + co.flush(zlib.Z_SYNC_FLUSH)
+    st0 = zlib.compressobj(0, zlib.DEFLATED, -15)
+    stored = st0.compress(fake) + st0.flush(zlib.Z_SYNC_FLUSH)
+    co2 = zlib.compressobj(6, zlib.DEFLATED, -15)
+    b = co2.compress(mix[:piece * 3]) + co2.flush()
+    comp4 = a + stored + b
+    cases.append(("stored-fakes", comp4, markers(comp4), b"", piece * 5 + len(fake) + 100))
+    # 5. proposals at random offsets (none of them a restart) + the true ones
+    seg5 = sorted(set(markers(comp) + [rng.randrange(1, len(comp)) for _ in range(12)]))
+    cases.append(("random-cuts", comp, seg5, b"", len(text) + 100))
+    cases.append(("only-false", comp, [0] + sorted(set(rng.randrange(1, len(comp)) for _ in range(6))), b"", len(text) + 100))
+    # 6. history in front: the second half of a stream, its matches reach into the first half's last 32 KiB
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    head = co.compress(text[:n // 3]) + co.flush(zlib.Z_SYNC_FLUSH)
+    rest = b""
+    for i in range(n // 3, n, piece):
+        rest += co.compress(text[i:i + piece]) + co.flush(zlib.Z_SYNC_FLUSH)
+    rest += co.flush()
+    cases.append(("history", rest, markers(rest), text[:n // 3][-32768:], n))
+    cases.append(("history-missing", rest, markers(rest), text[:n // 3][-2000:], n))   # distance too far back somewhere
+    # 7. too little room (stops in the middle), 8. a run that outgrows its region, 9. a corrupt segment
+    cases.append(("small-room", comp, markers(comp), b"", len(text) // 2 + 123))
+    run = b"\x07" * (n * 2) + text[:piece]
+    comp8, _ = flushed(run + text[:piece * 2], max(piece, len(run) // 2 + 10))
+    cases.append(("long-run", comp8, markers(comp8), b"", len(run) + piece * 3 + 100))
+    bad = bytearray(comp); bad[cuts[2] + 40] ^= 0x41
+    cases.append(("corrupt", bytes(bad), markers(bytes(bad)), b"", len(text) + 100))
+    # 10. a final block inside a segment, bytes (with a marker) behind the end of the stream
+    comp10 = comp + b"\x00\x00\xff\xff" + b"trailing bytes" * 10
+    cases.append(("behind-the-end", comp10, markers(comp10), b"", len(text) + 100))
+    used_any = 0
+    for name, stream, seg, hist, cap in cases:
+        want = e.inflate_resume(stream, 0, hist, cap=cap)
+        got = e.inflate_split(stream, seg, 0, hist, cap=cap)
+        assert got[:5] == want, (name, want[1:], got[1:], len(want[0]), len(got[0]))
+        used_any += got[5]
+        if name == "sync":
+            assert got[5] == len(seg) and got[1] == 0 and got[0] == text
+        if name in ("only-false",):
+            assert got[5] <= 1
+    assert used_any > 0
+    return len(cases)

@@ -384,6 +384,14 @@ def test_inflate_large_streams_fast_pass(eng, o):
     assert parity_checks.large_stream_checks(eng.inflate, o, lambda blobs, lvl, wrap: eng.deflate(blobs, level=lvl, wrap=wrap)) > 60
 
 
+def test_split_inflate_equals_serial_inflate():
+    """one stream decoded as segments cut at its flush points (zmi_inflate_split): the results of zmi_inflate_resume,
+    whatever the proposed cuts are (true markers, data that looks like one, random offsets)"""
+    e = zmi_ctypes.Engine(zmi_ctypes.load_emu())
+    assert parity_checks.split_inflate_checks(e, oracle_lib.load()) == 12
+    e.close()
+
+
 def test_jump_resolve_equals_serial_resolve():
     """few streams: back-references resolved by pointer jumping (resolve_jump.hip) -- byte for byte the serial pass's output"""
     e = zmi_ctypes.Engine(zmi_ctypes.load_emu())

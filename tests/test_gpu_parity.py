@@ -436,6 +436,17 @@ def test_inflate_large_streams_fast_pass_on_gpu(engine):
     assert n > 60
 
 
+def test_split_inflate_equals_serial_inflate_on_gpu():
+    """one stream decoded as segments cut at its flush points, on the whole chip (zmi_inflate_split): the results of the
+    serial zmi_inflate_resume for true markers, false ones, history, corruption, short room"""
+    import oracle_lib
+    import parity_checks
+    import zmi_ctypes
+    eng = zmi_ctypes.Engine(zmi_ctypes.load_product())
+    assert parity_checks.split_inflate_checks(eng, oracle_lib.load(rebuild=False), big=True) == 12
+    eng.close()
+
+
 def test_jump_resolve_equals_serial_resolve_on_gpu():
     """few streams: back-references resolved by pointer jumping on the whole chip (csrc/resolve_jump.hip) -- byte for byte
     the output of the one-wave-per-stream pass, incl. a 300 KB run of one byte, history and a corrupt stream"""

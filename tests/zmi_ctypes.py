@@ -30,6 +30,8 @@ def _bind(lib):
     lib.zmi_copy_ranges_dev.argtypes = [vp, vp, vp, C.c_uint64, vp, C.c_uint32, C.c_uint32, vp, vp, C.c_uint64, vp]
     lib.zmi_pack_slab_dev.argtypes = [vp, vp, C.c_uint64, vp, C.c_uint32, vp, C.c_uint64, vp, vp]
     lib.zmi_inflate_resume.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, u32p, i32p, i32p, u32p, u32p]
+    lib.zmi_inflate_split.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, u32p, i32p, i32p, u32p,
+                                      u32p, u32p]
     return lib
 
 
@@ -160,3 +162,18 @@ class Engine:
         if rc != 0:
             raise RuntimeError("zmi_inflate_resume failed: %d %s" % (rc, self.lib.zmi_last_error().decode()))
         return bytes(out[:min(olen.value, cap)]), st.value, det.value, used.value, list(res)
+
+    def inflate_split(self, data, seg_start, in_bit=0, hist=b"", cap=1 << 16):
+        """zmi_inflate_split: the same call with proposed restart points -> the same tuple + segments decoded in parallel"""
+        src = np.frombuffer(bytes(data) + b"\0", dtype=np.uint8).copy()
+        h = np.frombuffer(bytes(hist) + b"\0", dtype=np.uint8).copy()
+        out = np.zeros(max(1, cap), dtype=np.uint8)
+        seg = (C.c_uint32 * max(1, len(seg_start)))(*seg_start)
+        olen, used, nused = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        st, det = C.c_int32(0), C.c_int32(0)
+        res = (C.c_uint32 * 4)()
+        rc = self.lib.zmi_inflate_split(self.ctx, src.ctypes.data, len(data), in_bit, h.ctypes.data, len(hist), out.ctypes.data, cap,
+                                        seg, len(seg_start), C.byref(olen), C.byref(st), C.byref(det), C.byref(used), res, C.byref(nused))
+        if rc != 0:
+            raise RuntimeError("zmi_inflate_split failed: %d %s" % (rc, self.lib.zmi_last_error().decode()))
+        return bytes(out[:min(olen.value, cap)]), st.value, det.value, used.value, list(res), nused.value

@@ -141,6 +141,67 @@ __global__ void __launch_bounds__(256) zmi_jump_gather_kernel(uint8_t* out, cons
     }
 }
 
+// ---- one stream decoded as SEGMENTS (zmi_inflate_split, zmi_api.hip) ----------------------------------------------------
+// The segments of a stream that was cut at its flush points are decoded side by side, each into a region of its own with a
+// bitmap of its own; their outputs are then copied back to back into the final buffer (records included) and resolved as
+// ONE stream: byte g of the final output belongs to segment j = the last one with soff[j] <= g, its hole (if any) is found in
+// that segment's bitmap at g - soff[j], its pointer is g - distance in the stream's coordinates.  A segment behind the first
+// was decoded with "32 KiB of history are there" taken on trust: a pointer that reaches in front of the history that really
+// exists raises *err (the caller then falls back to the serial decode, which reports the reference's error).
+__global__ void __launch_bounds__(256) zmi_jump_init_seg_kernel(const uint8_t* __restrict__ fin, const uint64_t* __restrict__ soff,
+                                                                uint32_t nseg, const uint64_t* __restrict__ bitmap,
+                                                                const uint64_t* __restrict__ bm_off, int32_t* __restrict__ ptr,
+                                                                uint64_t total, uint32_t hist_len, uint32_t* __restrict__ flags,
+                                                                uint32_t* __restrict__ err) {
+    const uint64_t tid = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (tid == 0) { for (uint32_t r = 0; r < 40u; ++r) flags[r] = 0u; }
+    for (uint32_t it = 0; it < JUMP_ITEMS; ++it) {
+        const uint64_t g = tid + (uint64_t)it * gridDim.x * 256u;
+        if (g >= total) return;
+        uint32_t lo = 0, hi = nseg;   // the last segment that starts at or below g
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (soff[mid] <= g) lo = mid; else hi = mid;
+        }
+        const uint32_t b = (uint32_t)(g - soff[lo]);
+        const uint64_t* bm = bitmap + bm_off[lo];
+        const uint8_t* dst = fin + soff[lo];
+        int32_t p = (int32_t)g;
+        uint32_t w = b >> 6;
+        uint64_t m = bm[w] & ((2ull << (b & 63u)) - 1ull);
+        for (uint32_t k = 0; k < 5u && m == 0ull && w > 0u; ++k) m = bm[--w];
+        if (m != 0ull) {
+            const uint32_t q = (w << 6) + 63u - (uint32_t)__clzll((unsigned long long)m);
+            if (b - q < 258u) {
+                const uint32_t rec = (uint32_t)dst[q] | ((uint32_t)dst[q + 1u] << 8) | ((uint32_t)dst[q + 2u] << 16);
+                const uint32_t dist = (rec & 0x7FFFu) + 1u, len = (rec >> 15) + 3u;
+                if (b - q < len) {
+                    p = (int32_t)g - (int32_t)dist;
+                    if ((int64_t)g - (int64_t)dist < -(int64_t)hist_len) { atomicOr(err, 1u); p = (int32_t)g; }
+                }
+            }
+        }
+        ptr[g] = p;
+    }
+}
+
+// the final buffer as one stream: d_one_off[0] = 0 (its bitmap offset is not used by the rounds: only the index base),
+// d_one_len[0] = total
+extern "C" int zmi_launch_resolve_jump_segments(uint8_t* d_fin, const uint64_t* d_soff, uint32_t nseg, const uint64_t* d_bitmap,
+                                                const uint64_t* d_bm_off, int32_t* d_ptr, uint64_t total, uint32_t hist_len,
+                                                uint32_t rounds, uint32_t* d_flags, uint32_t* d_err, const uint64_t* d_one_off,
+                                                const uint32_t* d_one_len, hipStream_t stream) {
+    if (nseg == 0 || total == 0) return 0;
+    if (rounds > 40u) rounds = 40u;
+    const uint32_t grid = (uint32_t)((total + 256u * JUMP_ITEMS - 1u) / (256u * JUMP_ITEMS));
+    ZMI_LAUNCH(zmi_jump_init_seg_kernel, dim3(grid), dim3(256), 0, stream, (const uint8_t*)d_fin, d_soff, nseg, d_bitmap, d_bm_off, d_ptr,
+               total, hist_len, d_flags, d_err);
+    for (uint32_t r = 0; r < rounds; ++r)
+        ZMI_LAUNCH(zmi_jump_round_kernel, dim3(grid), dim3(256), 0, stream, d_one_len, 1u, d_one_off, d_ptr, total, d_flags, r);
+    ZMI_LAUNCH(zmi_jump_gather_kernel, dim3(grid), dim3(256), 0, stream, d_fin, d_one_off, d_one_len, 1u, d_one_off, (const int32_t*)d_ptr, total);
+    return 0;
+}
+
 // rounds: ceil(log2(largest possible output of one stream)) + 1, from the host's bound on the capacities
 extern "C" int zmi_launch_resolve_jump(uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_len, uint32_t n_streams,
                                        const uint64_t* d_bitmap, const uint64_t* d_bm_off, int32_t* d_ptr, uint64_t n_idx,

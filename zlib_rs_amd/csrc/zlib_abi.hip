@@ -39,6 +39,10 @@ extern "C" int zmi_inflate_batch_dict_dev(zmi_ctx* c, const void* d_in, const ui
                                           uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off,
                                           const uint32_t* d_out_cap, const uint32_t* d_out_hist, uint32_t* d_out_len,
                                           int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail, void* stream);
+extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist,
+                                 uint32_t hist_len, uint8_t* out, uint32_t out_cap, const uint32_t* seg_start, uint32_t nseg,
+                                 uint32_t* out_len, int32_t* status, int32_t* detail, uint32_t* in_used, uint32_t* resume,
+                                 uint32_t* segments_used);
 extern "C" int zmi_inflate_resume(zmi_ctx* c, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist,
                                   uint32_t hist_len, uint8_t* out, uint32_t out_cap, uint32_t* out_len, int32_t* status,
                                   int32_t* detail, uint32_t* in_used, uint32_t* resume);
@@ -723,6 +727,31 @@ size_t abi_limit(const char* name, size_t dflt) {
 size_t queue_limit() { return abi_limit("ZMI_ABI_QUEUE", (size_t)32 << 20); }
 size_t take_limit() { return abi_limit("ZMI_ABI_TAKE", (size_t)256 << 20); }
 
+// Flush points in what is buffered: a stream written with Z_SYNC_FLUSH / Z_FULL_FLUSH points (pigz, a logger, this library's
+// own deflate(): one every 64 KiB of input) has the bytes 00 00 FF FF in front of every restart, and the decode pass needs no
+// window -- zmi_inflate_split decodes the pieces side by side and checks every proposed cut (the same four bytes can be data).
+// Candidates at least 8 KiB apart, the bytes BEHIND each marker; seg[0] = 0.  Empty unless the split is worth it.
+bool split_enabled() {
+    static const bool on = [] { const char* e = getenv("ZMI_ABI_SPLIT"); return !(e && (e[0] == '0' || e[0] == 'o')); }();
+    return on;
+}
+void find_flush_points(const uint8_t* in, size_t n, std::vector<uint32_t>& seg) {
+    seg.clear();
+    if (n < ((size_t)256 << 10) || !split_enabled()) return;
+    static const uint8_t kMark[4] = {0x00, 0x00, 0xFF, 0xFF};
+    seg.push_back(0u);
+    size_t at = 8192;
+    while (at + 4 < n && seg.size() < 8192u) {
+        const void* m = memmem(in + at, n - at, kMark, 4);
+        if (!m) break;
+        const size_t cut = (size_t)((const uint8_t*)m - in) + 4u;
+        if (cut >= n) break;
+        seg.push_back((uint32_t)cut);
+        at = cut + 8192;
+    }
+    if (seg.size() < 4u) seg.clear();
+}
+
 // Decode what is buffered, from the checkpoint.  Queues every new byte, moves the checkpoint to the last block
 // boundary reached, and changes the mode when the final block ended or the data is invalid.
 int inflate_attempt(InflateState* s, int stop_mode = 0) {   // stop_mode 1: decode one block, 2: only the next block header
@@ -738,9 +767,16 @@ int inflate_attempt(InflateState* s, int stop_mode = 0) {   // stop_mode 1: deco
         uint32_t olen = 0, used = 0, res[4] = {0, 0, 0, 0};
         int32_t st = 0, det = 0;
         const uint32_t in_bit = s->sbit | (stop_mode == 1 ? (1u << 8) : 0u) | (stop_mode == 2 ? (1u << 24) : 0u);
-        if (zmi_inflate_resume(c, s->in.data(), (uint32_t)take, in_bit, s->hist.data(), (uint32_t)s->hist.size(), s->tmp.data(),
-                               (uint32_t)cap, &olen, &st, &det, &used, res) != 0)
-            return Z_MEM_ERROR;
+        std::vector<uint32_t> seg;
+        if (stop_mode == 0 && take <= ((size_t)16 << 20)) find_flush_points(s->in.data(), take, seg);
+        int rc;
+        if (!seg.empty())
+            rc = zmi_inflate_split(c, s->in.data(), (uint32_t)take, in_bit, s->hist.data(), (uint32_t)s->hist.size(), s->tmp.data(), (uint32_t)cap,
+                                   seg.data(), (uint32_t)seg.size(), &olen, &st, &det, &used, res, nullptr);
+        else
+            rc = zmi_inflate_resume(c, s->in.data(), (uint32_t)take, in_bit, s->hist.data(), (uint32_t)s->hist.size(), s->tmp.data(),
+                                    (uint32_t)cap, &olen, &st, &det, &used, res);
+        if (rc != 0) return Z_MEM_ERROR;
         if (st == Z_MEM_ERROR) return Z_MEM_ERROR;
         const size_t eff = olen < cap ? olen : cap;
         if (st == Z_BUF_ERROR && det == 3 && (res[3] & 2u)) {   // behind the block header: nothing decoded, the checkpoint stays

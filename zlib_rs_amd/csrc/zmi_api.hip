@@ -79,6 +79,7 @@ struct zmi_ctx {
     zmi_buf inf_bm;   // inflate: 1 bit per output byte of the batch (where back-references start)
     zmi_buf inf_ptr;  // inflate of few streams: 4 B per output byte, the pointers of the jump resolve (resolve_jump.hip)
     zmi_buf st_in, st_out, st_meta;  // zmi_inflate_resume: staging of one host stream (kept across calls)
+    zmi_buf sp_out;                  // zmi_inflate_split: the segments' decode regions
     // host-buffer batches (zmi_deflate_batch): two slots cycle through copy-in / kernels / copy-out on three streams
     struct hb_slot { zmi_buf in, out, meta; hipEvent_t in_done, k_done, out_done; } hb[ZMI_HB_SLOTS];
     zmi_buf hb_slab[ZMI_HB_SLOTS];                              // device: the chunk's compressed streams packed densely (what travels back)
@@ -128,6 +129,7 @@ extern "C" int zmi_ctx_destroy(zmi_ctx* c) {
     if (c->st_in.p) (void)hipFree(c->st_in.p);
     if (c->st_out.p) (void)hipFree(c->st_out.p);
     if (c->st_meta.p) (void)hipFree(c->st_meta.p);
+    if (c->sp_out.p) (void)hipFree(c->sp_out.p);
     if (c->hb_live) {
         for (auto& sl : c->hb) {
             if (sl.in.p) (void)hipFree(sl.in.p);
@@ -519,7 +521,7 @@ static int zmi_inflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
                             uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off,
                             const uint32_t* d_out_cap, const uint32_t* d_out_hist, uint32_t* d_out_len,
                             int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail, const uint32_t* d_in_bit,
-                            uint32_t* d_resume, void* stream_) {
+                            uint32_t* d_resume, void* stream_, bool decode_only = false) {
     if (!c) return zmi_fail(ZMI_E_ARG, "null context");
     if (wrap < ZMI_WRAP_RAW || wrap > ZMI_WRAP_AUTO) return zmi_fail(ZMI_E_ARG, "wrap must be raw/zlib/gzip/auto");
     if (n == 0) return ZMI_E_OK;
@@ -552,6 +554,7 @@ static int zmi_inflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     // output bytes at once (resolve_jump.hip), which costs 4 B of scratch per byte of capacity.
     // (below 256 KiB of capacity the serial pass takes less than the jump pass's two dozen launches)
     bool jump = n <= 16u && out_limit <= (1ull << 30) && out_limit >= (256ull << 10);
+    if (!decode_only) {
     if (const char* jv = zmi_tune("ZMI_INF_JUMP")) jump = atoi(jv) != 0 && out_limit <= (1ull << 30);
     if (jump && zmi_reserve(c->inf_ptr, (size_t)bm_words * 256u + 512u) != 0) jump = false;   // (no room: the serial pass needs none)
     {
@@ -567,6 +570,7 @@ static int zmi_inflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
         }
         if (lrc) return zmi_fail(ZMI_E_HIP, "inflate resolve launch setup", (hipError_t)lrc);
     }
+    }   // (decode_only: the caller resolves -- zmi_inflate_split stitches the segments of one stream first)
     if (wrap != ZMI_WRAP_RAW) {
         uint32_t kind = wrap == ZMI_WRAP_ZLIB ? 1u : (wrap == ZMI_WRAP_GZIP ? 2u : 3u);
         zmi_scope_timer tm(c, ZMI_K_CHECKSUM, stream);
@@ -684,6 +688,163 @@ static int zmi_deflate_batch_simple(zmi_ctx* c, const uint8_t* in, const uint64_
     return ZMI_E_OK;
 }
 
+
+// ---- one host stream decoded as segments (what the stream ABI's inflate() uses for streams with flush points) ----
+// A deflate stream that was written with Z_SYNC_FLUSH / Z_FULL_FLUSH points (pigz, this engine's own deflate(): a point every
+// 64 KiB of input) carries the marker 00 00 FF FF in front of every byte-aligned restart, and the decode pass needs no window:
+// so the pieces between markers can be decoded side by side like the streams of a batch -- thousands of waves instead of
+// the one workgroup a single stream gets -- and stitched afterwards (resolve_jump.hip: the back-references of the whole
+// output are resolved at once, across segment borders).  `seg_start[0..nseg)` are byte offsets into `in` (ascending,
+// seg_start[0] = 0) proposed by the caller, e.g. the bytes behind every marker it found; nothing is taken on trust:
+// a segment counts only if the decode of the one before ended exactly at its first byte, on a block boundary, and whatever
+// does not check out (a marker that was data, a segment that outgrew its room, a distance that reaches in front of the
+// real history) makes the call fall back to the serial decode from there.  Results are those of zmi_inflate_resume on the
+// same input: same bytes, status, detail, in_used, resume.
+extern "C" int zmi_inflate_resume(zmi_ctx* c, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist,
+                                  uint32_t hist_len, uint8_t* out, uint32_t out_cap, uint32_t* out_len, int32_t* status,
+                                  int32_t* detail, uint32_t* in_used, uint32_t* resume);
+extern "C" int zmi_launch_resolve_jump_segments(uint8_t* d_fin, const uint64_t* d_soff, uint32_t nseg, const uint64_t* d_bitmap,
+                                                const uint64_t* d_bm_off, int32_t* d_ptr, uint64_t total, uint32_t hist_len,
+                                                uint32_t rounds, uint32_t* d_flags, uint32_t* d_err, const uint64_t* d_one_off,
+                                                const uint32_t* d_one_len, hipStream_t stream);
+extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist,
+                                 uint32_t hist_len, uint8_t* out, uint32_t out_cap, const uint32_t* seg_start, uint32_t nseg,
+                                 uint32_t* out_len, int32_t* status, int32_t* detail, uint32_t* in_used, uint32_t* resume,
+                                 uint32_t* segments_used) {
+    if (segments_used) *segments_used = 0;
+    if (!c || (!in && in_len) || (!hist && hist_len) || (!out && out_cap) || !out_len || !status || !detail || !in_used || !resume || !seg_start)
+        return zmi_fail(ZMI_E_ARG, "null argument");
+    if (nseg < 2u || in_bit > 7u || out_cap > (1u << 30) || in_len > 0xFFFFFF00u || seg_start[0] != 0u)
+        return zmi_inflate_resume(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume);
+    for (uint32_t j = 1; j < nseg; ++j)
+        if (seg_start[j] <= seg_start[j - 1u] || seg_start[j] >= in_len)
+            return zmi_inflate_resume(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume);
+    ZMI_ON_DEVICE(c);
+    if (hist_len > 32768u) { hist += hist_len - 32768u; hist_len = 32768u; }
+    const size_t base = ((size_t)hist_len + 1023u) & ~(size_t)1023u;
+    // every segment decodes into a region of its own: 16 bytes of room per compressed byte (a segment that needs more ends the
+    // parallel part in front of it)
+    std::vector<uint64_t> ioff(nseg), ooff(nseg);
+    std::vector<uint32_t> ilen(nseg), ocap(nseg), shist(nseg), sbit(nseg);
+    uint64_t scratch = 0;
+    for (uint32_t j = 0; j < nseg; ++j) {
+        ioff[j] = seg_start[j];
+        ilen[j] = (j + 1u < nseg ? seg_start[j + 1u] : in_len) - seg_start[j];
+        uint64_t room = (uint64_t)ilen[j] * 16u + 4096u;
+        if (room > out_cap) room = out_cap;
+        ocap[j] = (uint32_t)room;
+        ooff[j] = scratch;
+        scratch += (room + 1023u) & ~1023ull;
+        shist[j] = j == 0u ? hist_len : 32768u;   // (taken on trust by the decode pass, which reads no history; checked at the stitch)
+        sbit[j] = j == 0u ? in_bit : 0u;
+    }
+    if (scratch > (3ull << 30)) return zmi_inflate_resume(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume);
+    // meta: ioff u64[n] | ooff u64[n] | soff u64[n + 1] | ilen | ocap | hist | bit | olen | status | used | detail (u32[n] each) | resume u32[4n] | one_off u64, one_len u32, err u32
+    const size_t n = nseg;
+    const size_t o_ioff = 0, o_ooff = 8 * n, o_soff = 16 * n, o_ilen = 24 * n + 8, o_ocap = o_ilen + 4 * n, o_hist = o_ocap + 4 * n, o_bit = o_hist + 4 * n,
+                 o_olen = o_bit + 4 * n, o_st = o_olen + 4 * n, o_used = o_st + 4 * n, o_det = o_used + 4 * n, o_res = o_det + 4 * n, o_one = ((o_res + 16 * n) + 7) & ~(size_t)7,
+                 meta_bytes = o_one + 32;
+    int rc = zmi_reserve(c->st_in, (size_t)in_len + 64u);
+    if (!rc) rc = zmi_reserve(c->st_out, base + (size_t)out_cap + 64u);
+    if (!rc) rc = zmi_reserve(c->st_meta, meta_bytes);
+    if (!rc) rc = zmi_reserve(c->sp_out, (size_t)scratch + 64u);
+    if (rc) return rc;
+    hipStream_t hs = c->host_stream;
+    uint8_t* d = (uint8_t*)c->st_meta.p;
+    std::vector<uint8_t> hm(meta_bytes, 0);
+    memcpy(hm.data() + o_ioff, ioff.data(), 8 * n); memcpy(hm.data() + o_ooff, ooff.data(), 8 * n);
+    memcpy(hm.data() + o_ilen, ilen.data(), 4 * n); memcpy(hm.data() + o_ocap, ocap.data(), 4 * n);
+    memcpy(hm.data() + o_hist, shist.data(), 4 * n); memcpy(hm.data() + o_bit, sbit.data(), 4 * n);
+    ZMI_HIP(hipMemcpyAsync(c->st_in.p, in, in_len, hipMemcpyHostToDevice, hs));
+    if (hist_len) ZMI_HIP(hipMemcpyAsync((uint8_t*)c->st_out.p + base - hist_len, hist, hist_len, hipMemcpyHostToDevice, hs));
+    ZMI_HIP(hipMemcpyAsync(d, hm.data(), meta_bytes, hipMemcpyHostToDevice, hs));
+    const uint64_t saved_limit = c->inflate_out_limit;
+    c->inflate_out_limit = scratch + (1ull << 16);
+    struct restore { zmi_ctx* c; uint64_t v; ~restore() { c->inflate_out_limit = v; } } restore_limit{c, saved_limit};
+    rc = zmi_inflate_impl(c, c->st_in.p, (const uint64_t*)(d + o_ioff), (const uint32_t*)(d + o_ilen), nseg, ZMI_WRAP_RAW, c->sp_out.p,
+                          (const uint64_t*)(d + o_ooff), (const uint32_t*)(d + o_ocap), (const uint32_t*)(d + o_hist), (uint32_t*)(d + o_olen),
+                          (int32_t*)(d + o_st), (uint32_t*)(d + o_used), (int32_t*)(d + o_det), (const uint32_t*)(d + o_bit), (uint32_t*)(d + o_res), hs, true);
+    if (rc) { (void)hipStreamSynchronize(hs); return rc; }
+    std::vector<uint32_t> r(8 * n);   // olen | status | used | detail | resume[4n]
+    ZMI_HIP(hipMemcpyAsync(r.data(), d + o_olen, 32 * n, hipMemcpyDeviceToHost, hs));
+    ZMI_HIP(hipStreamSynchronize(hs));
+    const uint32_t *olen = r.data(), *used = r.data() + 2 * n, *res = r.data() + 4 * n;
+    const int32_t *st = (const int32_t*)(r.data() + n), *det = (const int32_t*)(r.data() + 3 * n);
+    // the chain: segment j is CLEAN if its decode ended exactly at its last byte, on a block boundary, with all output complete
+    uint32_t tail = 0;   // the first segment that is not clean (or the last one): its result is "the serial decode of the rest"
+    std::vector<uint64_t> soff(n + 1, 0);
+    uint64_t total = 0;
+    for (uint32_t j = 0; j < nseg; ++j) {
+        tail = j;
+        soff[j] = total;
+        const bool clean = j + 1u < nseg && st[j] == ZMI_BUF_ERROR && det[j] == 1 && res[4 * j] == ilen[j] && res[4 * j + 1] == 0u &&
+                           res[4 * j + 2] == olen[j] && olen[j] <= ocap[j] && total + olen[j] <= out_cap;
+        if (!clean) break;
+        total += olen[j];
+    }
+    // the tail counts as it stands if it is the stream's real tail (the last segment) or ended the stream; a tail that stopped
+    // for any other reason (a marker that was data, no room) is decoded again serially below, from its first byte
+    // (and not one that ran out of a region smaller than the room the caller really has left)
+    const bool tail_ok = (tail + 1u == nseg || st[tail] == ZMI_OK) && olen[tail] <= ocap[tail] && total + olen[tail] <= out_cap &&
+                         (st[tail] == ZMI_OK || (st[tail] == ZMI_BUF_ERROR && (det[tail] == 1 || (det[tail] == 2 && ocap[tail] >= out_cap - total))));
+    const uint32_t take = tail + (tail_ok ? 1u : 0u);   // segments whose output is copied
+    if (take == 0u || (take == 1u && !tail_ok))        // nothing gained: the serial path
+        return zmi_inflate_resume(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume);
+    if (tail_ok) total += olen[tail] < ocap[tail] ? olen[tail] : ocap[tail];
+    soff[take] = total;
+    if (total == 0u)
+        return zmi_inflate_resume(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume);
+    // stitch: outputs back to back behind the history, then all back-references at once
+    rc = zmi_reserve(c->inf_ptr, (size_t)total * 4u + 512u);
+    if (rc) return rc;
+    struct { uint64_t off; uint32_t len, err; } one = {0ull, (uint32_t)total, 0u};
+    ZMI_HIP(hipMemcpyAsync(d + o_soff, soff.data(), 8 * (take + 1u), hipMemcpyHostToDevice, hs));
+    ZMI_HIP(hipMemcpyAsync(d + o_one, &one, sizeof(one), hipMemcpyHostToDevice, hs));
+    uint8_t* d_fin = (uint8_t*)c->st_out.p + base;
+    zmi_launch_copy_ranges((const uint8_t*)c->sp_out.p, (const uint64_t*)(d + o_ooff), 0, (const uint32_t*)(d + o_olen), take, d_fin,
+                           (const uint64_t*)(d + o_soff), total, 0xFFFFFFFFu, hs);
+    uint32_t rounds = 2u;
+    while (rounds < 34u && (1ull << (rounds - 1u)) < total) ++rounds;
+    {
+        zmi_scope_timer tm(c, ZMI_K_RESOLVE, hs);
+        zmi_launch_resolve_jump_segments(d_fin, (const uint64_t*)(d + o_soff), take, (const uint64_t*)c->inf_bm.p, (const uint64_t*)c->inf_tmp.p,
+                                         (int32_t*)c->inf_ptr.p, total, hist_len, rounds, (uint32_t*)((uint8_t*)c->inf_ptr.p + (size_t)total * 4u),
+                                         (uint32_t*)(d + o_one + 12), (const uint64_t*)(d + o_one), (const uint32_t*)(d + o_one + 8), hs);
+    }
+    uint32_t err = 0;
+    ZMI_HIP(hipMemcpyAsync(&err, d + o_one + 12, 4, hipMemcpyDeviceToHost, hs));
+    ZMI_HIP(hipMemcpyAsync(out, d_fin, (size_t)total, hipMemcpyDeviceToHost, hs));
+    ZMI_HIP(hipStreamSynchronize(hs));
+    ZMI_HIP(hipGetLastError());
+    if (err)   // a distance reaches in front of the history that is really there: let the serial decode find and name it
+        return zmi_inflate_resume(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume);
+    if (segments_used) *segments_used = take;
+    if (tail_ok) {
+        const uint32_t g = (uint32_t)soff[tail];
+        *out_len = g + olen[tail];
+        *status = st[tail];
+        *detail = det[tail];
+        *in_used = seg_start[tail] + used[tail];
+        resume[0] = seg_start[tail] + res[4 * tail]; resume[1] = res[4 * tail + 1]; resume[2] = g + res[4 * tail + 2]; resume[3] = res[4 * tail + 3];
+        return ZMI_E_OK;
+    }
+    // the clean segments are in `out`; the rest serially, with what has been produced as its history
+    const uint32_t at = seg_start[tail], done = (uint32_t)total;
+    std::vector<uint8_t> h2;
+    if (done >= 32768u) h2.assign(out + done - 32768u, out + done);
+    else {
+        const uint32_t keep = hist_len < 32768u - done ? hist_len : 32768u - done;
+        h2.assign(hist + hist_len - keep, hist + hist_len);
+        h2.insert(h2.end(), out, out + done);
+    }
+    uint32_t ol2 = 0, used2 = 0, res2[4] = {0, 0, 0, 0};
+    int32_t st2 = 0, det2 = 0;
+    rc = zmi_inflate_resume(c, in + at, in_len - at, 0u, h2.data(), (uint32_t)h2.size(), out + done, out_cap - done, &ol2, &st2, &det2, &used2, res2);
+    if (rc) return rc;
+    *out_len = done + ol2; *status = st2; *detail = det2; *in_used = at + used2;
+    resume[0] = at + res2[0]; resume[1] = res2[1]; resume[2] = done + res2[2]; resume[3] = res2[3];
+    return ZMI_E_OK;
+}
 
 // ---- host buffers, pipelined ----
 // A caller that hands over host memory pays PCIe both ways (the reference's own caller loop:

@@ -77,6 +77,10 @@ int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off, const uint
 int zmi_launch_resolve_jump(uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_len, uint32_t n_streams,
                             const uint64_t* d_bitmap, const uint64_t* d_bm_off, int32_t* d_ptr, uint64_t n_idx, uint32_t rounds,
                             uint32_t* d_flags, hipStream_t stream);
+int zmi_launch_resolve_jump_segments(uint8_t* d_fin, const uint64_t* d_soff, uint32_t nseg, const uint64_t* d_bitmap,
+                                     const uint64_t* d_bm_off, int32_t* d_ptr, uint64_t total, uint32_t hist_len, uint32_t rounds,
+                                     uint32_t* d_flags, uint32_t* d_err, const uint64_t* d_one_off, const uint32_t* d_one_len,
+                                     hipStream_t stream);
 int zmi_launch_inflate_resolve(uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_len, uint32_t n_streams,
                                const uint64_t* d_bitmap, const uint64_t* d_bm_off, const uint32_t* d_out_hist,
                                const uint32_t* d_order, hipStream_t stream);
