@@ -237,6 +237,11 @@ inline unsigned __builtin_amdgcn_alignbit(unsigned hi, unsigned lo, unsigned sh)
     uint64_t v = ((uint64_t)hi << 32) | lo;
     return (unsigned)(v >> (sh & 31));
 }
+// v_bfe_u32: offset and width are taken modulo 32; width 0 gives 0
+inline unsigned __builtin_amdgcn_ubfe(unsigned v, unsigned off, unsigned width) {
+    off &= 31u; width &= 31u;
+    return width ? (v >> off) & ((1u << width) - 1u) : 0u;
+}
 inline unsigned __umul24(unsigned a, unsigned b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
 inline float __log2f(float x) { return log2f(x); }
 inline int __popcll(uint64_t v) { return __builtin_popcountll(v); }

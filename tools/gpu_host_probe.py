@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Torch-free probe of the host-buffer path (zmi_deflate_batch / zmi_inflate_batch: pageable host memory in and out).
+    ZMI_HOST_THREADS=12 python tools/gpu_host_probe.py --shards 4096
+Prints GiB/s of raw data per call (best of --reps), the device-resident rate of the same shards beside it."""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+
+os.environ.setdefault("ZMI_TUNING", "1")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import gpu_fast_probe as P  # noqa: E402
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--shards", type=int, default=4096)
+    ap.add_argument("--level", type=int, default=6)
+    ap.add_argument("--reps", type=int, default=3)
+    a = ap.parse_args()
+    L, path = P.load_lib()
+    vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    L.zmi_deflate_batch.argtypes = [vp, vp, vp, vp, u32, i32, i32, i32, vp, u64, vp, vp]
+    L.zmi_inflate_batch.argtypes = [vp, vp, vp, vp, u32, i32, vp, vp, vp, vp, vp]
+    ctx = C.c_void_p()
+    assert L.zmi_ctx_create(C.byref(ctx), 0) == 0
+    B, S = 1 << 20, a.shards
+    stride = int(L.zmi_deflate_bound(B, 1))
+    d_in = P.dmalloc(S * B)
+    for s0 in range(0, S, 16384):
+        L.zmi_gen_shards_dev(ctx, d_in + s0 * B, 0x5A4C4942, s0, min(16384, S - s0), B, None)
+    P.hip.hipDeviceSynchronize()
+    h_in = np.empty(S * B, dtype=np.uint8)
+    P.ck(P.hip.hipMemcpy(h_in.ctypes.data, d_in, S * B, 2), "d2h")
+    P.hip.hipFree(d_in)
+    h_off = np.arange(S, dtype=np.uint64) * B
+    h_len = np.full(S, B, dtype=np.uint32)
+    h_out = np.zeros(S * stride, dtype=np.uint8)
+    h_olen = np.zeros(S, dtype=np.uint32)
+    h_st = np.zeros(S, dtype=np.int32)
+    best = None
+    for _ in range(a.reps):
+        t = time.perf_counter()
+        rc = L.zmi_deflate_batch(ctx, h_in.ctypes.data, h_off.ctypes.data, h_len.ctypes.data, S, a.level, 0, 1, h_out.ctypes.data, stride,
+                                 h_olen.ctypes.data, h_st.ctypes.data)
+        dt = time.perf_counter() - t
+        assert rc == 0 and not h_st.any(), L.zmi_last_error()
+        best = dt if best is None else min(best, dt)
+    print("deflate host path: %d shards %.1f ms = %.2f GiB/s (threads env %s)" % (S, best * 1e3, S * B / 2**30 / best, os.environ.get("ZMI_HOST_THREADS", "default")))
+    # inflate back through the host path
+    c_off = np.arange(S, dtype=np.uint64) * stride
+    o_off = np.arange(S, dtype=np.uint64) * B
+    o_cap = np.full(S, B, dtype=np.uint32)
+    h_back = np.zeros(S * B, dtype=np.uint8)
+    b_len = np.zeros(S, dtype=np.uint32)
+    b_st = np.zeros(S, dtype=np.int32)
+    best = None
+    for _ in range(a.reps):
+        t = time.perf_counter()
+        rc = L.zmi_inflate_batch(ctx, h_out.ctypes.data, c_off.ctypes.data, h_olen.ctypes.data, S, 1, h_back.ctypes.data, o_off.ctypes.data,
+                                 o_cap.ctypes.data, b_len.ctypes.data, b_st.ctypes.data)
+        dt = time.perf_counter() - t
+        assert rc == 0 and not b_st.any(), L.zmi_last_error()
+        best = dt if best is None else min(best, dt)
+    assert np.array_equal(h_back, h_in)
+    print("inflate host path: %d streams %.1f ms = %.2f GiB/s of output" % (S, best * 1e3, S * B / 2**30 / best))
+    # host memcpy bandwidth for reference (one thread)
+    t = time.perf_counter()
+    tmp = h_in.copy()
+    dt = time.perf_counter() - t
+    print("numpy copy of the input (one thread): %.2f GiB/s; cores %d" % (S * B / 2**30 / dt, os.cpu_count()))
+
+
+if __name__ == "__main__":
+    main()

@@ -16,7 +16,7 @@
 // parallelism -- one 64-lane wave per stream -- and the work of a stream is split so that no HBM round
 // trip sits in a dependent chain:
 //   decode  (zmi_inflate_kernel)          Huffman decoding only, two ways.  Fast pass (while >= 4 KiB of input lie ahead):
-//           3.5 KiB of the block are staged in LDS and cut into 64 sub-sequences, one per lane, decoded serially by that
+//           3.75 KiB of the block are staged in LDS and cut into 64 sub-sequences, one per lane, decoded serially by that
 //           lane; a prefix code resynchronises, so lanes started at a guess fall into step, lanes whose start is not the
 //           exit of the lane below walk again, and the consistent prefix is written (inf_fast_pass).  Token rounds
 //           (ends of streams, anything unusual): 64 lanes decode the tokens starting at 64 consecutive bit positions
@@ -70,10 +70,11 @@ static_assert(1023u + RES_NEAR + RES_SPAN + 258u + RES_BLK <= RES_RING && RES_RI
 #define INF_OP_LINK 0x80u   // | sub-table index bits; val = sub-table offset
 #define INF_ENTRY(val, op, bits) (((uint32_t)(val) << 16) | ((uint32_t)(op) << 8) | (uint32_t)(bits))
 
-// the compressed bytes of one fast pass (inf_fast_pass): 64 sub-sequences of 56 bytes
-#define INF_SUB_BITS 448u
+// the compressed bytes of one fast pass (inf_fast_pass): 64 sub-sequences of 60 bytes
+#define INF_SUB_BITS 480u   // 15 dwords: an ODD stride between the lanes' read positions (the walks stay within a dword or two of lock step,
+                            // so with 14 the three input reads of every token step were 4-way bank conflicts for the whole pass)
 #define INF_WARM_BITS 192u
-#define INF_FAST_BYTES 4096u     // 16 (alignment) + 64 * 56 + 6 (a token may end 48 bits behind the last boundary) + read slack
+#define INF_FAST_BYTES 4096u     // 16 (alignment) + 64 * 60 + 6 (a token may end 48 bits behind the last boundary) + read slack
 struct InfShared {
     uint32_t ltab[INF_LSIZE];
     uint32_t dtab[INF_DSIZE];
@@ -423,9 +424,9 @@ static __device__ __forceinline__ void inf_emit(uint8_t* dst, uint32_t* bm32, bo
 // The token rounds above spend 64 lanes on the ~8-15 tokens that really start inside a 128-bit window: ~230 VALU + ~250
 // SALU instructions per round.  A prefix code resynchronises: a decoder started at a wrong bit falls into step with the
 // true token sequence after a few dozen bits (the property massively parallel Huffman decoders are built on).  So the
-// next 3.5 KiB of the block are cut into 64 sub-sequences of 448 bits and every LANE decodes its own one serially --
+// next 3.75 KiB of the block are cut into 64 sub-sequences of 480 bits and every LANE decodes its own one serially --
 // 64 tokens per ~45 instructions instead of ~10 per ~480:
-//   1. sync:  lane 0 starts at the true position, lane i at "bit i * 448"; each decodes until it crosses into the next
+//   1. sync:  lane 0 starts at the true position, lane i at "bit i * 480"; each decodes until it crosses into the next
 //             sub-sequence and reports where (its exit).  Lanes whose start is not the exit of the lane below restart
 //             there; after a few iterations a prefix 0..m of the lanes is consistent -- lane 0 is right by construction,
 //             so the whole prefix is the true token chain.  The same pass counts every lane's output bytes and how far its
@@ -444,74 +445,110 @@ struct InfLane {
 };
 template <bool WRITE>
 static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, const uint8_t* fb, uint32_t start, uint32_t boundary,
-                                                          bool active, uint8_t* dst, uint32_t* bm32, uint32_t obase) {
+                                                          bool active, uint8_t* dst, uint32_t* bm32, uint32_t obase,
+                                                          uint32_t nout_total) {
     InfLane R;
-    R.exit = start; R.nout = 0; R.need = 0; R.flags = 0;
     const uint32_t* fw = (const uint32_t*)fb;
-    uint32_t pos = start;
+    uint32_t pos = start, nout = 0, need = 0, flags = 0;
     bool go = active && pos < boundary;
-    // One token per lane and iteration.  Straight-line selects instead of branches (a divergent branch costs exec-mask
-    // bookkeeping on the scalar unit; as nested ifs this loop had ~15 of them per token); the second-level table reads and
-    // the distance code sit behind wave-uniform branches, as in inf_tok.  The loop itself is wave-uniform too: lanes that
-    // are done ride along with their updates switched off.
-    while (__ballot(go)) {
-        const uint32_t wi = pos >> 5, sh = pos & 31u;
+    // WRITE: a lane's output is one contiguous range [obase, obase + nout_total) (known from the sync walk), written front to
+    // back.  Byte stores from 64 lanes are 64 different cache lines per instruction -- the texture path takes them one line per
+    // cycle, and a match was three of them plus an atomic: the write walks kept that path busy for half of the kernel's time.
+    // So the bytes are collected in a 64-bit accumulator over the aligned dword the lane stands in (and the one behind it: a
+    // 3-byte record may straddle), a dword is stored when the lane leaves it -- the part of it that lies in a hole is
+    // whatever the accumulator holds, zeros: the resolve pass overwrites every hole -- and the bitmap bits are collected
+    // per 32-bit word.  Only the two dwords at the ends of the range are shared with the neighbours: their bytes are stored
+    // one by one behind the loop.
+    const uint32_t A = WRITE ? (uint32_t)((uintptr_t)dst & 3u) : 0u;
+    uint32_t* const dw = (uint32_t*)(dst - A);
+    const uint32_t o_first = obase + A, o_end = o_first + (active ? nout_total : 0u);   // (in bytes from dw)
+    uint32_t o = o_first, first_acc = 0, bmw = 0, bmacc = 0;
+    uint64_t acc = 0;
+    // One token per lane and iteration; the loop is wave-uniform (lanes that are done ride along with their state frozen) and
+    // instruction-issue bound (17 streams per CU: the LDS round trips hide behind the other waves), so it is written for
+    // instruction count: every quantity comes straight out of the entry's fields (the low nibble of `op` is the number of
+    // extra bits for a length / distance code and ZERO for a literal, an end of block and an invalid code; holes of the
+    // tables are INF_OP_BAD entries, inf_build), nothing is gated by `go` except the four state updates at the end, the
+    // second-level reads and the distance code sit behind wave-uniform branches.
+    if (__ballot(go)) do {
+        const uint32_t wi = pos >> 5;
 #ifdef ZMI_EMU_DEBUG
         if (wi > 1100u) { fprintf(stderr, "lane %u wave %u pos %u start %u boundary %u active %d\n", zmi_lane(), zmi_wave(), pos, start, boundary, (int)active); abort(); }
 #endif
         const uint32_t d0 = fw[wi], d1 = fw[wi + 1u], d2 = fw[wi + 2u];
-        const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh), hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+        const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, pos & 31u);
         uint32_t e = S->ltab[lo & ((1u << INF_LROOT) - 1u)];
-        const bool link = ((e >> 8) & INF_OP_LINK) != 0u;
-        if (__ballot(link)) {
-            const uint32_t sb = (e >> 8) & 0x0Fu;
-            const uint32_t e2 = S->ltab[link ? (e >> 16) + ((lo >> INF_LROOT) & ((1u << sb) - 1u)) : 0u];
+        if (__ballot((e & (INF_OP_LINK << 8)) != 0u)) {
+            const bool link = (e & (INF_OP_LINK << 8)) != 0u;
+            const uint32_t e2 = S->ltab[link ? (e >> 16) + __builtin_amdgcn_ubfe(lo, INF_LROOT, (e >> 8) & 0x0Fu) : 0u];
             e = link ? e2 : e;
         }
-        const uint32_t bits = e & 0xFFu, op = (e >> 8) & 0xFFu;
-        const bool bad = go && (op == INF_OP_BAD || bits == 0u);
-        const bool is_eob = go && op == INF_OP_EOB;
-        const bool is_len = go && (op & INF_OP_BASE) != 0u && !bad;
-        const uint32_t xb = is_len ? (op & 0x0Fu) : 0u;
-        const uint32_t val = (e >> 16) + ((lo >> bits) & ((1u << xb) - 1u));   // literal byte | match length
-        const uint32_t used = bits + xb;                                       // <= 20
-        uint32_t dist = 0, dl = 0;
-        bool dbad = false;
+        const uint32_t bits = e & 0xFFu, xb = (e >> 8) & 0x0Fu;
+        const uint32_t val = (e >> 16) + __builtin_amdgcn_ubfe(lo, bits, xb);   // literal byte | match length
+        const uint32_t used = bits + xb;                                        // <= 20
+        const bool is_len = (e & (INF_OP_BASE << 8)) != 0u, is_eob = (e & (INF_OP_EOB << 8)) != 0u;
+        bool err = (e & (INF_OP_BAD << 8)) != 0u;                               // "invalid literal/length code"
+        uint32_t dist = 0, adv = used;
         if (__ballot(is_len)) {
+            const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, pos & 31u);
             const uint32_t rest = __builtin_amdgcn_alignbit(hi, lo, used);
             uint32_t d = S->dtab[rest & ((1u << INF_DROOT) - 1u)];
-            const bool dlink = is_len && ((d >> 8) & INF_OP_LINK) != 0u;
+            const bool dlink = is_len && (d & (INF_OP_LINK << 8)) != 0u;
             if (__ballot(dlink)) {
-                const uint32_t sb = (d >> 8) & 0x0Fu;
-                const uint32_t d2x = S->dtab[dlink ? (d >> 16) + ((rest >> INF_DROOT) & ((1u << sb) - 1u)) : 0u];
+                const uint32_t d2x = S->dtab[dlink ? (d >> 16) + __builtin_amdgcn_ubfe(rest, INF_DROOT, (d >> 8) & 0x0Fu) : 0u];
                 d = dlink ? d2x : d;
             }
-            const uint32_t dbits = d & 0xFFu, dop = (d >> 8) & 0xFFu;
-            dbad = is_len && (dop == INF_OP_BAD || dbits == 0u || !(dop & INF_OP_BASE));
-            const uint32_t dxb = dop & 0x0Fu;
-            dist = (d >> 16) + ((rest >> dbits) & ((1u << dxb) - 1u));
-            dl = dbits + dxb;
+            const uint32_t dbits = d & 0xFFu, dxb = (d >> 8) & 0x0Fu;
+            const uint32_t dv = (d >> 16) + __builtin_amdgcn_ubfe(rest, dbits, dxb);
+            err = err || (is_len && (d & (INF_OP_BASE << 8)) == 0u);            // "invalid distance code" (a hole or a non-distance entry)
+            dist = is_len ? dv : 0u;
+            adv += is_len ? dbits + dxb : 0u;
         }
-        const bool err = bad || dbad;
-        const bool mat = is_len && !err, lit = go && !is_len && !is_eob && !err;
+        const bool live = go && !err;                  // the token counts
+        const bool mat = live && is_len, lit = live && !is_len && !is_eob;
         if (WRITE) {
-            const uint32_t off = obase + R.nout;
-            if (lit) dst[off] = (uint8_t)val;
+            const uint32_t rec = (dist - 1u) | ((val - 3u) << 15);         // the record the resolve pass reads (inf_emit)
+            const uint32_t n = mat ? val : (lit ? 1u : 0u);
+            const uint32_t v = mat ? rec : (lit ? val : 0u);
+            acc |= (uint64_t)v << ((o & 3u) * 8u);
+            const uint32_t no = o + n, w = o >> 2, cross = (no >> 2) - w;
             if (mat) {
-                const uint32_t rec = (dist - 1u) | ((val - 3u) << 15);     // the record the resolve pass reads (inf_emit)
-                dst[off] = (uint8_t)rec;
-                dst[off + 1u] = (uint8_t)(rec >> 8);
-                dst[off + 2u] = (uint8_t)(rec >> 16);
-                atomicOr(&bm32[off >> 5], 1u << (off & 31u));
+                const uint32_t off = o - A, bi = off >> 5;
+                if (bi != bmw && bmacc != 0u) { atomicOr(&bm32[bmw], bmacc); bmacc = 0u; }
+                bmw = bi;
+                bmacc |= 1u << (off & 31u);
             }
+            if (cross != 0u) {
+                const uint32_t lo32 = (uint32_t)acc, hi32 = (uint32_t)(acc >> 32);
+                if (w == (o_first >> 2) && (o_first & 3u) != 0u) first_acc = lo32; else dw[w] = lo32;
+                if (cross > 1u && hi32 != 0u) dw[w + 1u] = hi32;           // (the tail of a record; dwords that are all hole stay unwritten)
+                acc = cross > 1u ? 0ull : (uint64_t)hi32;
+            }
+            o = no;
         }
-        const uint32_t reach = dist > R.nout ? dist - R.nout : 0u;            // history in front of this lane's output
-        R.need = (mat && reach > R.need) ? reach : R.need;
-        R.nout += mat ? val : (lit ? 1u : 0u);
-        pos += (err || !go) ? 0u : (is_len ? used + dl : bits);
-        R.flags |= err ? 1u : (is_eob ? 2u : 0u);
-        go = go && !err && !is_eob && pos < boundary;
+        const uint32_t reach = dist > nout ? dist - nout : 0u;             // history in front of this lane's output
+        need = (mat && reach > need) ? reach : need;
+        nout += mat ? val : (lit ? 1u : 0u);
+        pos += live ? adv : 0u;
+        flags |= go ? (err ? 1u : (is_eob ? 2u : 0u)) : 0u;
+        go = live && !is_eob && pos < boundary;
+    } while (__ballot(go));
+    if (WRITE) {
+        if (bmacc != 0u) atomicOr(&bm32[bmw], bmacc);
+        uint8_t* const db = dst - A;
+        const bool first_pending = (o_first & 3u) != 0u && (o_first >> 2) < (o_end >> 2);
+#pragma unroll
+        for (uint32_t j = 1; j < 4u; ++j) {
+            const uint32_t q = (o_first & ~3u) + j;
+            if (first_pending && q >= o_first) db[q] = (uint8_t)(first_acc >> (8u * j));
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 3u; ++j) {
+            const uint32_t q = (o_end & ~3u) + j;
+            if (q >= o_first && q < o_end) db[q] = (uint8_t)((uint32_t)acc >> (8u * j));
+        }
     }
+    R.nout = nout; R.need = need; R.flags = flags;
     R.exit = pos;
     return R;
 }
@@ -521,7 +558,7 @@ static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, co
 static __device__ __forceinline__ uint32_t inf_fast_pass(InfShared* S, const uint8_t* src, uint64_t P, uint8_t* dst,
                                                       uint32_t* bm32, uint32_t opos, uint32_t cap, uint32_t hist, uint32_t sub,
                                                       uint32_t* bits_used, uint32_t* out_made, uint32_t* hit_eob) {
-    // sub: bits per lane, 64 .. INF_SUB_BITS (wave-uniform; see the caller for how it is chosen)
+    // sub: bits per lane, 96 .. INF_SUB_BITS (wave-uniform; see the caller for how it is chosen)
     const uint32_t lane = zmi_lane();
     // stage the input: from the 16-byte line holding bit P, 4 KiB, four coalesced loads
     const uint32_t ib = (uint32_t)(P >> 3);
@@ -541,10 +578,10 @@ static __device__ __forceinline__ uint32_t inf_fast_pass(InfShared* S, const uin
         // (lane 0 rides along switched off: it must still hold a position inside the staged bytes, its reads happen; with
         // short sub-sequences the lowest lanes warm up from the pass's own first bit, which is a true token start)
         const uint32_t wfrom = start - p_rel > INF_WARM_BITS ? start - INF_WARM_BITS : p_rel;
-        const InfLane Wm = inf_lane_decode<false>(S, S->fb, wfrom, start, lane != 0u, nullptr, nullptr, 0u);
+        const InfLane Wm = inf_lane_decode<false>(S, S->fb, wfrom, start, lane != 0u, nullptr, nullptr, 0u, 0u);
         if (lane != 0u && Wm.flags == 0u) start = Wm.exit;   // (a warm-up that ran into an invalid code or an end of block: keep the guess)
     }
-    InfLane R = inf_lane_decode<false>(S, S->fb, start, boundary, true, nullptr, nullptr, 0u);
+    InfLane R = inf_lane_decode<false>(S, S->fb, start, boundary, true, nullptr, nullptr, 0u, 0u);
     uint32_t good = 1u;   // lanes 0 .. good-1 are known to sit on the true token chain
     for (uint32_t it = 0;; ++it) {
         // the lane below tells where this lane has to start
@@ -561,7 +598,7 @@ static __device__ __forceinline__ uint32_t inf_fast_pass(InfShared* S, const uin
         // restart the wrong lanes where their neighbours ended (most fall into step inside their own sub-sequence, so
         // the next check usually finds everything consistent)
         if (wrong) start = below_exit;
-        const InfLane N = inf_lane_decode<false>(S, S->fb, start, boundary, wrong, nullptr, nullptr, 0u);
+        const InfLane N = inf_lane_decode<false>(S, S->fb, start, boundary, wrong, nullptr, nullptr, 0u, 0u);
         if (wrong) R = N;
     }
     // 2. scan: offsets, and what can be committed
@@ -575,7 +612,7 @@ static __device__ __forceinline__ uint32_t inf_fast_pass(InfShared* S, const uin
     if (badm) { const uint32_t fb1 = (uint32_t)__ffsll((unsigned long long)badm) - 1u; commit = fb1 < commit ? fb1 : commit; }
     if (commit == 0u) return 0u;
     // 3. write
-    (void)inf_lane_decode<true>(S, S->fb, start, boundary, lane < commit, dst, bm32, base);
+    (void)inf_lane_decode<true>(S, S->fb, start, boundary, lane < commit, dst, bm32, base, R.nout);
     const uint32_t last = commit - 1u;
     *bits_used = zmi_readlane(R.exit, last) - p_rel;
     *out_made = zmi_readlane(incl, last);
@@ -593,7 +630,7 @@ static __device__ __forceinline__ uint32_t inf_fast_pass(InfShared* S, const uin
 // of wave w has to start where lane 63 of wave w - 1 ended, and a wave commits only if every wave below it committed all
 // its lanes.  Wave 0 is the stream's master (headers, table construction, token rounds, everything the single-wave kernel
 // does); the other waves sleep at a workgroup barrier until it posts a pass.  A pass covers at most the rest of the block
-// (the tables change behind an end-of-block), so the gain is bounded by the block size: 8 waves x 3.5 KiB = 28 KiB of
+// (the tables change behind an end-of-block), so the gain is bounded by the block size: 8 waves x 3.75 KiB = 30 KiB of
 // compressed data, more than the ~20 KiB of a 16 383-symbol zlib block.
 #define INF_MW 8u
 #define INF_MW_ROUNDS 4u   // cross-wave fix-up rounds (a wave whose lane 0 started at a wrong guess restarts it and re-stitches)
@@ -647,10 +684,10 @@ static __device__ __noinline__ void inf_pass_mw(const uint8_t* src, uint8_t* dst
         {
             const bool warm = lane != 0u || wave != 0u;
             const uint32_t wfrom = (wave != 0u || start - p_rel > INF_WARM_BITS) ? start - INF_WARM_BITS : p_rel;
-            const InfLane Wm = inf_lane_decode<false>(S, fb, wfrom, start, warm, nullptr, nullptr, 0u);
+            const InfLane Wm = inf_lane_decode<false>(S, fb, wfrom, start, warm, nullptr, nullptr, 0u, 0u);
             if (warm && Wm.flags == 0u) start = Wm.exit;
         }
-        R = inf_lane_decode<false>(S, fb, start, boundary, true, nullptr, nullptr, 0u);
+        R = inf_lane_decode<false>(S, fb, start, boundary, true, nullptr, nullptr, 0u, 0u);
     }
     for (uint32_t g = 0;; ++g) {
         if (act) {
@@ -665,7 +702,7 @@ static __device__ __noinline__ void inf_pass_mw(const uint8_t* src, uint8_t* dst
                 good = first_wrong < first_stop ? first_wrong : first_stop;
                 if (first_stop <= first_wrong || first_wrong >= 64u || it == 5u) break;
                 if (wrong) start = below_exit;
-                const InfLane N = inf_lane_decode<false>(S, fb, start, boundary, wrong, nullptr, nullptr, 0u);
+                const InfLane N = inf_lane_decode<false>(S, fb, start, boundary, wrong, nullptr, nullptr, 0u, 0u);
                 if (wrong) R = N;
             }
             const uint32_t s0 = zmi_readlane(start, 0u), e63 = zmi_readlane(R.exit, 63u);
@@ -685,7 +722,7 @@ static __device__ __noinline__ void inf_pass_mw(const uint8_t* src, uint8_t* dst
             if (want != have && want >= org && want < org + 64u) {
                 const bool l0 = lane == 0u;
                 if (l0) start = want - org + p_rel;
-                const InfLane N = inf_lane_decode<false>(S, fb, start, boundary, l0, nullptr, nullptr, 0u);
+                const InfLane N = inf_lane_decode<false>(S, fb, start, boundary, l0, nullptr, nullptr, 0u, 0u);
                 if (l0) R = N;
             }
         }
@@ -739,7 +776,7 @@ static __device__ __noinline__ void inf_pass_mw(const uint8_t* src, uint8_t* dst
             fc = w == wave ? c : fc;
         }
     }
-    if (fc != 0u) (void)inf_lane_decode<true>(S, fb, start, boundary, lane < fc, dst, bm32, base);
+    if (fc != 0u) (void)inf_lane_decode<true>(S, fb, start, boundary, lane < fc, dst, bm32, base, R.nout);
     if (total_lanes != 0u && wave == last_wave) {
         const uint32_t k = fc - 1u;
         const uint32_t bits = zmi_readlane(R.exit, k) - p_rel + org, outm = wbase - opos + zmi_readlane(incl, k),
@@ -1050,14 +1087,14 @@ __global__ void __launch_bounds__(64 * NW) zmi_inflate_kernel(const uint8_t* __r
                     if (Pend - P >= 8ull * (INF_FAST_BYTES + 32u)) {
                         // Bits per lane.  A pass ends at the end of the block, and the lanes behind that point have worked
                         // for nothing: streams of small blocks (drifting data: 4 KiB a block) spent every second pass
-                        // on a block's last few hundred bytes at the price of 3.5 KiB.  The block before is the estimate
+                        // on a block's last few hundred bytes at the price of 3.75 KiB.  The block before is the estimate
                         // of how much is left of this one; what is left is spread over all 64 lanes.
                         uint32_t sub = INF_SUB_BITS;
                         if (last_blk_bits != 0u) {
                             const uint64_t done = P - Pblk;
                             const uint32_t rest = done < (uint64_t)last_blk_bits ? last_blk_bits - (uint32_t)done : 0u;
-                            if (rest == 0u) sub = 256u;   // longer than the block before: feel the way forward
-                            else if (rest < 56u * INF_SUB_BITS) { sub = (rest + (rest >> 3) + 63u) >> 6; sub = sub < 64u ? 64u : (sub > INF_SUB_BITS ? INF_SUB_BITS : sub); }
+                            if (rest == 0u) sub = 288u;   // longer than the block before: feel the way forward
+                            else if (rest < 56u * INF_SUB_BITS) { sub = (rest + (rest >> 3) + 63u) >> 6; sub = (((sub + 31u) >> 5) | 1u) << 5; sub = sub < 96u ? 96u : (sub > INF_SUB_BITS ? INF_SUB_BITS : sub); }   // (whole dwords, an odd number of them)
                         }
                         uint32_t fbits = 0, fout = 0, feob = 0;
                         uint32_t lanes;
@@ -1068,13 +1105,14 @@ __global__ void __launch_bounds__(64 * NW) zmi_inflate_kernel(const uint8_t* __r
                             if (last_blk_bits != 0u) {
                                 const uint64_t done = P - Pblk;
                                 const uint32_t rest = done < (uint64_t)last_blk_bits ? last_blk_bits - (uint32_t)done : 0u;
-                                if (rest == 0u) { nact = 2u; sub = 256u; }
+                                if (rest == 0u) { nact = 2u; sub = 288u; }
                                 else {
                                     const uint32_t want = rest + (rest >> 3);
                                     nact = (want + 64u * INF_SUB_BITS - 1u) / (64u * INF_SUB_BITS);
                                     nact = nact < 1u ? 1u : (nact > NW ? NW : nact);
                                     sub = (want + 64u * nact - 1u) / (64u * nact);
-                                    sub = sub < 64u ? 64u : (sub > INF_SUB_BITS ? INF_SUB_BITS : sub);
+                                    sub = (((sub + 31u) >> 5) | 1u) << 5;
+                                    sub = sub < 96u ? 96u : (sub > INF_SUB_BITS ? INF_SUB_BITS : sub);
                                 }
                             } else sub = INF_SUB_BITS;
                             while (nact > 1u && Pend - P < (uint64_t)(nact - 1u) * 64u * sub + 8ull * (INF_FAST_BYTES + 32u)) --nact;

@@ -39,18 +39,20 @@ __global__ void __launch_bounds__(1024) zmi_scan_sizes_kernel(const uint32_t* __
     if (t == 1023u) off[n] = part[1023];
 }
 
-// grid = n * split workgroups: workgroup b handles tiles b % split, b % split + split, ... of range b / split
+// n * split jobs: job b handles tiles b % split, b % split + split, ... of range b / split; the grid is the number of jobs, or
+// fewer workgroups that take the jobs in turn (a destination in host memory: see zmi_launch_copy_ranges_few)
 __global__ void __launch_bounds__(PK_T) zmi_copy_ranges_kernel(const uint8_t* __restrict__ src, const uint64_t* __restrict__ src_off,
                                                               uint64_t src_stride, const uint32_t* __restrict__ len,
                                                               uint8_t* __restrict__ dst, const uint64_t* __restrict__ dst_off,
-                                                              uint64_t dst_cap, uint32_t split) {
+                                                              uint64_t dst_cap, uint32_t split, uint32_t jobs) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[PK_TILE + 32];
     const uint32_t t = threadIdx.x;
-    const uint32_t r = blockIdx.x / split, part = blockIdx.x % split;
+  for (uint32_t job = blockIdx.x; job < jobs; job += gridDim.x) {
+    const uint32_t r = job / split, part = job % split;
     const uint32_t l = len[r];
     const uint64_t so = src_off ? src_off[r] : (uint64_t)r * src_stride;
     const uint64_t d0 = dst_off[r];
-    if (d0 + l > dst_cap) return;   // does not fit: the caller sees that from the offsets
+    if (d0 + l > dst_cap) continue;   // does not fit: the caller sees that from the offsets
     const uint8_t* s = src + so;
     const uint32_t mis = (uint32_t)((uintptr_t)s & 15u);   // the tile loads start at the 16-byte line at or below s
     for (uint32_t base = part * PK_TILE; base < l; base += split * PK_TILE) {
@@ -83,6 +85,7 @@ __global__ void __launch_bounds__(PK_T) zmi_copy_ranges_kernel(const uint8_t* __
         }
         __syncthreads();
     }
+  }
 }
 
 extern "C" int zmi_launch_scan_sizes(const uint32_t* d_len, uint32_t n, uint64_t* d_off, hipStream_t stream) {
@@ -99,6 +102,23 @@ extern "C" int zmi_launch_copy_ranges(const uint8_t* d_src, const uint64_t* d_sr
     const uint32_t tiles = (max_len + PK_TILE - 1u) / PK_TILE;
     while ((uint64_t)n * split < 4096u && split < tiles) split <<= 1;
     ZMI_LAUNCH(zmi_copy_ranges_kernel, dim3(n * split), dim3(PK_T), 0, stream, d_src, d_src_off, src_stride, d_len, d_dst, d_dst_off,
-               dst_cap, split);
+               dst_cap, split, n * split);
+    return 0;
+}
+
+// The same copy with `groups` workgroups only, for a destination in pinned HOST memory (the host-buffer pipeline's slab): the
+// stores leave over PCIe at ~50 GB/s whatever the launch looks like, and a launch of thousands of workgroups sits on every CU
+// for the 5 ms that takes -- the next chunk's match search (one 1024-thread workgroup per CU, 152 KiB of LDS) could not
+// start beside it.  A few dozen workgroups keep the link busy and leave the CUs to the kernels.
+extern "C" int zmi_launch_copy_ranges_few(const uint8_t* d_src, const uint64_t* d_src_off, uint64_t src_stride, const uint32_t* d_len,
+                                          uint32_t n, uint8_t* d_dst, const uint64_t* d_dst_off, uint64_t dst_cap, uint32_t max_len,
+                                          uint32_t groups, hipStream_t stream) {
+    if (n == 0) return 0;
+    uint32_t split = 1;
+    const uint32_t tiles = (max_len + PK_TILE - 1u) / PK_TILE;
+    while ((uint64_t)n * split < 4096u && split < tiles) split <<= 1;
+    const uint32_t jobs = n * split;
+    ZMI_LAUNCH(zmi_copy_ranges_kernel, dim3(jobs < groups ? jobs : groups), dim3(PK_T), 0, stream, d_src, d_src_off, src_stride, d_len, d_dst,
+               d_dst_off, dst_cap, split, jobs);
     return 0;
 }

@@ -84,10 +84,12 @@ struct zmi_ctx {
     struct hb_slot { zmi_buf in, out, meta; hipEvent_t in_done, k_done, out_done; } hb[ZMI_HB_SLOTS];
     zmi_buf hb_slab[ZMI_HB_SLOTS];                              // device: the chunk's compressed streams packed densely (what travels back)
     zmi_buf hb_pin_in[ZMI_HB_SLOTS], hb_pin_out[ZMI_HB_SLOTS], hb_pin_meta[ZMI_HB_SLOTS];   // pinned host staging of the two slots
-    hipStream_t hs_in = nullptr, hs_k = nullptr, hs_out = nullptr;
+    hipStream_t hs_in = nullptr, hs_k = nullptr, hs_out = nullptr, hs_slab = nullptr;
     bool hb_live = false;
     uint64_t inflate_out_limit = 0;  // output bytes one inflate batch may cover; 0 = scratch_limit
     hipStream_t host_stream = nullptr;  // zmi_ctx_set_stream: where the host-buffer wrappers copy and launch
+    hipStream_t side = nullptr;         // deflate: the wrapper checksums run here, beside the match search (zmi_deflate_impl)
+    hipEvent_t ev_fork{}, ev_join{};
 };
 
 static int zmi_reserve(zmi_buf& b, size_t bytes) {
@@ -129,6 +131,7 @@ extern "C" int zmi_ctx_destroy(zmi_ctx* c) {
     if (c->st_in.p) (void)hipFree(c->st_in.p);
     if (c->st_out.p) (void)hipFree(c->st_out.p);
     if (c->st_meta.p) (void)hipFree(c->st_meta.p);
+    if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); }
     if (c->sp_out.p) (void)hipFree(c->sp_out.p);
     if (c->hb_live) {
         for (auto& sl : c->hb) {
@@ -143,7 +146,7 @@ extern "C" int zmi_ctx_destroy(zmi_ctx* c) {
             if (c->hb_pin_out[k].p) (void)hipHostFree(c->hb_pin_out[k].p);
             if (c->hb_pin_meta[k].p) (void)hipHostFree(c->hb_pin_meta[k].p);
         }
-        (void)hipStreamDestroy(c->hs_in); (void)hipStreamDestroy(c->hs_k); (void)hipStreamDestroy(c->hs_out);
+        (void)hipStreamDestroy(c->hs_in); (void)hipStreamDestroy(c->hs_k); (void)hipStreamDestroy(c->hs_out); if (c->hs_slab) (void)hipStreamDestroy(c->hs_slab);
     }
     delete c;
     return ZMI_E_OK;
@@ -380,9 +383,26 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     uint32_t* d_adler = (uint32_t*)c->sums.p;
     uint32_t* d_crc = d_adler + n;
     uint32_t kind = wrap == ZMI_WRAP_ZLIB ? 1u : (wrap == ZMI_WRAP_GZIP ? 2u : 0u);
+    // The checksums are needed by the encoder's trailers only: they run on a side stream beside the match search (one is
+    // HBM-bound, the other instruction-bound; in a launch of a few hundred shards the checksum kernel is one workgroup per
+    // shard with nothing to hide its latency behind: 4.5 ms in front of 6.4 ms of lz77 for 512 shards) and join in front of
+    // the first encode launch.
+    bool forked = false;
+    struct join_guard { zmi_ctx* c; hipStream_t st; bool& f; ~join_guard() { if (f) (void)hipStreamWaitEvent(st, c->ev_join, 0); } } join_on_exit{c, stream, forked};
     if (kind) {
-        zmi_scope_timer tm(c, ZMI_K_CHECKSUM, stream);
-        zmi_launch_checksum((const uint8_t*)d_in, d_in_off, d_in_len, n, kind, d_adler, d_crc, stream);
+        if (!c->side) {
+            ZMI_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+            ZMI_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            ZMI_HIP(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+        }
+        ZMI_HIP(hipEventRecord(c->ev_fork, stream));
+        ZMI_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+        {
+            zmi_scope_timer tm(c, ZMI_K_CHECKSUM, c->side);
+            zmi_launch_checksum((const uint8_t*)d_in, d_in_off, d_in_len, n, kind, d_adler, d_crc, c->side);
+        }
+        ZMI_HIP(hipEventRecord(c->ev_join, c->side));
+        forked = true;
     }
 
     const zmi_level_cfg& L = kLevels[level];
@@ -493,6 +513,7 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
                                       per_shard / 4u, lp, stream);
             if (lrc) return zmi_fail(ZMI_E_HIP, "lz77 launch setup", (hipError_t)lrc);
         }
+        if (forked) { ZMI_HIP(hipStreamWaitEvent(stream, c->ev_join, 0)); forked = false; }
         zmi_scope_timer tm2(c, ZMI_K_ENCODE, stream);
         zmi_launch_encode((const uint8_t*)d_in, d_in_off, d_in_len, (uint32_t)first, cnt, (uint32_t*)c->match.p,
                           per_shard / 4u, d_adler, d_crc, (uint8_t*)d_out, out_stride, (uint32_t)out_stride, d_out_len,
@@ -623,6 +644,7 @@ static int zmi_host_pipeline_init(zmi_ctx* c) {   // three streams (in / kernels
     ZMI_HIP(hipStreamCreateWithFlags(&c->hs_in, hipStreamNonBlocking));
     ZMI_HIP(hipStreamCreateWithFlags(&c->hs_k, hipStreamNonBlocking));
     ZMI_HIP(hipStreamCreateWithFlags(&c->hs_out, hipStreamNonBlocking));
+    ZMI_HIP(hipStreamCreateWithFlags(&c->hs_slab, hipStreamNonBlocking));
     for (auto& sl : c->hb) {
         ZMI_HIP(hipEventCreateWithFlags(&sl.in_done, hipEventDisableTiming));
         ZMI_HIP(hipEventCreateWithFlags(&sl.k_done, hipEventDisableTiming));
@@ -860,12 +882,14 @@ extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len,
 //   stage out  the host threads scatter the streams to the caller's out + i * out_stride.
 // Per chunk the host thread stages chunk k in, hands chunk k-2 out (the slot chunk k is about to use), issues chunk k's
 // copies and kernels and chunk k-1's slab copy: the device works on chunks k-1 and k while the host copies.
+#include <chrono>
 #include <thread>
 #include <atomic>
 static unsigned zmi_host_threads() {
     unsigned t = std::thread::hardware_concurrency() / 2u;
-    if (const char* e = zmi_tune("ZMI_HOST_THREADS")) { if (atoi(e) > 0) t = (unsigned)atoi(e); }
-    return t < 1u ? 1u : (t > 8u ? 8u : t);
+    t = t < 1u ? 1u : (t > 8u ? 8u : t);
+    if (const char* e = zmi_tune("ZMI_HOST_THREADS")) { if (atoi(e) > 0) t = (unsigned)atoi(e) > 64u ? 64u : (unsigned)atoi(e); }
+    return t;
 }
 struct zmi_copy_job { void* dst; const void* src; size_t n; };
 // the jobs' bytes split evenly over T threads (the calling thread is one of them)
@@ -913,7 +937,12 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     // A chunk should fill the chip by itself: one workgroup per shard on 256 CUs wants a few hundred shards per launch (measured:
     // 128-shard chunks made the kernels, not PCIe, the bottleneck; 512 shards of 1 MiB run within 10 % of the per-shard time of
     // the largest launches).  ZMI_HOST_CHUNK (bytes) overrides both bounds (tests).
-    uint64_t budget = 512ull << 20;
+    // Large batches take larger chunks (an eighth of the input, up to 1 GiB): launches of 512 shards run at 40 GiB/s (two rounds of
+    // workgroups on 256 CUs, the slower data classes set the pace), launches of 1024+ at 55-60, above the 46 GiB/s PCIe delivers.
+    uint64_t total_in = 0;
+    for (uint32_t i = 0; i < n; ++i) total_in += in_len[i];
+    uint64_t budget = total_in / 8u;
+    budget = budget < (512ull << 20) ? (512ull << 20) : (budget > (1024ull << 20) ? (1024ull << 20) : budget);
     uint32_t min_count = 384u;
     if (const char* e = zmi_tune("ZMI_HOST_CHUNK")) { if (atoll(e) > 0) { budget = (uint64_t)atoll(e); min_count = 1u; } }
     struct chunk { uint32_t first, count; uint64_t bytes; std::vector<uint64_t> doff; };
@@ -950,12 +979,16 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     }
     // meta (device and pinned twin): doff u64[count] | in_len u32[count] | out_len u32[count] | status i32[count] | soff u64[count + 1]
     const size_t meta_bytes = (size_t)max_count * 28u + 64u;
+    bool zero_copy = true;   // the slab is written into pinned host memory by the pack kernel (0: packed on the device, copied by a copy engine)
+    if (const char* zv = zmi_tune("ZMI_HB_ZEROCOPY")) zero_copy = atoi(zv) != 0;
+    uint32_t pack_groups = 16u;   // workgroups of the pack kernel that writes to host memory (zmi_launch_copy_ranges_few)
+    if (const char* gv = zmi_tune("ZMI_HB_PACK_GROUPS")) { if (atoi(gv) > 0) pack_groups = (uint32_t)atoi(gv); }
     for (int k = 0; k < ZMI_HB_SLOTS; ++k) {
         zmi_ctx::hb_slot& sl = c->hb[k];
         int rc = zmi_reserve(sl.in, (size_t)max_bytes + 64u);
         if (!rc) rc = zmi_reserve(sl.out, (size_t)max_count * out_stride + 64u);
         if (!rc) rc = zmi_reserve(sl.meta, meta_bytes);
-        if (!rc) rc = zmi_reserve(c->hb_slab[k], (size_t)max_slab + 64u);
+        if (!rc && !zero_copy) rc = zmi_reserve(c->hb_slab[k], (size_t)max_slab + 64u);
         if (!rc) rc = zmi_reserve_pinned(c->hb_pin_in[k], (size_t)max_bytes + 64u);
         if (!rc) rc = zmi_reserve_pinned(c->hb_pin_out[k], (size_t)max_slab + 64u);
         if (!rc) rc = zmi_reserve_pinned(c->hb_pin_meta[k], meta_bytes);
@@ -992,6 +1025,7 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         const int s2 = (int)(k % ZMI_HB_SLOTS);
         zmi_ctx::hb_slot& sl = c->hb[s2];
         if (k >= ZMI_HB_SLOTS) ZMI_HIP(hipStreamWaitEvent(c->hs_in, sl.k_done, 0));   // the kernels of the chunk that had this slot have read it
+        if (k >= ZMI_HB_SLOTS && zero_copy) ZMI_HIP(hipStreamWaitEvent(c->hs_in, slab_done[s2], 0));   // ... and its pack has read the sizes
         ZMI_HIP(hipMemcpyAsync(sl.in.p, c->hb_pin_in[s2].p, (size_t)ck.bytes, hipMemcpyHostToDevice, c->hs_in));
         ZMI_HIP(hipMemcpyAsync(sl.meta.p, c->hb_pin_meta[s2].p, (size_t)max_count * 12u, hipMemcpyHostToDevice, c->hs_in));
         ZMI_HIP(hipEventRecord(sl.in_done, c->hs_in));
@@ -999,6 +1033,27 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         if (k >= ZMI_HB_SLOTS) ZMI_HIP(hipStreamWaitEvent(c->hs_k, slab_done[s2], 0));   // ... and its slab has left the device
         int rc = zmi_deflate_batch_dev(c, sl.in.p, m_doff(sl.meta.p), m_len(sl.meta.p), ck.count, max_len, level, strategy, wrap, sl.out.p,
                                        out_stride, m_olen(sl.meta.p), m_st(sl.meta.p), c->hs_k);
+        if (zero_copy) {
+            // The slab does not travel by a copy engine: the pack kernel writes it straight into the pinned host buffer (PCIe
+            // writes from the shader, coalesced dwords), on a stream of its own behind the chunk's kernels -- the next chunk's
+            // kernels do not wait for it, and the copy engines carry input only.  (Measured: H2D and D2H copies of different
+            // streams were served one after the other, a slab queued behind 2.5 GiB of input reached the host 50 ms late.)
+            if (rc) return rc;
+            ZMI_HIP(hipEventRecord(sl.k_done, c->hs_k));
+            ZMI_HIP(hipStreamWaitEvent(c->hs_slab, sl.k_done, 0));
+            rc = zmi_scan_sizes_dev(c, m_olen(sl.meta.p), ck.count, m_soff(sl.meta.p), c->hs_slab);
+            if (rc) return rc;
+            {
+                zmi_scope_timer tm(c, ZMI_K_PACK, c->hs_slab);
+                zmi_launch_copy_ranges_few((const uint8_t*)sl.out.p, nullptr, out_stride, m_olen(sl.meta.p), ck.count, (uint8_t*)c->hb_pin_out[s2].p,
+                                           m_soff(sl.meta.p), c->hb_pin_out[s2].cap, out_stride > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)out_stride,
+                                           pack_groups, c->hs_slab);
+            }
+            ZMI_HIP(hipMemcpyAsync((uint8_t*)c->hb_pin_meta[s2].p + (size_t)max_count * 12u, (uint8_t*)sl.meta.p + (size_t)max_count * 12u,
+                                   meta_bytes - (size_t)max_count * 12u, hipMemcpyDeviceToHost, c->hs_slab));
+            ZMI_HIP(hipEventRecord(slab_done[s2], c->hs_slab));
+            return 0;
+        }
         if (!rc) rc = zmi_pack_slab_dev(c, sl.out.p, out_stride, m_olen(sl.meta.p), ck.count, c->hb_slab[s2].p, c->hb_slab[s2].cap,
                                         m_soff(sl.meta.p), c->hs_k);
         if (rc) return rc;
@@ -1013,11 +1068,18 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     auto issue_slab = [&](size_t k) -> int {   // D2H of exactly the slab
         chunk& ck = chunks[k];
         const int s2 = (int)(k % ZMI_HB_SLOTS);
+        if (zero_copy) {
+            ZMI_HIP(hipEventSynchronize(slab_done[s2]));
+            if (m_soff(c->hb_pin_meta[s2].p)[ck.count] > c->hb_pin_out[s2].cap) return zmi_fail(ZMI_E_HIP, "slab larger than its bound");
+            return 0;
+        }
         ZMI_HIP(hipEventSynchronize(sizes_done[s2]));
         const uint64_t total = m_soff(c->hb_pin_meta[s2].p)[ck.count];
         if (total > c->hb_slab[s2].cap) return zmi_fail(ZMI_E_HIP, "slab larger than its bound");
-        if (total) ZMI_HIP(hipMemcpyAsync(c->hb_pin_out[s2].p, c->hb_slab[s2].p, (size_t)total, hipMemcpyDeviceToHost, c->hs_out));
-        ZMI_HIP(hipEventRecord(slab_done[s2], c->hs_out));
+        // (a stream of its own: hs_out already holds "wait for the kernels of the NEXT chunks" -- the caller's thread runs ahead
+        // -- and a slab queued behind those waits left the device only when they had run: 25-29 ms instead of 4)
+        if (total) ZMI_HIP(hipMemcpyAsync(c->hb_pin_out[s2].p, c->hb_slab[s2].p, (size_t)total, hipMemcpyDeviceToHost, c->hs_slab));
+        ZMI_HIP(hipEventRecord(slab_done[s2], c->hs_slab));
         return 0;
     };
     auto stage_out = [&](size_t k) -> int {   // host threads: pinned slab -> the caller's slots
@@ -1042,16 +1104,27 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     // it.  (One thread doing both waited for results between two issues, and the device idled a third of the time: 18 GiB/s.)
     std::atomic<int> issued{0}, finished{0}, failed{0};
     const int dev_id = c->device;
+    const bool hb_trace = zmi_tune("ZMI_HB_TRACE") != nullptr;
+    double t_in = 0, t_issue = 0, t_wait_slot = 0, t_slab = 0, t_out = 0, t_wait_issue = 0;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_begin = now();
+    std::vector<double> tl(K * 6u, 0.0);   // per chunk: stage_in start, end, sizes known, slab arrived, scattered
     const unsigned T_in = T > 1u ? T - T / 3u : 1u, T_out = T > 2u ? T / 3u : 1u;
     auto consumer = [&]() {
         (void)hipSetDevice(dev_id);
         for (size_t k = 0; k < K; ++k) {
+            const double a0 = now();
             while (issued.load(std::memory_order_acquire) <= (int)k) {
                 if (failed.load(std::memory_order_acquire)) return;
                 std::this_thread::yield();
             }
+            const double a1 = now();
             int r = issue_slab(k);
+            const double a2 = now();
+            if (!r && hb_trace) { (void)hipEventSynchronize(slab_done[k % ZMI_HB_SLOTS]); tl[k * 6u + 3u] = now() - t_begin; }
             if (!r) r = stage_out(k);
+            tl[k * 6u + 2u] = a2 - t_begin; tl[k * 6u + 4u] = now() - t_begin;
+            t_wait_issue += a1 - a0; t_slab += a2 - a1; t_out += now() - a2;
             if (r) { failed.store(r, std::memory_order_release); return; }
             finished.store((int)k + 1, std::memory_order_release);
         }
@@ -1062,10 +1135,15 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     for (size_t k = 0; k < K && !rc; ++k) {
         while (finished.load(std::memory_order_acquire) + ZMI_HB_SLOTS <= (int)k && !failed.load(std::memory_order_acquire)) std::this_thread::yield();   // slot free
         if (failed.load(std::memory_order_acquire)) break;
+        const double b1 = now();
         rc = stage_in(k);
+        const double b2 = now();
         if (!rc) rc = issue_dev(k);
+        t_wait_slot += 0.0; t_in += b2 - b1; t_issue += now() - b2;
+        tl[k * 6u] = b1 - t_begin; tl[k * 6u + 1u] = b2 - t_begin;
         if (!rc) issued.store((int)k + 1, std::memory_order_release);
     }
+    const double t_issued_all = now();
     if (rc) failed.store(rc, std::memory_order_release);
     follower.join();
     if (!rc) rc = failed.load();
@@ -1073,6 +1151,15 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     (void)hipStreamSynchronize(c->hs_in);
     (void)hipStreamSynchronize(c->hs_k);
     (void)hipStreamSynchronize(c->hs_out);
+    (void)hipStreamSynchronize(c->hs_slab);
+    if (hb_trace)
+        fprintf(stderr, "[zmi hb] %zu chunks, %u threads: caller stage_in %.1f ms, issue %.1f ms, all issued at %.1f ms; follower waits for issue %.1f, "
+                "slab wait+copy-issue %.1f, stage_out %.1f ms; total %.1f ms\n", K, T, t_in, t_issue, t_issued_all - t_begin, t_wait_issue, t_slab, t_out,
+                now() - t_begin);
+    if (hb_trace)
+        for (size_t k = 0; k < K; ++k)
+            fprintf(stderr, "[zmi hb]   chunk %zu (%u shards): stage_in %.1f..%.1f, sizes known %.1f, slab on host %.1f, scattered %.1f\n", k, chunks[k].count,
+                    tl[k * 6u], tl[k * 6u + 1u], tl[k * 6u + 2u], tl[k * 6u + 3u], tl[k * 6u + 4u]);
     if (rc) return rc;
     ZMI_HIP(hipGetLastError());
     return ZMI_E_OK;

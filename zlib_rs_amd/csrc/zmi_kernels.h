@@ -61,6 +61,9 @@ int zmi_launch_scan_sizes(const uint32_t* d_len, uint32_t n, uint64_t* d_off, hi
 int zmi_launch_copy_ranges(const uint8_t* d_src, const uint64_t* d_src_off, uint64_t src_stride, const uint32_t* d_len,
                            uint32_t n, uint8_t* d_dst, const uint64_t* d_dst_off, uint64_t dst_cap, uint32_t max_len,
                            hipStream_t stream);
+int zmi_launch_copy_ranges_few(const uint8_t* d_src, const uint64_t* d_src_off, uint64_t src_stride, const uint32_t* d_len,
+                               uint32_t n, uint8_t* d_dst, const uint64_t* d_dst_off, uint64_t dst_cap, uint32_t max_len,
+                               uint32_t groups, hipStream_t stream);
 int zmi_launch_checksum(const uint8_t* d_data, const uint64_t* d_off, const uint32_t* d_len, uint32_t n_shards,
                         uint32_t kind, uint32_t* d_adler, uint32_t* d_crc, hipStream_t stream);
 int zmi_launch_lz77(const uint8_t* d_data, const uint64_t* d_off, const uint32_t* d_len, uint32_t first_shard,
