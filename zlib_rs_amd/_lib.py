@@ -34,6 +34,7 @@ def lib():
     L.zmi_copy_ranges_dev.argtypes = [vp, vp, vp, u64, vp, u32, u32, vp, vp, u64, vp]
     L.zmi_pack_slab_dev.argtypes = [vp, vp, u64, vp, u32, vp, u64, vp, vp]
     L.zmi_deflate_batch.argtypes = [vp, vp, vp, vp, u32, i32, i32, i32, vp, u64, vp, vp]
+    L.zmi_inflate_batch.argtypes = [vp, vp, vp, vp, u32, i32, vp, vp, vp, vp, vp]
     _lib = L
     return L
 

@@ -1218,28 +1218,32 @@ static int zmi_inflate_batch_simple(zmi_ctx* c, const uint8_t* in, const uint64_
     return ZMI_E_OK;
 }
 
-// Host buffers, pipelined like zmi_deflate_batch: chunks of consecutive streams (by output capacity) cycle through the
-// two device slots.  A chunk's outputs leave in one copy when the caller's regions are laid out like the slot (capacities
-// back to back, 16-byte granules -- the usual array of equal shards), otherwise one copy per stream of its capacity.
+// Host buffers, pipelined like zmi_deflate_batch: chunks of consecutive streams (by output capacity) cycle through three slots.
+// The caller's thread copies a chunk's compressed streams into pinned staging and issues its H2D copy and kernels; the
+// decoded bytes leave the device through a copy kernel of a few workgroups that writes straight into pinned host memory
+// (PCIe writes from the shader run beside the copy engine's H2D traffic; two copy-engine directions were served one after
+// the other, see zmi_deflate_batch), and a second thread scatters every finished chunk into the caller's regions --
+// min(out_len, out_cap) bytes of every stream.
 extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
                                  int wrap, uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len,
                                  int32_t* status) {
     if (!c || (!in && n) || !in_off || !in_len || !out_off || !out_cap || !out_len || !status)
         return zmi_fail(ZMI_E_ARG, "null argument");
     if (n == 0) return ZMI_E_OK;
-    // one wave per stream: a launch wants >= 8192 streams to keep the chip busy (2048 streams run at
-    // 17 GiB/s, 16384 at 41), so only very large host batches are cut.  ZMI_HOST_CHUNK (bytes) overrides both bounds (tests).
-    uint64_t budget = 1ull << 30;
-    uint32_t min_count = 8192u;
+    // one wave per stream: a launch wants a few thousand streams to keep the chip busy (2048 streams of 1 MiB decode at ~80
+    // GiB/s, above what PCIe carries), and a chunk's output has to fit the pinned staging: 2 GiB of capacity per chunk.
+    // ZMI_HOST_CHUNK (bytes) overrides both bounds (tests).
+    uint64_t budget = 2ull << 30;
+    uint32_t min_count = 2048u;
     if (const char* e = zmi_tune("ZMI_HOST_CHUNK")) { if (atoll(e) > 0) { budget = (uint64_t)atoll(e); min_count = 1u; } }
-    struct chunk { uint32_t first, count; uint64_t in_bytes, out_bytes; bool packed; std::vector<uint64_t> ioff, ooff; };
+    struct chunk { uint32_t first, count; uint64_t in_bytes, out_bytes; std::vector<uint64_t> ioff, ooff; };
     std::vector<chunk> chunks;
     for (uint32_t i = 0; i < n;) {
-        chunk ck{i, 0, 0, 0, true, {}, {}};
+        chunk ck{i, 0, 0, 0, {}, {}};
         while (i < n) {
             const uint64_t ai = ((uint64_t)in_len[i] + 15u) & ~15ull, ao = ((uint64_t)out_cap[i] + 15u) & ~15ull;
+            if (ck.count != 0u && (ck.out_bytes + ao > 0xFFFFF000ull || ck.in_bytes + ai > 0xFFFFF000ull)) break;   // (one copy range, u32 length)
             if (ck.count >= min_count && ck.out_bytes + ao > budget) break;
-            if (out_off[i] - out_off[ck.first] != ck.out_bytes) ck.packed = false;   // the caller's layout differs from the slot's
             ck.ioff.push_back(ck.in_bytes);
             ck.ooff.push_back(ck.out_bytes);
             ck.in_bytes += ai;
@@ -1250,7 +1254,7 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         chunks.push_back(std::move(ck));
     }
     const char* pl = zmi_tune("ZMI_HOST_PIPELINE");
-    if (chunks.size() < 3 || (pl && !atoi(pl)))
+    if (chunks.size() < 2 || (pl && !atoi(pl)))
         return zmi_inflate_batch_simple(c, in, in_off, in_len, n, wrap, out, out_off, out_cap, out_len, status);
     ZMI_ON_DEVICE(c);
     int rc = zmi_host_pipeline_init(c);
@@ -1262,82 +1266,131 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         if (ck.out_bytes > max_out) max_out = ck.out_bytes;
         if (ck.count > max_count) max_count = ck.count;
     }
-    for (auto& sl : c->hb) {
+    // meta (device and pinned twin): in_off u64 | out_off u64 | in_len | out_cap | out_len | status (u32 each) per stream, then the
+    // copy-out job: one range {offset 0 (u64), length (u32)}
+    const size_t meta_bytes = (size_t)max_count * 32u + 32u;
+    for (int k = 0; k < ZMI_HB_SLOTS; ++k) {
+        zmi_ctx::hb_slot& sl = c->hb[k];
         rc = zmi_reserve(sl.in, (size_t)max_in + 64u);
         if (!rc) rc = zmi_reserve(sl.out, (size_t)max_out + 64u);
-        if (!rc) rc = zmi_reserve(sl.meta, (size_t)max_count * 32u);   // in_off u64 | out_off u64 | in_len | out_cap | out_len | status
+        if (!rc) rc = zmi_reserve(sl.meta, meta_bytes);
+        if (!rc) rc = zmi_reserve_pinned(c->hb_pin_in[k], (size_t)max_in + 64u);
+        if (!rc) rc = zmi_reserve_pinned(c->hb_pin_out[k], (size_t)max_out + 64u);
+        if (!rc) rc = zmi_reserve_pinned(c->hb_pin_meta[k], meta_bytes);
         if (rc) return rc;
     }
     const uint64_t saved_limit = c->inflate_out_limit;
     c->inflate_out_limit = max_out + (1ull << 20);   // bitmap scratch for the largest chunk, once
     struct restore { zmi_ctx* c; uint64_t v; ~restore() { c->inflate_out_limit = v; } } restore_limit{c, saved_limit};
-    auto m_ioff = [&](zmi_ctx::hb_slot& sl) { return (uint64_t*)sl.meta.p; };
-    auto m_ooff = [&](zmi_ctx::hb_slot& sl) { return (uint64_t*)((uint8_t*)sl.meta.p + (size_t)max_count * 8u); };
-    auto m_ilen = [&](zmi_ctx::hb_slot& sl) { return (uint32_t*)((uint8_t*)sl.meta.p + (size_t)max_count * 16u); };
-    auto m_ocap = [&](zmi_ctx::hb_slot& sl) { return (uint32_t*)((uint8_t*)sl.meta.p + (size_t)max_count * 20u); };
-    auto m_olen = [&](zmi_ctx::hb_slot& sl) { return (uint32_t*)((uint8_t*)sl.meta.p + (size_t)max_count * 24u); };
-    auto m_st = [&](zmi_ctx::hb_slot& sl) { return (int32_t*)((uint8_t*)sl.meta.p + (size_t)max_count * 28u); };
-    auto issue_in = [&](size_t k) -> int {
+    auto m_ioff = [&](void* b) { return (uint64_t*)b; };
+    auto m_ooff = [&](void* b) { return (uint64_t*)((uint8_t*)b + (size_t)max_count * 8u); };
+    auto m_ilen = [&](void* b) { return (uint32_t*)((uint8_t*)b + (size_t)max_count * 16u); };
+    auto m_ocap = [&](void* b) { return (uint32_t*)((uint8_t*)b + (size_t)max_count * 20u); };
+    auto m_olen = [&](void* b) { return (uint32_t*)((uint8_t*)b + (size_t)max_count * 24u); };
+    auto m_st = [&](void* b) { return (int32_t*)((uint8_t*)b + (size_t)max_count * 28u); };
+    auto m_job_off = [&](void* b) { return (uint64_t*)((uint8_t*)b + (size_t)max_count * 32u); };
+    auto m_job_len = [&](void* b) { return (uint32_t*)((uint8_t*)b + (size_t)max_count * 32u + 8u); };
+    const unsigned T = zmi_host_threads();
+    const size_t K = chunks.size();
+    std::vector<hipEvent_t> out_done(ZMI_HB_SLOTS);
+    for (int k = 0; k < ZMI_HB_SLOTS; ++k) ZMI_HIP(hipEventCreateWithFlags(&out_done[k], hipEventDisableTiming));
+    struct ev_guard { std::vector<hipEvent_t>& a; ~ev_guard() { for (hipEvent_t e : a) (void)hipEventDestroy(e); } } evg{out_done};
+    uint32_t pack_groups = 16u;
+    if (const char* gv = zmi_tune("ZMI_HB_PACK_GROUPS")) { if (atoi(gv) > 0) pack_groups = (uint32_t)atoi(gv); }
+    auto stage_in = [&](size_t k) -> int {   // host threads: caller memory -> pinned staging
         chunk& ck = chunks[k];
-        zmi_ctx::hb_slot& sl = c->hb[k & 1u];
-        if (k >= 2) ZMI_HIP(hipStreamWaitEvent(c->hs_in, sl.k_done, 0));
-        for (uint32_t i = 0; i < ck.count;) {
-            const uint32_t g = ck.first + i;
-            uint32_t j = i;
-            uint64_t bytes = in_len[g];
-            while (j + 1 < ck.count && in_off[ck.first + j + 1] == in_off[ck.first + j] + in_len[ck.first + j] &&
-                   ck.ioff[j + 1] == ck.ioff[j] + in_len[ck.first + j] && bytes < (1ull << 30))
-                bytes += in_len[ck.first + ++j];
-            if (bytes) ZMI_HIP(hipMemcpyAsync((uint8_t*)sl.in.p + ck.ioff[i], in + in_off[g], bytes, hipMemcpyHostToDevice, c->hs_in));
-            i = j + 1;
-        }
-        ZMI_HIP(hipMemcpyAsync(m_ioff(sl), ck.ioff.data(), (size_t)ck.count * 8u, hipMemcpyHostToDevice, c->hs_in));
-        ZMI_HIP(hipMemcpyAsync(m_ooff(sl), ck.ooff.data(), (size_t)ck.count * 8u, hipMemcpyHostToDevice, c->hs_in));
-        ZMI_HIP(hipMemcpyAsync(m_ilen(sl), in_len + ck.first, (size_t)ck.count * 4u, hipMemcpyHostToDevice, c->hs_in));
-        ZMI_HIP(hipMemcpyAsync(m_ocap(sl), out_cap + ck.first, (size_t)ck.count * 4u, hipMemcpyHostToDevice, c->hs_in));
-        ZMI_HIP(hipEventRecord(sl.in_done, c->hs_in));
+        const int s2 = (int)(k % ZMI_HB_SLOTS);
+        if (k >= ZMI_HB_SLOTS) ZMI_HIP(hipEventSynchronize(c->hb[s2].in_done));
+        std::vector<zmi_copy_job> jobs;
+        jobs.reserve(ck.count);
+        uint8_t* pin = (uint8_t*)c->hb_pin_in[s2].p;
+        for (uint32_t i = 0; i < ck.count; ++i) jobs.push_back({pin + ck.ioff[i], in + in_off[ck.first + i], in_len[ck.first + i]});
+        zmi_parallel_copy(jobs, T);
+        void* pm = c->hb_pin_meta[s2].p;
+        memcpy(m_ioff(pm), ck.ioff.data(), (size_t)ck.count * 8u);
+        memcpy(m_ooff(pm), ck.ooff.data(), (size_t)ck.count * 8u);
+        memcpy(m_ilen(pm), in_len + ck.first, (size_t)ck.count * 4u);
+        memcpy(m_ocap(pm), out_cap + ck.first, (size_t)ck.count * 4u);
+        *m_job_off(pm) = 0ull;
+        *m_job_len(pm) = (uint32_t)ck.out_bytes;
         return 0;
     };
-    auto issue_k = [&](size_t k) -> int {
+    auto issue_dev = [&](size_t k) -> int {
         chunk& ck = chunks[k];
-        zmi_ctx::hb_slot& sl = c->hb[k & 1u];
+        const int s2 = (int)(k % ZMI_HB_SLOTS);
+        zmi_ctx::hb_slot& sl = c->hb[s2];
+        if (k >= ZMI_HB_SLOTS) {
+            ZMI_HIP(hipStreamWaitEvent(c->hs_in, sl.k_done, 0));      // the kernels of the chunk that had this slot have read its input
+            ZMI_HIP(hipStreamWaitEvent(c->hs_in, out_done[s2], 0));   // ... and its copy-out has read the job and the results
+        }
+        ZMI_HIP(hipMemcpyAsync(sl.in.p, c->hb_pin_in[s2].p, (size_t)ck.in_bytes, hipMemcpyHostToDevice, c->hs_in));
+        // (two pieces: the results in the middle of the pinned twin belong to the follower thread until it has read them)
+        ZMI_HIP(hipMemcpyAsync(sl.meta.p, c->hb_pin_meta[s2].p, (size_t)max_count * 24u, hipMemcpyHostToDevice, c->hs_in));
+        ZMI_HIP(hipMemcpyAsync(m_job_off(sl.meta.p), m_job_off(c->hb_pin_meta[s2].p), 16u, hipMemcpyHostToDevice, c->hs_in));
+        ZMI_HIP(hipEventRecord(sl.in_done, c->hs_in));
         ZMI_HIP(hipStreamWaitEvent(c->hs_k, sl.in_done, 0));
-        if (k >= 2) ZMI_HIP(hipStreamWaitEvent(c->hs_k, sl.out_done, 0));
-        int r = zmi_inflate_batch_dev(c, sl.in.p, m_ioff(sl), m_ilen(sl), ck.count, wrap, sl.out.p, m_ooff(sl), m_ocap(sl), m_olen(sl),
-                                      m_st(sl), c->hs_k);
+        if (k >= ZMI_HB_SLOTS) ZMI_HIP(hipStreamWaitEvent(c->hs_k, out_done[s2], 0));   // the slot's output has left the device
+        int r = zmi_inflate_batch_dev(c, sl.in.p, m_ioff(sl.meta.p), m_ilen(sl.meta.p), ck.count, wrap, sl.out.p, m_ooff(sl.meta.p),
+                                      m_ocap(sl.meta.p), m_olen(sl.meta.p), m_st(sl.meta.p), c->hs_k);
         if (r) return r;
         ZMI_HIP(hipEventRecord(sl.k_done, c->hs_k));
-        return 0;
-    };
-    auto issue_out = [&](size_t k) -> int {
-        chunk& ck = chunks[k];
-        zmi_ctx::hb_slot& sl = c->hb[k & 1u];
-        ZMI_HIP(hipStreamWaitEvent(c->hs_out, sl.k_done, 0));
-        if (ck.packed) {
-            const uint64_t last = ck.ooff[ck.count - 1u] + out_cap[ck.first + ck.count - 1u];   // not past the caller's last region
-            ZMI_HIP(hipMemcpyAsync(out + out_off[ck.first], sl.out.p, (size_t)last, hipMemcpyDeviceToHost, c->hs_out));
-        } else {
-            for (uint32_t i = 0; i < ck.count; ++i)
-                if (out_cap[ck.first + i])
-                    ZMI_HIP(hipMemcpyAsync(out + out_off[ck.first + i], (uint8_t*)sl.out.p + ck.ooff[i], out_cap[ck.first + i],
-                                           hipMemcpyDeviceToHost, c->hs_out));
+        ZMI_HIP(hipStreamWaitEvent(c->hs_slab, sl.k_done, 0));
+        {
+            zmi_scope_timer tm(c, ZMI_K_PACK, c->hs_slab);
+            zmi_launch_copy_ranges_few((const uint8_t*)sl.out.p, m_job_off(sl.meta.p), 0, m_job_len(sl.meta.p), 1u, (uint8_t*)c->hb_pin_out[s2].p,
+                                       m_job_off(sl.meta.p), c->hb_pin_out[s2].cap, (uint32_t)ck.out_bytes, pack_groups, c->hs_slab);
         }
-        ZMI_HIP(hipMemcpyAsync(out_len + ck.first, m_olen(sl), (size_t)ck.count * 4u, hipMemcpyDeviceToHost, c->hs_out));
-        ZMI_HIP(hipMemcpyAsync(status + ck.first, m_st(sl), (size_t)ck.count * 4u, hipMemcpyDeviceToHost, c->hs_out));
-        ZMI_HIP(hipEventRecord(sl.out_done, c->hs_out));
+        ZMI_HIP(hipMemcpyAsync(m_olen(c->hb_pin_meta[s2].p), m_olen(sl.meta.p), (size_t)max_count * 8u, hipMemcpyDeviceToHost, c->hs_slab));
+        ZMI_HIP(hipEventRecord(out_done[s2], c->hs_slab));
         return 0;
     };
-    const size_t K = chunks.size();
+    auto stage_out = [&](size_t k) -> int {   // host threads: pinned output -> the caller's regions
+        chunk& ck = chunks[k];
+        const int s2 = (int)(k % ZMI_HB_SLOTS);
+        ZMI_HIP(hipEventSynchronize(out_done[s2]));
+        const void* pm = c->hb_pin_meta[s2].p;
+        const uint32_t* ol = m_olen((void*)pm);
+        memcpy(out_len + ck.first, ol, (size_t)ck.count * 4u);
+        memcpy(status + ck.first, m_st((void*)pm), (size_t)ck.count * 4u);
+        std::vector<zmi_copy_job> jobs;
+        jobs.reserve(ck.count);
+        const uint8_t* pin = (const uint8_t*)c->hb_pin_out[s2].p;
+        for (uint32_t i = 0; i < ck.count; ++i) {
+            const uint32_t cap = out_cap[ck.first + i], take = ol[i] < cap ? ol[i] : cap;
+            if (take) jobs.push_back({out + out_off[ck.first + i], pin + ck.ooff[i], take});
+        }
+        zmi_parallel_copy(jobs, T);
+        return 0;
+    };
+    std::atomic<int> issued{0}, finished{0}, failed{0};
+    const int dev_id = c->device;
+    auto consumer = [&]() {
+        (void)hipSetDevice(dev_id);
+        for (size_t k = 0; k < K; ++k) {
+            while (issued.load(std::memory_order_acquire) <= (int)k) {
+                if (failed.load(std::memory_order_acquire)) return;
+                std::this_thread::yield();
+            }
+            const int r = stage_out(k);
+            if (r) { failed.store(r, std::memory_order_release); return; }
+            finished.store((int)k + 1, std::memory_order_release);
+        }
+    };
+    std::thread follower(consumer);
     rc = 0;
     for (size_t k = 0; k < K && !rc; ++k) {
-        rc = issue_in(k);
-        if (!rc) rc = issue_k(k);
-        if (!rc && k >= 1) rc = issue_out(k - 1);
+        while (finished.load(std::memory_order_acquire) + ZMI_HB_SLOTS <= (int)k && !failed.load(std::memory_order_acquire)) std::this_thread::yield();   // slot free
+        if (failed.load(std::memory_order_acquire)) break;
+        rc = stage_in(k);
+        if (!rc) rc = issue_dev(k);
+        if (!rc) issued.store((int)k + 1, std::memory_order_release);
     }
-    if (!rc) rc = issue_out(K - 1);
+    if (rc) failed.store(rc, std::memory_order_release);
+    follower.join();
+    if (!rc) rc = failed.load();
     (void)hipStreamSynchronize(c->hs_in);
     (void)hipStreamSynchronize(c->hs_k);
-    (void)hipStreamSynchronize(c->hs_out);
+    (void)hipStreamSynchronize(c->hs_slab);
     if (rc) return rc;
     ZMI_HIP(hipGetLastError());
     return ZMI_E_OK;
