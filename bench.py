@@ -125,7 +125,7 @@ def main():
                     help="distinct gzip members the CPU oracle produces for the inflate leg (tiled on the device to --shards streams)")
     ap.add_argument("--launch-streams", type=int, default=16384, help="streams per inflate launch (round trip and inflate leg)")
     ap.add_argument("--sweep-shards", type=int, default=16384, help="shards of the level 1 / level 9 sweep (configs[3])")
-    ap.add_argument("--pcie-shards", type=int, default=2048, help="shards of the host-buffer (PCIe inclusive) measurement")
+    ap.add_argument("--pcie-shards", type=int, default=8192, help="shards of the host-buffer (PCIe inclusive) measurement")
     ap.add_argument("--scratch-gib", type=float, default=float(os.environ.get("ZMI_BENCH_SCRATCH_GIB", 70)),
                     help="device scratch of the engine (one launch group of the deflate pipeline): 70 GiB = 16384 shards per launch")
     ap.add_argument("--no-cpu", action="store_true")
@@ -486,10 +486,13 @@ def stream_abi_leg(level):
     t0 = time.perf_counter()
     comp = H.deflate_stream(lib, data, level=level, wbits=31, chunk_in=1 << 22, chunk_out=1 << 22)
     td = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    rc, back, unused = H.inflate_stream(lib, comp, 31, chunk_in=1 << 22, chunk_out=1 << 22)
-    ti = time.perf_counter() - t0
-    assert rc == 1 and back == data and unused == 0, "stream ABI round trip failed"
+    ti = None
+    for _ in range(2):   # (the first pass pays for the staging buffers of this size)
+        t0 = time.perf_counter()
+        rc, back, unused = H.inflate_stream(lib, comp, 31, chunk_in=1 << 22, chunk_out=1 << 22)
+        dt = time.perf_counter() - t0
+        ti = dt if ti is None else min(ti, dt)
+        assert rc == 1 and back == data and unused == 0, "stream ABI round trip failed"
     rc, ocomp = o.deflate(data[:4 << 20], level, 2)
     t0 = time.perf_counter()
     rc, ocomp = o.deflate(data, level, 2)
@@ -497,10 +500,13 @@ def stream_abi_leg(level):
     assert o.inflate(comp, len(data), 2)[1] == data          # the oracle reads the GPU's stream
     # the same bytes as a stream of the CPU oracle (the reference's algorithm: blocks of 16 383 symbols, no flush points --
     # what an unmodified caller's inflate() meets most often), through inflate() and through one uncompress2()-style call
-    t0 = time.perf_counter()
-    rc2, back2, unused2 = H.inflate_stream(lib, ocomp, 31, chunk_in=1 << 22, chunk_out=1 << 22)
-    ti2 = time.perf_counter() - t0
-    assert rc2 == 1 and back2 == data and unused2 == 0, "stream ABI inflate of the oracle's stream failed"
+    ti2 = None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        rc2, back2, unused2 = H.inflate_stream(lib, ocomp, 31, chunk_in=1 << 22, chunk_out=1 << 22)
+        dt = time.perf_counter() - t0
+        ti2 = dt if ti2 is None else min(ti2, dt)
+        assert rc2 == 1 and back2 == data and unused2 == 0, "stream ABI inflate of the oracle's stream failed"
     import zlib
     zc = zlib.compress(data, level)
     dst = C.create_string_buffer(len(data))
@@ -519,8 +525,9 @@ def stream_abi_leg(level):
             "inflate_of_cpu_made_stream_GiB_s": len(data) / GIB / ti2, "uncompress_of_zlib_stream_GiB_s": len(data) / GIB / tu,
             "system_zlib_inflate_single_thread_GiB_s": len(data) / GIB / tz,
             "oracle_single_thread_GiB_s": len(data) / GIB / to, "oracle_ratio": len(data) / float(len(ocomp)),
-            "note": "one stream: deflate = 16 segments of 1 MiB on the device; inflate = one workgroup of 8 waves (a pass covers at most "
-                    "one deflate block: this engine's own streams cut a block every few KiB of drifting data, the CPU's every 16 383 symbols)"}
+            "note": "one stream: deflate = 16 segments of 1 MiB on the device; inflate of a stream with flush points (this library's own: "
+                    "a marker every 64 KiB of input) = the pieces between the markers decoded side by side and stitched (zmi_inflate_split); "
+                    "a stream without them (the CPU's) = one workgroup of 8 waves, a pass covers at most one deflate block"}
 
 
 def real_data_leg(e, torch, dev, B):
