@@ -16,8 +16,13 @@ from zlib_rs_amd import _build       # noqa: E402
 lib = H.bind(C.CDLL(_build.ABI_LIB))
 o = oracle_lib.load(rebuild=False)
 data = b"".join(o.gen_shard(i, 1 << 20) for i in range(15))
-comp = H.deflate_stream(lib, data, level=6, wbits=31, chunk_in=1 << 22, chunk_out=1 << 22)
-for rep in range(2):
+comp_own = H.deflate_stream(lib, data, level=6, wbits=31, chunk_in=1 << 22, chunk_out=1 << 22)
+import zlib as _z
+_co = _z.compressobj(6, _z.DEFLATED, 31)
+comp_cpu = _co.compress(data) + _co.flush()
+for rep in range(4):
+    comp = comp_own if rep < 2 else comp_cpu
+    print("own stream (flush points)" if rep < 2 else "CPU-made stream (no flush points)")
     strm = H.ZStream()
     assert lib.inflateInit2_(C.byref(strm), 31, lib.zlibVersion(), C.sizeof(H.ZStream)) == 0
     src = C.create_string_buffer(comp, len(comp))

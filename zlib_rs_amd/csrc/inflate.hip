@@ -630,9 +630,10 @@ static __device__ __forceinline__ uint32_t inf_fast_pass(InfShared* S, const uin
 // of wave w has to start where lane 63 of wave w - 1 ended, and a wave commits only if every wave below it committed all
 // its lanes.  Wave 0 is the stream's master (headers, table construction, token rounds, everything the single-wave kernel
 // does); the other waves sleep at a workgroup barrier until it posts a pass.  A pass covers at most the rest of the block
-// (the tables change behind an end-of-block), so the gain is bounded by the block size: 8 waves x 3.75 KiB = 30 KiB of
+// (the tables change behind an end-of-block), so the gain is bounded by the block size: 16 waves x up to 3.75 KiB of
 // compressed data, more than the ~20 KiB of a 16 383-symbol zlib block.
-#define INF_MW 8u
+#define INF_MW 16u
+#define INF_MW_SUB 192u   // a pass is spread over as many waves as give every lane about this many bits (below that the 192-bit warm-up dominates)
 #define INF_MW_ROUNDS 4u   // cross-wave fix-up rounds (a wave whose lane 0 started at a wrong guess restarts it and re-stitches)
 struct InfMulti {
     __attribute__((aligned(16))) uint8_t fb[INF_MW - 1u][INF_FAST_BYTES];
@@ -689,21 +690,24 @@ static __device__ __noinline__ void inf_pass_mw(const uint8_t* src, uint8_t* dst
         }
         R = inf_lane_decode<false>(S, fb, start, boundary, true, nullptr, nullptr, 0u, 0u);
     }
+    bool l0_redo = false;   // this wave's lane 0 has been moved to where the wave below ended and has to walk again
     for (uint32_t g = 0;; ++g) {
         if (act) {
             // inside the wave, as inf_fast_pass: a lane restarts where the lane below ended until a prefix is consistent
+            // (lane 0's restart, decided between the waves below, rides in the same walk as the lanes it may upset)
             for (uint32_t it = 0;; ++it) {
                 const uint32_t below_exit = (uint32_t)__shfl_up((int)R.exit, 1u);
-                const bool wrong = lane != 0u && below_exit != start;
-                stopm = __ballot(R.flags != 0u);
+                const bool wrong = lane != 0u ? below_exit != start : l0_redo;
+                stopm = l0_redo ? 0ull : __ballot(R.flags != 0u);   // (lane 0's old walk says nothing any more)
                 const uint64_t wrongm = __ballot(wrong);
                 const uint32_t first_wrong = wrongm ? (uint32_t)__ffsll((unsigned long long)wrongm) - 1u : 64u;
                 const uint32_t first_stop = stopm ? (uint32_t)__ffsll((unsigned long long)stopm) : 64u;   // index + 1
                 good = first_wrong < first_stop ? first_wrong : first_stop;
                 if (first_stop <= first_wrong || first_wrong >= 64u || it == 5u) break;
-                if (wrong) start = below_exit;
+                if (wrong && lane != 0u) start = below_exit;
                 const InfLane N = inf_lane_decode<false>(S, fb, start, boundary, wrong, nullptr, nullptr, 0u, 0u);
                 if (wrong) R = N;
+                l0_redo = false;
             }
             const uint32_t s0 = zmi_readlane(start, 0u), e63 = zmi_readlane(R.exit, 63u);
             if (lane == 0u) {
@@ -720,10 +724,8 @@ static __device__ __noinline__ void inf_pass_mw(const uint8_t* src, uint8_t* dst
             const uint32_t want = zmi_uniform(M->exit63[wave - 1u]), have = zmi_uniform(M->start0[wave]);
             // (a wave below that stopped early -- end of block, invalid code -- ended in front of this wave's bits: nothing to link to)
             if (want != have && want >= org && want < org + 64u) {
-                const bool l0 = lane == 0u;
-                if (l0) start = want - org + p_rel;
-                const InfLane N = inf_lane_decode<false>(S, fb, start, boundary, l0, nullptr, nullptr, 0u, 0u);
-                if (l0) R = N;
+                if (lane == 0u) start = want - org + p_rel;
+                l0_redo = true;
             }
         }
         __syncthreads();   // (this round's values have been read before the next round overwrites them)
@@ -1108,7 +1110,8 @@ __global__ void __launch_bounds__(64 * NW) zmi_inflate_kernel(const uint8_t* __r
                                 if (rest == 0u) { nact = 2u; sub = 288u; }
                                 else {
                                     const uint32_t want = rest + (rest >> 3);
-                                    nact = (want + 64u * INF_SUB_BITS - 1u) / (64u * INF_SUB_BITS);
+                                    // (a pass takes as long as one lane's sub-sequence: more waves with shorter ones, not fewer with full ones)
+                                    nact = (want + 64u * INF_MW_SUB - 1u) / (64u * INF_MW_SUB);
                                     nact = nact < 1u ? 1u : (nact > NW ? NW : nact);
                                     sub = (want + 64u * nact - 1u) / (64u * nact);
                                     sub = (((sub + 31u) >> 5) | 1u) << 5;
