@@ -125,6 +125,21 @@ def test_random_streaming_roundtrips():
         H.random_streaming_roundtrips(lib, o, 6, seed)
 
 
+def test_streams_with_flush_points_are_decoded_as_segments(monkeypatch, capfd):
+    """inflate() of streams with sync / full flush points: the segment-parallel decode gives the serial decode's results"""
+    monkeypatch.setenv("ZMI_TUNING", "1")
+    monkeypatch.setenv("ZMI_ABI_SPLIT_MIN", "20000")   # (the product splits from 256 KiB of buffered input)
+    monkeypatch.setenv("ZMI_ABI_SPLIT_GAP", "1500")
+    monkeypatch.setenv("ZMI_ABI_TRACE", "1")
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    assert H.flush_point_stream_checks(lib, oracle_lib.load(), seeds=range(700, 703)) == 9
+    err = capfd.readouterr().err
+    import re
+    used = [int(m) for m in re.findall(r"(\d+) pieces decoded side by side", err)]
+    assert used and max(used) >= 4, used   # the parallel path ran
+
+
 def test_random_deflate_streams(monkeypatch):
     """randomised deflate(): level, strategy, wrapper, input pieces, output room, flush points, primed bits; the
     system's zlib must read every stream back"""

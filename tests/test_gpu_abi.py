@@ -109,6 +109,14 @@ def test_reference_inflate_vectors_through_the_stream_abi_on_gpu():
     assert H.golden_inflate_checks(lib, vectors, steps=(0, 1, 2, 3, 5, 17, 64)) > 100
 
 
+def test_streams_with_flush_points_are_decoded_as_segments_on_gpu():
+    """inflate() of streams with sync / full flush points (marker look-alikes inside stored blocks included): the
+    segment-parallel decode (zmi_inflate_split) gives the serial decode's bytes and codes; truncated and corrupted variants"""
+    from zlib_rs_amd import _build
+    lib = H.bind(C.CDLL(_build.ABI_LIB))
+    assert H.flush_point_stream_checks(lib, oracle_lib.load(rebuild=False), seeds=range(800, 812), big=True) == 36
+
+
 def test_random_streaming_roundtrips_on_gpu():
     """randomised pieces / rooms / flush arguments through inflate() against streams of the system's zlib"""
     from zlib_rs_amd import _build

@@ -1402,3 +1402,65 @@ def block_stop_checks(lib, syslib, data):
     assert rc == Z_STREAM_END and bytes(got) == data and stops >= 3, (rc, len(got), stops)
     assert lib.inflateEnd(C.byref(strm)) == Z_OK
     return n_calls
+
+
+def flush_point_stream_checks(lib, o, seeds, big=False):
+    """streams WITH flush points through inflate(): the stream ABI cuts what is buffered at the 00 00 FF FF markers and decodes
+    the pieces side by side (zmi_inflate_split) -- the caller must see the serial decode's bytes and codes.  Random piece sizes
+    and flush kinds (sync / full / none, so that some 'markers' sit inside stored blocks of data that holds the four bytes),
+    raw / zlib / gzip wrappers, random feeding chunk and room sizes, a truncated and a corrupted variant of every stream."""
+    import random
+    import zlib
+    n_cases = 0
+    for seed in seeds:
+        rng = random.Random(seed)
+        total = rng.randrange(300000, 1200000 if big else 500000)
+        parts = []
+        while sum(len(x) for x in parts) < total:
+            k = rng.randrange(8)
+            ln = rng.randrange(2000, 300000 if big else 60000)
+            if k == 7:
+                parts.append((b"\x00\x00\xff\xff" + bytes(rng.randrange(256) for _ in range(40))) * (ln // 44))   # marker look-alikes
+            else:
+                parts.append(o.gen_shard(k, ln))
+        data = b"".join(parts)
+        wbits = rng.choice((-15, 15, 31))
+        co = zlib.compressobj(rng.choice((0, 1, 6, 9)) if rng.random() < 0.3 else 6, zlib.DEFLATED, wbits)
+        comp = b""
+        pos = 0
+        while pos < len(data):
+            step = rng.randrange(4000, 200000 if big else 40000)
+            comp += co.compress(data[pos:pos + step])
+            pos += step
+            r = rng.random()
+            if r < 0.6:
+                comp += co.flush(zlib.Z_SYNC_FLUSH)
+            elif r < 0.8:
+                comp += co.flush(zlib.Z_FULL_FLUSH)
+        comp += co.flush()
+        chunk_in = rng.choice((1 << 30, 1 << 22, 300000, 70001))
+        chunk_out = rng.choice((1 << 22, 65536, 8192))
+        rc, back, unused = inflate_stream(lib, comp, wbits, chunk_in=chunk_in, chunk_out=chunk_out)
+        assert rc == Z_STREAM_END and back == data and unused == 0, (seed, rc, len(back), len(data), unused)
+        # truncated: everything in front of the cut comes out, no error
+        cut = rng.randrange(len(comp) // 2, len(comp) - 8)
+        rc, back, unused = inflate_stream(lib, comp[:cut], wbits, chunk_in=chunk_in, chunk_out=chunk_out)
+        want = zlib.decompressobj(wbits).decompress(comp[:cut])
+        assert rc in (Z_OK, Z_BUF_ERROR) and back == want, (seed, "truncated", rc, len(back), len(want))
+        # corrupted: the system zlib's verdict and its valid prefix
+        bad = bytearray(comp)
+        at = rng.randrange(len(comp) // 3, len(comp) - 8)
+        bad[at] ^= 1 << rng.randrange(8)
+        d = zlib.decompressobj(wbits)
+        try:
+            want = d.decompress(bytes(bad))
+            failed = False
+        except zlib.error:
+            failed = True
+        rc, back, unused = inflate_stream(lib, bytes(bad), wbits, chunk_in=chunk_in, chunk_out=chunk_out)
+        if failed:
+            assert rc == Z_DATA_ERROR, (seed, "corrupt", rc)
+        else:
+            assert back == want and rc in (Z_OK, Z_STREAM_END, Z_BUF_ERROR), (seed, "corrupt-but-valid", rc)
+        n_cases += 3
+    return n_cases

@@ -737,17 +737,20 @@ bool split_enabled() {
 }
 void find_flush_points(const uint8_t* in, size_t n, std::vector<uint32_t>& seg) {
     seg.clear();
-    if (n < ((size_t)256 << 10) || !split_enabled()) return;
+    // (ZMI_ABI_SPLIT_MIN / ZMI_ABI_SPLIT_GAP, bytes, under ZMI_TUNING: the tests split small streams)
+    static const size_t kMin = [] { const char* e = abi_tune("ZMI_ABI_SPLIT_MIN"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)256 << 10; }();
+    static const size_t kGap = [] { const char* e = abi_tune("ZMI_ABI_SPLIT_GAP"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)8192; }();
+    if (n < kMin || !split_enabled()) return;
     static const uint8_t kMark[4] = {0x00, 0x00, 0xFF, 0xFF};
     seg.push_back(0u);
-    size_t at = 8192;
+    size_t at = kGap;
     while (at + 4 < n && seg.size() < 8192u) {
         const void* m = memmem(in + at, n - at, kMark, 4);
         if (!m) break;
         const size_t cut = (size_t)((const uint8_t*)m - in) + 4u;
         if (cut >= n) break;
         seg.push_back((uint32_t)cut);
-        at = cut + 8192;
+        at = cut + kGap;
     }
     if (seg.size() < 4u) seg.clear();
 }
@@ -770,9 +773,13 @@ int inflate_attempt(InflateState* s, int stop_mode = 0) {   // stop_mode 1: deco
         std::vector<uint32_t> seg;
         if (stop_mode == 0 && take <= ((size_t)16 << 20)) find_flush_points(s->in.data(), take, seg);
         int rc;
-        if (!seg.empty())
+        if (!seg.empty()) {
+            uint32_t used_seg = 0;
             rc = zmi_inflate_split(c, s->in.data(), (uint32_t)take, in_bit, s->hist.data(), (uint32_t)s->hist.size(), s->tmp.data(), (uint32_t)cap,
-                                   seg.data(), (uint32_t)seg.size(), &olen, &st, &det, &used, res, nullptr);
+                                   seg.data(), (uint32_t)seg.size(), &olen, &st, &det, &used, res, &used_seg);
+            static const bool trace = abi_tune("ZMI_ABI_TRACE") != nullptr;
+            if (trace) fprintf(stderr, "[zmi abi] inflate: %zu bytes buffered, %zu cuts proposed, %u pieces decoded side by side\n", take, seg.size(), used_seg);
+        }
         else
             rc = zmi_inflate_resume(c, s->in.data(), (uint32_t)take, in_bit, s->hist.data(), (uint32_t)s->hist.size(), s->tmp.data(),
                                     (uint32_t)cap, &olen, &st, &det, &used, res);
