@@ -190,7 +190,7 @@ def main():
             best = None
             for rep in range(2):
                 timing(L, ctx)
-                L.zmi_deflate_batch_dev(ctx, d_in, d_off2, d_len2, len(idx), B, lvl, 0, 1, d_out, stride, d_olen, d_st, None)
+                L.zmi_deflate_batch_dev(ctx, d_in, d_off2, d_len2, len(idx), B, lvl, int(os.environ.get('PROBE_STRATEGY', '0')), 1, d_out, stride, d_olen, d_st, None)
                 hip.hipDeviceSynchronize()
                 tm = timing(L, ctx)
                 if best is None or tm[1] + tm[2] < best[1] + best[2]:
