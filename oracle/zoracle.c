@@ -279,11 +279,15 @@ int zo_inflate(const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, i
             b.pos -= b.bits >> 3;
             b.bits = 0;
             b.hold = 0;
-            if (b.pos + len > b.n) ZO_FAIL(ZO_BUF_ERROR, NULL);
-            if (op + len > out_cap) ZO_FAIL(ZO_BUF_ERROR, NULL);
-            memcpy(out + op, in + b.pos, len);
-            op += len;
-            b.pos += len;
+            { /* Mode::CopyBlock, inflate.rs:1374-1394: min(length, room, input) bytes are copied, whatever is missing */
+                uint32_t have = (uint32_t)(b.n - b.pos), room = (uint32_t)(out_cap - op);
+                uint32_t copy = len < have ? len : have;
+                if (copy > room) copy = room;
+                memcpy(out + op, in + b.pos, copy);
+                op += copy;
+                b.pos += copy;
+                if (copy < len) ZO_FAIL(ZO_BUF_ERROR, NULL);
+            }
             continue;
         }
         if (type == 3) ZO_FAIL(ZO_DATA_ERROR, "invalid block type");

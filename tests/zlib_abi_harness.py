@@ -1412,6 +1412,14 @@ def flush_point_stream_checks(lib, o, seeds, big=False):
     import random
     import zlib
     n_cases = 0
+    # a stored block whose end has not arrived: the bytes that are there come out (Mode::CopyBlock, inflate.rs:1374-1394)
+    raw = o.gen_shard(5, 150000)
+    co = zlib.compressobj(0, zlib.DEFLATED, -15)
+    st_stream = co.compress(raw) + co.flush()
+    for cut in (len(st_stream) - 1000, 70000, 65540, 10):
+        rc, back, unused = inflate_stream(lib, st_stream[:cut], -15, chunk_in=1 << 30, chunk_out=1 << 20)
+        want = zlib.decompressobj(-15).decompress(st_stream[:cut])
+        assert rc in (Z_OK, Z_BUF_ERROR) and back == want, ("stored, cut", cut, rc, len(back), len(want))
     for seed in seeds:
         rng = random.Random(seed)
         total = rng.randrange(300000, 1200000 if big else 500000)

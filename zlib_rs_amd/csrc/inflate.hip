@@ -934,11 +934,18 @@ __global__ void __launch_bounds__(64 * NW) zmi_inflate_kernel(const uint8_t* __r
                 st = ZMI_BLOCK_STOP;
                 break;
             }
-            if (B.ipos + l > B.n) { st = ZMI_BUF_ERROR; break; }
-            if (opos + l > cap) { st = ZMI_NEED_OUTPUT; break; }
-            for (uint32_t i = lane; i < l; i += 64u) dst[opos + i] = B.src[B.ipos + i];
-            opos += l;
-            B.ipos += l;
+            {
+                // a stored block that is not complete yet, or has no room: what there is is copied (Mode::CopyBlock,
+                // inflate.rs:1374-1394: min(length, room, input)) -- the bytes count as output of an unfinished block, the
+                // checkpoint stays in front of the block's header
+                const uint32_t have = B.n - B.ipos, room = cap > opos ? cap - opos : 0u;
+                uint32_t copy = l < have ? l : have;
+                copy = copy < room ? copy : room;
+                for (uint32_t i = lane; i < copy; i += 64u) dst[opos + i] = B.src[B.ipos + i];
+                opos += copy;
+                B.ipos += copy;
+                if (copy < l) { st = (room < l && room <= have) ? ZMI_NEED_OUTPUT : ZMI_BUF_ERROR; break; }
+            }
             ++blocks_done;
             continue;
         }
