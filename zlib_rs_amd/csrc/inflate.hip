@@ -847,6 +847,7 @@ __global__ void __launch_bounds__(64 * NW) zmi_inflate_kernel(const uint8_t* __r
     uint32_t kind_found = wrap;  // resolved wrapper: 0 raw, 1 zlib, 2 gzip
     uint32_t fixed_ready = 0;
     uint32_t last_blk_bits = 0;   // token bits of the block decoded last (0: none yet): sizes the fast passes of the next one
+    uint32_t fskip = 0, fskip_len = 0;   // token rounds left before the next fast pass is tried, and how many it was last time
 
     // ---- wrapper header ----
     if (wrap == 3u) kind_found = (B.n >= 2u && inf_byte(B, 0) == 0x1Fu && inf_byte(B, 1) == 0x8Bu) ? 2u : 1u;
@@ -1093,7 +1094,11 @@ __global__ void __launch_bounds__(64 * NW) zmi_inflate_kernel(const uint8_t* __r
                 {
                     // lane-serial fast pass while there are >= 4 KiB of input behind P (see inf_fast_pass); it commits only
                     // what is certain, everything unusual falls through to a token round below
-                    if (Pend - P >= 8ull * (INF_FAST_BYTES + 32u)) {
+                    // (a block whose code does not re-synchronise -- the fixed code over literal-dense data is nearly fixed-length --
+                    // commits a lane or two per pass at the price of 64: after such a pass the token rounds take over for a
+                    // while, twice as long every time it happens again)
+                    if (fskip != 0u) --fskip;
+                    else if (Pend - P >= 8ull * (INF_FAST_BYTES + 32u)) {
                         // Bits per lane.  A pass ends at the end of the block, and the lanes behind that point have worked
                         // for nothing: streams of small blocks (drifting data: 4 KiB a block) spent every second pass
                         // on a block's last few hundred bytes at the price of 3.75 KiB.  The block before is the estimate
@@ -1138,6 +1143,8 @@ __global__ void __launch_bounds__(64 * NW) zmi_inflate_kernel(const uint8_t* __r
                         } else
                         lanes = zmi_uniform(inf_fast_pass(S, B.src, P, dst, bm32, opos, cap, hist, sub, &fbits, &fout, &feob));
                         B.cbase = -(int32_t)(2u * INF_CHUNK);   // the pass staged its input over the token rounds' chunk
+                        if (lanes < 8u && sub >= 288u) { fskip_len = fskip_len == 0u ? 4u : (fskip_len < 64u ? fskip_len * 2u : 64u); fskip = fskip_len; }
+                        else if (lanes >= 32u) fskip_len = 0u;
                         if (lanes != 0u) {
                             P += zmi_uniform(fbits);
                             opos += zmi_uniform(fout);
