@@ -527,7 +527,7 @@ def stream_abi_leg(level):
             "oracle_single_thread_GiB_s": len(data) / GIB / to, "oracle_ratio": len(data) / float(len(ocomp)),
             "note": "one stream: deflate = 16 segments of 1 MiB on the device; inflate of a stream with flush points (this library's own: "
                     "a marker every 64 KiB of input) = the pieces between the markers decoded side by side and stitched (zmi_inflate_split); "
-                    "a stream without them (the CPU's) = one workgroup of 8 waves, a pass covers at most one deflate block"}
+                    "a stream without them (the CPU's) = one workgroup of 16 waves, a pass covers at most one deflate block"}
 
 
 def real_data_leg(e, torch, dev, B):

@@ -15,6 +15,9 @@ import numpy as np  # noqa: E402
 
 
 def main():
+    if os.environ.get("PROBE_WITH_TORCH"):   # (does a process that also holds torch's runtime see the same rates?)
+        import torch
+        torch.zeros(1 << 20, device="cuda").sum().item()
     ap = argparse.ArgumentParser()
     ap.add_argument("--shards", type=int, default=4096)
     ap.add_argument("--level", type=int, default=6)
