@@ -7,6 +7,7 @@ make -s -C tests/emu libzmi355_emu_asan.so
 ASAN=$(gcc -print-file-name=libasan.so)
 export ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0
 export ZMI_NO_ALLOC_FAULTS=1
+export ZMI_TUNING=1 ZMI_ABI_SPLIT_MIN=20000 ZMI_ABI_SPLIT_GAP=1500   # (streams of the tests' sizes are cut at their flush points)
 LD_PRELOAD=$ASAN python - <<'PY'
 import ctypes as C, json, os, sys, tempfile, zlib
 sys.path.insert(0, "tests")
@@ -34,5 +35,16 @@ for lvl in (1, 6, 9):
     for strat in (0, 2, 3, 4):
         outs, st = eng.deflate(shards, level=lvl, strategy=strat, wrap=2)
         assert [zlib.decompress(x, 31) for x in outs] == shards
+# round 3: segment-parallel inflate, pointer-jumping resolve, the host-buffer pipelines in small chunks, truncated stored blocks
+import parity_checks
+parity_checks.split_inflate_checks(eng, o)
+parity_checks.jump_resolve_checks(eng, o)
+H.flush_point_stream_checks(lib, o, seeds=range(700, 702))
+os.environ["ZMI_HOST_CHUNK"] = "30000"
+blobs = [o.gen_shard(i % 8, 9000 + 700 * i) for i in range(24)]
+outs, st = eng.deflate_host(blobs, level=6, wrap=1) if hasattr(eng, "deflate_host") else eng.deflate(blobs, level=6, wrap=1)
+assert [zlib.decompress(x) for x in outs] == blobs
+back, st2 = eng.inflate_host(outs, [len(b) for b in blobs], wrap=1) if hasattr(eng, "inflate_host") else eng.inflate(outs, [len(b) for b in blobs], wrap=1)
+assert back == blobs and not any(st2)
 print("asan check ok")
 PY
