@@ -470,6 +470,33 @@ def main():
     e.close()
 
 
+def _inflate_loop(H, lib, comp, wbits, expect_len, chunk=1 << 22):
+    """the blogpost-uncompress.rs loop with the output written where it belongs (no Python-side copies inside the timed region):
+    input in `chunk` pieces, room in `chunk` pieces; returns (seconds, rc, output bytes object)"""
+    strm = H.ZStream()
+    assert lib.inflateInit2_(C.byref(strm), wbits, lib.zlibVersion(), C.sizeof(H.ZStream)) == 0
+    src = C.create_string_buffer(comp, len(comp))
+    dst = C.create_string_buffer(expect_len + chunk)
+    pos = got = 0
+    rc = 0
+    t0 = time.perf_counter()
+    while True:
+        if strm.avail_in == 0 and pos < len(comp):
+            n = min(chunk, len(comp) - pos)
+            strm.next_in, strm.avail_in = C.addressof(src) + pos, n
+            pos += n
+        room = min(chunk, expect_len + chunk - got)
+        strm.next_out, strm.avail_out = C.addressof(dst) + got, room
+        rc = lib.inflate(C.byref(strm), 0)
+        got += room - strm.avail_out
+        if rc == 1 or (rc < 0 and rc != -5) or (rc == -5 and strm.avail_in == 0 and pos >= len(comp) and strm.avail_out != 0):
+            break
+    dt = time.perf_counter() - t0
+    unused = strm.avail_in + (len(comp) - pos)
+    lib.inflateEnd(C.byref(strm))
+    return dt, rc, dst.raw[:got], unused
+
+
 def stream_abi_leg(level):
     """BASELINE.json configs[0] (plumbing / reference): one ~15.74 MB input (silesia-small.tar is not in the reference
     checkout: 15 synthetic shards + the bytes that make up the size) through the stream ABI of libz_mi355.so exactly as
@@ -488,9 +515,7 @@ def stream_abi_leg(level):
     td = time.perf_counter() - t0
     ti = None
     for _ in range(2):   # (the first pass pays for the staging buffers of this size)
-        t0 = time.perf_counter()
-        rc, back, unused = H.inflate_stream(lib, comp, 31, chunk_in=1 << 22, chunk_out=1 << 22)
-        dt = time.perf_counter() - t0
+        dt, rc, back, unused = _inflate_loop(H, lib, comp, 31, len(data))
         ti = dt if ti is None else min(ti, dt)
         assert rc == 1 and back == data and unused == 0, "stream ABI round trip failed"
     rc, ocomp = o.deflate(data[:4 << 20], level, 2)
@@ -502,9 +527,7 @@ def stream_abi_leg(level):
     # what an unmodified caller's inflate() meets most often), through inflate() and through one uncompress2()-style call
     ti2 = None
     for _ in range(2):
-        t0 = time.perf_counter()
-        rc2, back2, unused2 = H.inflate_stream(lib, ocomp, 31, chunk_in=1 << 22, chunk_out=1 << 22)
-        dt = time.perf_counter() - t0
+        dt, rc2, back2, unused2 = _inflate_loop(H, lib, ocomp, 31, len(data))
         ti2 = dt if ti2 is None else min(ti2, dt)
         assert rc2 == 1 and back2 == data and unused2 == 0, "stream ABI inflate of the oracle's stream failed"
     import zlib
