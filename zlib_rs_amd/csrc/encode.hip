@@ -258,15 +258,20 @@ static __device__ void enc_huff_lengths_w(EncShared* S, const uint32_t* freq, ui
         zmi_wave_sync();
         return;
     }
-    // sorted leaf weights and the weights of the nodes made so far live in five registers per lane; the heads of the
-    // two queues are fetched with scalar lane reads, so the serial merge never waits for the LDS
-    uint32_t swr[5], nwr[5];
+    // The sorted leaf weights live in five registers per lane (the head of the leaf queue is a scalar lane read); the weights
+    // of the nodes made so far are a FIFO in LDS -- the scratch of the steps that come later (idep, and the header's symbol
+    // list for queues longer than 144) -- written by lane 0 and read back by all lanes at one address.  (Round 2 kept the node
+    // queue in five registers too: indexing a register array with a wave-uniform index is a switch, ~60 instructions per merge
+    // against ~28 with the LDS round trip; the merge is a third of a block's ~30 K instructions and the kernel is issue-bound.)
+    uint32_t swr[5];
 #pragma unroll
     for (uint32_t c = 0; c < 5u; ++c) {
         const uint32_t k = lane + 64u * c;
         swr[c] = k < nnz ? freq[S->order[k]] : 0xFFFFFFFFu;
-        nwr[c] = 0xFFFFFFFFu;
     }
+    zmi_wave_sync();   // (the weights have been read through S->order: the node queue may now reuse what lies behind it)
+    volatile uint32_t* const nq_lo = (volatile uint32_t*)S->idep;   // nodes 0..143
+    volatile uint32_t* const nq_hi = (volatile uint32_t*)S->hsym;   // nodes 144.. (hsym + hext: 160 words)
     {
         uint32_t li = 0, ii = 0;
         uint32_t cur = swr[0];              // the register holding the leaf queue's current 64 entries
@@ -286,10 +291,10 @@ static __device__ void enc_huff_lengths_w(EncShared* S, const uint32_t* freq, ui
                     w += nw;
                     if (lane == 0) S->ipar[ii] = (uint16_t)ni;
                     ++ii;
-                    nw = ii < ni ? enc_rd5(nwr, ii) : 0xFFFFFFFFu;
+                    nw = ii < ni ? zmi_uniform(ii < 144u ? nq_lo[ii] : nq_hi[ii - 144u]) : 0xFFFFFFFFu;
                 }
             }
-            enc_wr5(nwr, ni, w);
+            if (lane == 0) { if (ni < 144u) nq_lo[ni] = w; else nq_hi[ni - 144u] = w; }
             if (ii == ni) nw = w;   // the node just made is the head of its queue
         }
     }
