@@ -25,7 +25,7 @@
 //   * blocks follow the data: after every sub-block of 4096 tokens an entropy test decides whether it joins the
 //     open block or starts a new one (enc_split_pays).
 //   * per block: lane-parallel rank sort of the symbol frequencies (scalar lane reads), two-queue Huffman merge on
-//     wave-uniform state with both queues in registers, depths by parallel relaxation, Kraft-exact length limiting,
+//     wave-uniform state (leaf queue in registers, node queue a FIFO in LDS scratch), depths by parallel relaxation, Kraft-exact length limiting,
 //     canonical codes by ballot ranks, RFC 1951 header planned from registers and emitted through the bit packer.
 //   * bit packing: a wave prefix-sum over the code lengths gives every token its output bit
 //     position; codes are OR-ed into an LDS staging window with ds_or and whole dwords are stored
