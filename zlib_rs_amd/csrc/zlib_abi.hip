@@ -741,16 +741,20 @@ void find_flush_points(const uint8_t* in, size_t n, std::vector<uint32_t>& seg) 
     static const size_t kMin = [] { const char* e = abi_tune("ZMI_ABI_SPLIT_MIN"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)256 << 10; }();
     static const size_t kGap = [] { const char* e = abi_tune("ZMI_ABI_SPLIT_GAP"); return e && atol(e) > 0 ? (size_t)atol(e) : (size_t)8192; }();
     if (n < kMin || !split_enabled()) return;
-    static const uint8_t kMark[4] = {0x00, 0x00, 0xFF, 0xFF};
+    // 00 00 FF FF, found through its third byte: memchr runs at memory speed and 0xFF is every 256th byte of compressed data
+    // (memmem with a four-byte needle: 2.9 GB/s, 1.5 ms per 4 MiB piece -- an eighth of the call)
     seg.push_back(0u);
-    size_t at = kGap;
+    size_t at = kGap;   // where the next marker may start
     while (at + 4 < n && seg.size() < 8192u) {
-        const void* m = memmem(in + at, n - at, kMark, 4);
-        if (!m) break;
-        const size_t cut = (size_t)((const uint8_t*)m - in) + 4u;
-        if (cut >= n) break;
-        seg.push_back((uint32_t)cut);
-        at = cut + kGap;
+        const uint8_t* p = (const uint8_t*)memchr(in + at + 2, 0xFF, n - (at + 2) - 1);   // candidate for the marker's third byte
+        if (!p) break;
+        const size_t i = (size_t)(p - in);   // i >= at + 2, i + 1 < n
+        if (in[i + 1] == 0xFF && in[i - 1] == 0x00 && in[i - 2] == 0x00) {
+            const size_t cut = i + 2;
+            if (cut >= n) break;
+            seg.push_back((uint32_t)cut);
+            at = cut + kGap;
+        } else at = i - 1;   // the next candidate third byte is at i + 1 at the earliest
     }
     if (seg.size() < 4u) seg.clear();
 }
