@@ -7,7 +7,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzmi355.so")
 ABI_LIB = os.path.join(HERE, "libz_mi355.so")
 SOURCES = ["gen.hip", "checksum.hip", "lz77.hip", "encode.hip", "inflate.hip", "resolve_jump.hip", "pack.hip", "zmi_api.hip"]
-ABI_SOURCES = ["zlib_abi.hip", "gz_api.hip"]
+ABI_SOURCES = ["zlib_abi.hip", "gz_api.hip", "host_sums.cpp"]
 
 
 def _stale():

@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <string>
 #include <vector>
 
@@ -742,6 +743,9 @@ extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len,
         if (seg_start[j] <= seg_start[j - 1u] || seg_start[j] >= in_len)
             return zmi_inflate_resume(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume);
     ZMI_ON_DEVICE(c);
+    const bool sp_trace = zmi_tune("ZMI_SPLIT_TRACE") != nullptr;
+    auto sp_now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double sp_t0 = sp_trace ? sp_now() : 0.0;
     if (hist_len > 32768u) { hist += hist_len - 32768u; hist_len = 32768u; }
     const size_t base = ((size_t)hist_len + 1023u) & ~(size_t)1023u;
     // every segment decodes into a region of its own: 16 bytes of room per compressed byte (a segment that needs more ends the
@@ -790,6 +794,7 @@ extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len,
     std::vector<uint32_t> r(8 * n);   // olen | status | used | detail | resume[4n]
     ZMI_HIP(hipMemcpyAsync(r.data(), d + o_olen, 32 * n, hipMemcpyDeviceToHost, hs));
     ZMI_HIP(hipStreamSynchronize(hs));
+    const double sp_t1 = sp_trace ? sp_now() : 0.0;
     const uint32_t *olen = r.data(), *used = r.data() + 2 * n, *res = r.data() + 4 * n;
     const int32_t *st = (const int32_t*)(r.data() + n), *det = (const int32_t*)(r.data() + 3 * n);
     // the chain: segment j is CLEAN if its decode ended exactly at its last byte, on a block boundary, with all output complete
@@ -838,6 +843,7 @@ extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len,
     ZMI_HIP(hipMemcpyAsync(out, d_fin, (size_t)total, hipMemcpyDeviceToHost, hs));
     ZMI_HIP(hipStreamSynchronize(hs));
     ZMI_HIP(hipGetLastError());
+    if (sp_trace) fprintf(stderr, "[zmi split] %u segments, %u B in, %llu B out: copy-in + decode %.2f ms, stitch + resolve + copy-out %.2f ms\n", nseg, in_len, (unsigned long long)total, sp_t1 - sp_t0, sp_now() - sp_t1);
     if (err)   // a distance reaches in front of the history that is really there: let the serial decode find and name it
         return zmi_inflate_resume(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume);
     if (segments_used) *segments_used = take;
