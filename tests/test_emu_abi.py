@@ -145,6 +145,24 @@ def test_streams_with_flush_points_are_decoded_as_segments():
     assert used and max(used) >= 4, used   # the parallel path ran
 
 
+def test_host_checksums_match_zlib_at_every_length_and_alignment():
+    """crc32() / adler32() of the drop-in library (csrc/host_sums.cpp: carry-less-multiply folding and SSSE3 sums with scalar
+    heads and tails) against Python's zlib: lengths around the block sizes of the vector paths, odd offsets, running values"""
+    import random
+    import zlib
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    rng = random.Random(3)
+    pool = bytes(rng.randrange(256) for _ in range(70000)) + b"\xff" * 12000
+    lens = list(range(0, 200)) + [255, 256, 257, 5535, 5536, 5537, 5551, 5552, 5553, 11072, 65535, 65536, 70001] + [rng.randrange(82000) for _ in range(300)]
+    for n in lens:
+        off = rng.randrange(0, len(pool) - n + 1)
+        d = pool[off:off + n]
+        c0, a0 = rng.randrange(1 << 32), (rng.randrange(65521) << 16) | rng.randrange(65521)
+        assert lib.crc32(c0, d, n) == zlib.crc32(d, c0), n
+        assert lib.adler32(a0, d, n) == zlib.adler32(d, a0), n
+
+
 def test_random_deflate_streams(monkeypatch):
     """randomised deflate(): level, strategy, wrapper, input pieces, output room, flush points, primed bits; the
     system's zlib must read every stream back"""
