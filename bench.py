@@ -497,6 +497,37 @@ def _inflate_loop(H, lib, comp, wbits, expect_len, chunk=1 << 22):
     return dt, rc, dst.raw[:got], unused
 
 
+def _deflate_loop(H, lib, data, level, wbits, chunk=1 << 22):
+    """the blogpost-compress.rs loop (input in `chunk` pieces, Z_NO_FLUSH, then Z_FINISH) with the output written where it
+    belongs -- no Python-side copies inside the timed region; returns (seconds, compressed bytes)"""
+    strm = H.ZStream()
+    assert lib.deflateInit2_(C.byref(strm), level, 8, wbits, 8, 0, lib.zlibVersion(), C.sizeof(H.ZStream)) == 0
+    src = C.create_string_buffer(data, len(data))
+    cap = len(data) + (len(data) >> 3) + 4096
+    dst = C.create_string_buffer(cap)
+    pos = got = 0
+    t0 = time.perf_counter()
+    while True:
+        n = min(chunk, len(data) - pos)
+        strm.next_in, strm.avail_in = C.addressof(src) + pos, n
+        pos += n
+        flush = 4 if pos >= len(data) else 0   # Z_FINISH / Z_NO_FLUSH
+        while True:
+            room = min(chunk, cap - got)
+            strm.next_out, strm.avail_out = C.addressof(dst) + got, room
+            rc = lib.deflate(C.byref(strm), flush)
+            assert rc in (0, 1, -5), rc
+            got += room - strm.avail_out
+            if rc == 1 or (strm.avail_out != 0 and flush != 4) or rc == -5:
+                break
+        if flush == 4:
+            assert rc == 1
+            break
+    dt = time.perf_counter() - t0
+    assert lib.deflateEnd(C.byref(strm)) == 0
+    return dt, dst.raw[:got]
+
+
 def stream_abi_leg(level):
     """BASELINE.json configs[0] (plumbing / reference): one ~15.74 MB input (silesia-small.tar is not in the reference
     checkout: 15 synthetic shards + the bytes that make up the size) through the stream ABI of libz_mi355.so exactly as
@@ -510,9 +541,10 @@ def stream_abi_leg(level):
     data = b"".join(o.gen_shard(i, 1 << 20) for i in range(15))
     data += o.gen_shard(15, 1 << 20)[:total - len(data)]
     H.deflate_stream(lib, data[:1 << 20], level=level, wbits=31, chunk_in=1 << 20, chunk_out=1 << 20)   # first-use costs
-    t0 = time.perf_counter()
-    comp = H.deflate_stream(lib, data, level=level, wbits=31, chunk_in=1 << 22, chunk_out=1 << 22)
-    td = time.perf_counter() - t0
+    td = None
+    for _ in range(2):
+        dt, comp = _deflate_loop(H, lib, data, level, 31)
+        td = dt if td is None else min(td, dt)
     ti = None
     for _ in range(2):   # (the first pass pays for the staging buffers of this size)
         dt, rc, back, unused = _inflate_loop(H, lib, comp, 31, len(data))
