@@ -1260,7 +1260,9 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         chunks.push_back(std::move(ck));
     }
     const char* pl = zmi_tune("ZMI_HOST_PIPELINE");
-    if (chunks.size() < 2 || (pl && !atoi(pl)))
+    bool fits = true;   // (a chunk leaves the device as one copy range with a 32-bit length)
+    for (const chunk& ck : chunks) fits = fits && ck.out_bytes <= 0xFFFFF000ull && ck.in_bytes <= 0xFFFFF000ull;
+    if (chunks.size() < 2 || !fits || (pl && !atoi(pl)))
         return zmi_inflate_batch_simple(c, in, in_off, in_len, n, wrap, out, out_off, out_cap, out_len, status);
     ZMI_ON_DEVICE(c);
     int rc = zmi_host_pipeline_init(c);
