@@ -261,3 +261,19 @@ def split_inflate_checks(e, o, big=False):
             assert got[5] <= 1
     assert used_any > 0
     return len(cases)
+
+
+def truncated_stored_checks(inflate_fn, o):
+    """a stored block that is cut off, or does not fit its room, through the batch kernel: the bytes and the code of the oracle
+    (Mode::CopyBlock, inflate.rs:1374-1394: min(length, room, input) bytes are copied)"""
+    import zlib
+    raw = o.gen_shard(5, 150000)
+    co = zlib.compressobj(0, zlib.DEFLATED, -15)
+    stream = co.compress(raw) + co.flush()
+    cases = [(stream[:cut], len(raw)) for cut in (len(stream) - 1000, 70000, 65540, 10, 5)] + [(stream, 70000), (stream, 65535), (stream, len(raw))]
+    outs, st = inflate_fn([c for c, _ in cases], [cap for _, cap in cases], 0)
+    for (c, cap), got, s_ in zip(cases, outs, st):
+        rc, want, used, msg = o.inflate(c, cap, wrap=0)
+        rc = 0 if rc == 1 else rc   # (the oracle says Z_STREAM_END, the batch status 0 for a complete stream)
+        assert int(s_) == rc and bytes(got[:len(want)]) == want and len(got) >= len(want), (len(c), cap, int(s_), rc, len(got), len(want))
+    return len(cases)

@@ -384,6 +384,12 @@ def test_inflate_large_streams_fast_pass(eng, o):
     assert parity_checks.large_stream_checks(eng.inflate, o, lambda blobs, lvl, wrap: eng.deflate(blobs, level=lvl, wrap=wrap)) > 60
 
 
+def test_truncated_stored_blocks_match_the_oracle():
+    e = zmi_ctypes.Engine(zmi_ctypes.load_emu())
+    assert parity_checks.truncated_stored_checks(lambda streams, caps, wrap: e.inflate(streams, caps, wrap=wrap), oracle_lib.load()) == 8
+    e.close()
+
+
 def test_split_inflate_equals_serial_inflate():
     """one stream decoded as segments cut at its flush points (zmi_inflate_split): the results of zmi_inflate_resume,
     whatever the proposed cuts are (true markers, data that looks like one, random offsets)"""

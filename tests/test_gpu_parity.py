@@ -436,6 +436,12 @@ def test_inflate_large_streams_fast_pass_on_gpu(engine):
     assert n > 60
 
 
+def test_truncated_stored_blocks_match_the_oracle_on_gpu(engine):
+    import oracle_lib
+    import parity_checks
+    assert parity_checks.truncated_stored_checks(_inflate_fn(engine), oracle_lib.load(rebuild=False)) == 8
+
+
 def test_split_inflate_equals_serial_inflate_on_gpu():
     """one stream decoded as segments cut at its flush points, on the whole chip (zmi_inflate_split): the results of the
     serial zmi_inflate_resume for true markers, false ones, history, corruption, short room"""

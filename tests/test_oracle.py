@@ -129,3 +129,18 @@ def test_prng_matches_reference_lcg(o):
         state = (state * 1664525 + 1013904223) & 0xFFFFFFFF
         out += bytes([state >> 24]) * 2
     assert o.prng_bytes(314159, 20, 2) == bytes(out)
+
+
+def test_truncated_stored_block_hands_out_what_is_there(o):
+    """Mode::CopyBlock (inflate.rs:1374-1394) copies min(length, room, input): a stored block whose end is missing still
+    yields the bytes that arrived, and one that does not fit yields what fits -- checked against Python's zlib"""
+    import zlib
+    raw = o.gen_shard(5, 150000)
+    co = zlib.compressobj(0, zlib.DEFLATED, -15)
+    stream = co.compress(raw) + co.flush()
+    for cut in (len(stream) - 1000, 70000, 65540, 10, 5):
+        want = zlib.decompressobj(-15).decompress(stream[:cut])
+        rc, got, used, msg = o.inflate(stream[:cut], len(raw), wrap=0)
+        assert rc == -5 and got == want, (cut, rc, len(got), len(want))
+    rc, got, used, msg = o.inflate(stream, 70000, wrap=0)   # room for one block and a bit
+    assert rc == -5 and got == raw[:70000]
