@@ -5,7 +5,8 @@
  *  1. The zlib stream ABI of the reference, unchanged: z_stream, deflateInit2_/deflate/deflateEnd,
  *     inflateInit2_/inflate/inflateEnd, compress2/uncompress, adler32/crc32 (+_combine) ...
  *     Declared in zmi355_zlib.h with the reference line each symbol replaces
- *     (libz-rs-sys/src/lib.rs).  A caller of libz-rs-sys relinks against libzmi355.so.
+ *     (libz-rs-sys/src/lib.rs) and exported by the drop-in library libz_mi355.so, which is built on this one:
+ *     a caller of libz-rs-sys relinks against libz_mi355.so.
  *
  *  2. The batch entry points below (new, additive).  The reference's ABI is one stream per call
  *     (libz-rs-sys/src/lib.rs:1281 deflate, :636 inflate); the north-star workload is thousands of
@@ -43,6 +44,8 @@ typedef struct zmi_ctx zmi_ctx;
 #define ZMI_E_HIP (-102)
 #define ZMI_E_ARG (-103)
 #define ZMI_E_NOMEM (-104)
+#define ZMI_E_NORCCL (-105) /* the multi-GPU entry points need RCCL (librccl.so.1) and it could not be loaded */
+#define ZMI_E_RCCL (-106)   /* an RCCL call failed; zmi_last_error() holds ncclGetErrorString's text */
 
 const char* zmi_version(void);
 const char* zmi_last_error(void);
@@ -56,9 +59,24 @@ int zmi_ctx_set_scratch_limit(zmi_ctx* ctx, uint64_t bytes);
  * limit, i.e. 8 GiB of output -> 1 GiB of bitmap).  Streams beyond it report Z_MEM_ERROR (-4). */
 int zmi_ctx_set_inflate_out_limit(zmi_ctx* ctx, uint64_t bytes);
 
+/* Host-buffer batches (zmi_deflate_batch / zmi_inflate_batch) stage their chunks through pinned host memory and device slots
+ * that the context keeps for the next call (three slots; up to ~6.4 GiB pinned + as much HBM after a multi-GiB batch).
+ * zmi_ctx_set_pinned_limit bounds the pinned part (default 8 GiB, env ZMI_PINNED_MB; >= 64 MiB): chunk sizes follow it and a
+ * call that ends above it releases the staging.  zmi_ctx_trim releases it now.  If pinned memory cannot be had at all
+ * (memlock / container limits) the calls fall back to plain copies instead of failing. */
+int zmi_ctx_set_pinned_limit(zmi_ctx* ctx, uint64_t bytes);
+int zmi_ctx_trim(zmi_ctx* ctx);
+
 /* hipStream_t the single-stream host wrappers of this context (zmi_inflate_resume) copy and launch on, and the only thing
  * they wait for; default: the null stream.  One context per thread, each with its own stream, run concurrently. */
 int zmi_ctx_set_stream(zmi_ctx* ctx, void* stream);
+
+/* Decode-table entries (literal/length + distance tables) the device built for the most recent dynamic block that
+ * zmi_inflate_resume calls on this context met; 0 before the first one.  The reference's inflateCodesUsed
+ * (libz-rs-sys/src/lib.rs:1252, zlib-rs/src/inflate.rs:2372: state.next) reports the same quantity for its own tables
+ * (roots 10 / 9, ENOUGH 1332 + 592); the device tables use roots 9 / 8 with exact-fit sub-tables (at most 852 + 400). */
+int zmi_ctx_last_codes_used(zmi_ctx* ctx, uint32_t* entries);
+int zmi_ctx_reset_codes_used(zmi_ctx* ctx);
 
 /* per-kernel HIP-event timing for benchmarking: kernels 0 checksum, 1 lz77, 2 encode, 3 inflate (decode),
  * 4 verify, 6 inflate (resolve), 7 pack / stitch copies.  zmi_ctx_get_timing synchronises, returns the sums (ms) / launch counts since the
@@ -169,6 +187,46 @@ int zmi_copy_ranges_dev(zmi_ctx* ctx, const void* d_src, const uint64_t* d_src_o
                         uint32_t n, uint32_t max_len, void* d_dst, const uint64_t* d_dst_off, uint64_t dst_cap, void* stream);
 int zmi_pack_slab_dev(zmi_ctx* ctx, const void* d_slots, uint64_t slot_stride, const uint32_t* d_len, uint32_t n,
                       void* d_slab, uint64_t slab_cap, uint64_t* d_off, void* stream);
+
+/* ---- the stitch across the GPUs of a node (BASELINE.json configs[4]; csrc/exchange.hip) -------------------------------
+ * Shard g of a job lives on rank g % world (round-robin); every rank compresses its shards with zmi_deflate_batch_dev (no
+ * collective in the compression) and packs them into one dense slab (zmi_pack_slab_dev).  "Append the pieces in order" --
+ * the loop of the reference's parallel-deflate recipe, zlib-rs/src/deflate.rs:4145-4221 -- then is:
+ *   zmi_exchange_sizes        all-gather of the u32 size tables: d_table[r * n_local + j] = size of shard j * world + r
+ *   zmi_stitch_plan_dev       from the table alone: d_goff[r * n_local + j] = byte offset of that shard in the stitched
+ *                             output, d_soff[r * (n_local + 1) + j] = its offset inside rank r's slab (last entry of a row =
+ *                             the slab's size), d_totals[r] = slab size of rank r, d_totals[world] = size of the output;
+ *                             totals_host (may be NULL) receives a copy of d_totals (the call then waits for the stream)
+ *   zmi_exchange_slabs        the slabs travel point to point: per round of chunk_bytes ONE ncclGroupStart / End holding an
+ *                             ncclSend to and an ncclRecv from every peer -- xGMI is a full mesh, so the 7 transfers of a
+ *                             round run side by side, one link each; there is no all-gather-v in RCCL and a ring is never
+ *                             used.  root < 0: every rank receives every slab (d_recv[p] = room for slab_bytes[p] bytes;
+ *                             the own entry and NULL entries are skipped); root >= 0: only that rank receives
+ *   zmi_exchange_slabs_round  one round with bounded memory: peer p's bytes [lo, lo + chunk_bytes) arrive at the start of
+ *                             d_stage[p]; the caller consumes them and reuses the staging for the next round
+ *   zmi_copy_ranges_dev       (above) scatters a slab or a round of it into the ordered output: d_src_off = the peer's row
+ *                             of d_soff, d_dst_off = its row of d_goff.
+ * All operations are enqueued on `stream`; slab_bytes / d_recv / d_stage are HOST arrays of `world` entries.
+ * The communicator: zmi_comm_unique_id on one rank, the 128 bytes carried to the others by whatever the host has (MPI, a
+ * file, torch's store), zmi_comm_create on every rank (ncclCommInitRank on the context's device) -- or zmi_comm_adopt for a
+ * host that already holds an ncclComm_t.  RCCL is loaded on first use (dlopen librccl.so.1; ZMI_RCCL_LIB overrides the
+ * file): processes that never call these functions do not need it. */
+#define ZMI_UNIQUE_ID_BYTES 128
+typedef struct zmi_comm zmi_comm;
+int zmi_comm_unique_id(void* id128);
+int zmi_comm_create(zmi_comm** comm, zmi_ctx* ctx, int world, int rank, const void* id128);
+int zmi_comm_adopt(zmi_comm** comm, zmi_ctx* ctx, void* nccl_comm);
+int zmi_comm_destroy(zmi_comm* comm);
+int zmi_comm_abort(zmi_comm* comm); /* ncclCommAbort: for a communicator whose peers are gone */
+int zmi_comm_world(const zmi_comm* comm);
+int zmi_comm_rank(const zmi_comm* comm);
+int zmi_exchange_sizes(zmi_comm* comm, const uint32_t* d_sizes, uint32_t n_local, uint32_t* d_table, void* stream);
+int zmi_stitch_plan_dev(zmi_ctx* ctx, const uint32_t* d_table, uint32_t world, uint32_t n_local, uint64_t* d_goff,
+                        uint64_t* d_soff, uint64_t* d_totals, uint64_t* totals_host, void* stream);
+int zmi_exchange_slabs(zmi_comm* comm, const void* d_slab, const uint64_t* slab_bytes, void* const* d_recv,
+                       uint64_t chunk_bytes, int root, void* stream);
+int zmi_exchange_slabs_round(zmi_comm* comm, const void* d_slab, const uint64_t* slab_bytes, uint64_t lo,
+                             uint64_t chunk_bytes, void* const* d_stage, int root, void* stream);
 
 /* ---- host-buffer convenience wrappers: copy in, run the batch on the GPU, copy back ---- */
 int zmi_deflate_batch(zmi_ctx* ctx, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n_shards,

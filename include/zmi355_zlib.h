@@ -1,8 +1,9 @@
-/* zmi355_zlib.h -- the zlib stream ABI exported by libzmi355.so.
+/* zmi355_zlib.h -- the zlib stream ABI exported by libz_mi355.so (the drop-in library; the batch engine it runs on is
+ * libzmi355.so, include/zmi355.h).
  *
  * Same symbols, same z_stream layout (112 bytes on LP64) and same return codes as the reference's
  * C ABI crate libz-rs-sys, so a C program or a Rust `extern "C"` block written against
- * libz-rs-sys/include/zlib.h links against libzmi355.so unchanged.  Behind these entry points the
+ * libz-rs-sys/include/zlib.h links against libz_mi355.so unchanged.  Behind these entry points the
  * deflate / inflate work runs on the MI355X (kernels in zlib_rs_amd/csrc); without a HIP device the
  * *Init* functions fail with Z_MEM_ERROR and msg "no HIP device" -- there is no CPU fallback.
  *
@@ -23,8 +24,10 @@
  *              (zmi_inflate_resume, include/zmi355.h; the reference's Mode / BitReader / Window,
  *              zlib-rs/src/inflate.rs:288-320): a block is decoded again only while it is incomplete, memory
  *              is bounded by the block size.  Bytes behind the end of the stream are handed back (avail_in / next_in)
- *              exactly, whenever the end is reached.  Wrapper header / trailer are parsed on the host.  Z_BLOCK and
- *              Z_TREES do not stop at block ends (they behave like Z_NO_FLUSH).  The bytes in front of a corrupt
+ *              exactly, whenever the end is reached.  Wrapper header / trailer are parsed on the host.  Z_BLOCK stops at
+ *              the next block boundary and Z_TREES also behind the next block header, with data_type = unused bits |
+ *              64 (last block) | 128 (boundary) | 256 (behind a header), as the reference does (zlib-rs/src/inflate.rs:
+ *              1276-1284,1323,1369,1772,1856-1873).  The bytes in front of a corrupt
  *              spot are delivered before Z_DATA_ERROR, as the reference does; header, trailer and deflate-data errors
  *              carry the reference's messages ("invalid stored block lengths", "invalid distance too far back", ...:
  *              the decode kernel reports the cause, inflate.rs State::bad).

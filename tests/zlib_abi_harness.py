@@ -1176,7 +1176,17 @@ def misc_symbol_checks(lib, o):
     lib.inflateUndermine.argtypes = [P, C.c_int]
     lib.inflateCodesUsed.argtypes, lib.inflateCodesUsed.restype = [P], C.c_ulong
     assert lib.inflateUndermine(C.byref(s), 1) in (Z_OK, Z_DATA_ERROR) and lib.inflateUndermine(None, 1) == Z_STREAM_ERROR
-    assert lib.inflateCodesUsed(C.byref(s)) < 1332 + 592 + 1   # never more than ENOUGH (zlib-rs/src/lib.rs:88-102)
+    # inflateCodesUsed (libz-rs-sys/src/lib.rs:1252, zlib-rs/src/inflate.rs:2372): the last stream above was a dynamic-block
+    # stream -> the tables' entry count: at least the two root tables (2^9 + 2^8 here), never more than ENOUGH
+    # (zlib-rs/src/lib.rs:88-102); zero again after a reset, still zero after a stored-only stream, (ulong)-1 for no stream
+    used = lib.inflateCodesUsed(C.byref(s))
+    assert 512 + 256 <= used <= 852 + 400 < 1332 + 592 + 1, used
+    assert lib.inflateReset2(C.byref(s), 15) == Z_OK and lib.inflateCodesUsed(C.byref(s)) == 0
+    blob0 = zlib.compress(data[:3000], 0)
+    src, dst = C.create_string_buffer(blob0, len(blob0)), C.create_string_buffer(3000)
+    s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), len(blob0), C.addressof(dst), 3000
+    assert lib.inflate(C.byref(s), Z_FINISH) == Z_STREAM_END and dst.raw == data[:3000] and lib.inflateCodesUsed(C.byref(s)) == 0
+    assert lib.inflateCodesUsed(None) == C.c_ulong(-1).value
     assert lib.inflateEnd(C.byref(s)) == Z_OK
     # --- the _z one-shots (lib.rs:1379-1561, :433-583)
     zsz = C.c_size_t

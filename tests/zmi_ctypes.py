@@ -32,6 +32,16 @@ def _bind(lib):
     lib.zmi_inflate_resume.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, u32p, i32p, i32p, u32p, u32p]
     lib.zmi_inflate_split.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, u32p, i32p, i32p, u32p,
                                       u32p, u32p]
+    # the multi-GPU stitch (csrc/exchange.hip)
+    lib.zmi_comm_unique_id.argtypes = [vp]
+    lib.zmi_comm_create.argtypes = [C.POINTER(vp), vp, C.c_int, C.c_int, vp]
+    lib.zmi_comm_destroy.argtypes = [vp]
+    lib.zmi_comm_world.argtypes = [vp]
+    lib.zmi_comm_rank.argtypes = [vp]
+    lib.zmi_exchange_sizes.argtypes = [vp, vp, C.c_uint32, vp, vp]
+    lib.zmi_stitch_plan_dev.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, vp, vp, vp, vp]
+    lib.zmi_exchange_slabs.argtypes = [vp, vp, vp, vp, C.c_uint64, C.c_int, vp]
+    lib.zmi_exchange_slabs_round.argtypes = [vp, vp, vp, C.c_uint64, C.c_uint64, vp, C.c_int, vp]
     return lib
 
 

@@ -45,3 +45,5 @@ res = {k: {"fetch_bytes_per_launch": v.get("FETCH_SIZE", 0) * 1024 * 2, "write_b
 res["_collected"] = "$TAG, " + datetime.date.today().isoformat()
 json.dump(res, open("$O/$TAG/traffic.json", "w"), indent=1)
 PY
+# (the caller redirects stdout into gpurun_out/TAG/rocprofv3_summary.csv: the issue file is made from it afterwards)
+echo "python tools/make_issue_json.py gpurun_out/$TAG/rocprofv3_summary.csv profiles/${TAG}_issue.json $TAG" > $O/$TAG/make_issue.cmd

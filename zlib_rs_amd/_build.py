@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzmi355.so")
 ABI_LIB = os.path.join(HERE, "libz_mi355.so")
-SOURCES = ["gen.hip", "checksum.hip", "lz77.hip", "encode.hip", "inflate.hip", "resolve_jump.hip", "pack.hip", "zmi_api.hip"]
+SOURCES = ["gen.hip", "checksum.hip", "lz77.hip", "encode.hip", "inflate.hip", "resolve_jump.hip", "pack.hip", "exchange.hip", "zmi_api.hip"]
 ABI_SOURCES = ["zlib_abi.hip", "gz_api.hip", "host_sums.cpp"]
 
 
@@ -25,7 +25,7 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + srcs
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + srcs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -35,6 +35,15 @@ def lib():
     L.zmi_pack_slab_dev.argtypes = [vp, vp, u64, vp, u32, vp, u64, vp, vp]
     L.zmi_deflate_batch.argtypes = [vp, vp, vp, vp, u32, i32, i32, i32, vp, u64, vp, vp]
     L.zmi_inflate_batch.argtypes = [vp, vp, vp, vp, u32, i32, vp, vp, vp, vp, vp]
+    # the multi-GPU stitch (csrc/exchange.hip); RCCL itself is loaded by the library on first use
+    L.zmi_comm_unique_id.argtypes = [vp]
+    L.zmi_comm_create.argtypes = [C.POINTER(vp), vp, i32, i32, vp]
+    L.zmi_comm_destroy.argtypes = [vp]
+    L.zmi_comm_abort.argtypes = [vp]
+    L.zmi_exchange_sizes.argtypes = [vp, vp, u32, vp, vp]
+    L.zmi_stitch_plan_dev.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp, vp]
+    L.zmi_exchange_slabs.argtypes = [vp, vp, vp, vp, u64, i32, vp]
+    L.zmi_exchange_slabs_round.argtypes = [vp, vp, vp, u64, u64, vp, i32, vp]
     _lib = L
     return L
 

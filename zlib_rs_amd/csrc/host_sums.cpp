@@ -37,6 +37,9 @@ uint32_t crc_table(uint32_t crc, const uint8_t* buf, size_t len) {
 }
 
 #if defined(__x86_64__)
+// Attribution: the folding scheme, its constants and the register naming (x0..x8, y5..y8) follow the public PCLMULQDQ CRC-32
+// routine of Chromium's zlib (contrib/optimizations crc32_simd.c, BSD-style licence, (c) The Chromium Authors), itself an
+// implementation of Intel's white paper below -- NOT the reference's crc32/pclmulqdq.rs, which is structured differently.
 // CRC-32 by carry-less multiplication ("Fast CRC Computation for Generic Polynomials Using PCLMULQDQ", Gopal et al.): four
 // 128-bit lanes folded 64 bytes at a time, then to one lane, to 64 bits, Barrett reduction.  len >= 64, a multiple of 16.
 // The constants are x^n mod P for the bit-reflected polynomial 0x1DB710641: n = 4*128+32, 4*128-32, 128+32, 128-32, 64.

@@ -241,6 +241,7 @@ static __device__ __noinline__ uint32_t inf_build(InfShared* S_, uint32_t kind, 
     const uint32_t rsize = 1u << root;
     for (uint32_t i = lane; i < rsize; i += 64u) tab[i] = INF_ENTRY(0, INF_OP_BAD, 0);
     zmi_wave_sync();
+    if (lane == 0u) S->misc[3] = rsize;   // entries this table occupies (the root alone so far); inflateCodesUsed sums them
     if (maxl == 0u) return 0u;  // no codes at all: every lookup reports an invalid code
 
     // every symbol: its place in the (length, index) order and its code; short codes fill their root entries
@@ -309,6 +310,7 @@ static __device__ __noinline__ uint32_t inf_build(InfShared* S_, uint32_t kind, 
         used += zmi_readlane(incl, 63u);
     }
     if (used > cap) return 2u;
+    if (lane == 0u) S->misc[3] = used;
     for (uint32_t j = rsize + lane; j < used; j += 64u) tab[j] = INF_ENTRY(0, INF_OP_BAD, 0);
     zmi_wave_sync();
     for (uint32_t base = 0; base < nlong; base += 64u) {
@@ -472,9 +474,6 @@ static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, co
     // second-level reads and the distance code sit behind wave-uniform branches.
     if (__ballot(go)) do {
         const uint32_t wi = pos >> 5;
-#ifdef ZMI_EMU_DEBUG
-        if (wi > 1100u) { fprintf(stderr, "lane %u wave %u pos %u start %u boundary %u active %d\n", zmi_lane(), zmi_wave(), pos, start, boundary, (int)active); abort(); }
-#endif
         const uint32_t d0 = fw[wi], d1 = fw[wi + 1u], d2 = fw[wi + 2u];
         const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, pos & 31u);
         uint32_t e = S->ltab[lo & ((1u << INF_LROOT) - 1u)];
@@ -785,9 +784,6 @@ static __device__ __noinline__ void inf_pass_mw(const uint8_t* src, uint8_t* dst
                        eobf = (zmi_readlane(R.flags, k) >> 1) & 1u;
         if (lane == 0u) { M->res_bits = bits; M->res_out = outm; M->res_eob = eobf; }
     }
-#ifdef ZMI_EMU_DEBUG
-    if (wave == 0u && lane == 0u) fprintf(stderr, "pass nact %u sub %u lanes %u\n", nact, sub, total_lanes);
-#endif
     if (wave == 0u && lane == 0u) M->res_lanes = total_lanes;
     __syncthreads();
 }
@@ -898,7 +894,7 @@ __global__ void __launch_bounds__(64 * NW) zmi_inflate_kernel(const uint8_t* __r
         const uint32_t sb = ibw & 7u;
         max_blocks = (ibw >> 8) & 0xFFFFu;
         hdr_stop = ((ibw >> 24) & 1u) != 0u;
-        if (lane == 0) { S->rs[0] = 0; S->rs[1] = sb; S->rs[2] = 0; S->rs[3] = 0; }
+        if (lane == 0) { S->rs[0] = 0; S->rs[1] = sb; S->rs[2] = 0; S->rs[3] = 0; S->misc[5] = 0; }
         if (sb) {
             inf_refill(B);
             if (B.nbits < sb) st = ZMI_BUF_ERROR;
@@ -1065,9 +1061,13 @@ __global__ void __launch_bounds__(64 * NW) zmi_inflate_kernel(const uint8_t* __r
             zmi_wave_sync();
             if (zmi_uniform(S->lens[256]) == 0) { st = ZMI_DERR(DE_MISSING_EOB); break; }  // "invalid code -- missing end-of-block"
             if (zmi_uniform(inf_build(S, 1u, nlen, S->ltab, INF_LROOT, INF_LSIZE))) { st = ZMI_DERR(DE_LITLEN_SET); break; }  // "invalid literal/lengths set"
+            if (RESUME && lane == 0u) S->misc[5] = S->misc[3];
             if (lane < ndist) S->lens[lane] = S->stage[nlen + lane];
             zmi_wave_sync();
             if (zmi_uniform(inf_build(S, 2u, ndist, S->dtab, INF_DROOT, INF_DSIZE))) { st = ZMI_DERR(DE_DIST_SET); break; }  // "invalid distances set"
+            // table entries in use for the most recent dynamic block: what inflateCodesUsed reports (the reference's state.next,
+            // zlib-rs/src/inflate.rs:1753-1768,2372 -- there with roots 10 / 9, here with this kernel's 9 / 8 and exact-fit sub-tables)
+            if (RESUME && lane == 0u) S->misc[5] += S->misc[3];
         }
 
         if (RESUME && hdr_stop) {   // behind the block type bits (fixed codes) or the transmitted code lengths (dynamic)
@@ -1281,7 +1281,7 @@ __global__ void __launch_bounds__(64 * NW) zmi_inflate_kernel(const uint8_t* __r
     if (lane == 0) {
         out_len[s] = opos;
         in_used[s] = B.ipos;
-        check[s] = chk;
+        check[s] = RESUME ? S->misc[5] : chk;   // (a resumable decode is a raw stream: no trailer value; the word carries the tables' size)
         status[s] = st;
         if (RESUME) {
             resume[4u * s] = S->rs[0]; resume[4u * s + 1u] = S->rs[1]; resume[4u * s + 2u] = S->rs[2]; resume[4u * s + 3u] = S->rs[3];

@@ -221,6 +221,16 @@ static __device__ __forceinline__ void lz_build_tile_t(const uint8_t* win, uint1
     }
 }
 
+#ifdef ZMI_EMU
+// emulator-only experiment counters (tools/emu_lz_probe.py): 0 lane chain steps, 1 wave chain steps, 2 lane extension rounds,
+// 3 wave extension rounds, 4 claims
+static uint64_t g_emu_lz[8];
+static inline void emu_lz_count(int k, uint64_t v) { __atomic_fetch_add(&g_emu_lz[k], v, __ATOMIC_RELAXED); }
+extern "C" void zmi_emu_lz_counts(uint64_t* out, int reset) {
+    for (int i = 0; i < 8; ++i) { out[i] = g_emu_lz[i]; if (reset) g_emu_lz[i] = 0; }
+}
+#endif
+
 template <bool H6>
 static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_t* prev, uint16_t* head, uint16_t* head4,
                                                      uint16_t* c4, uint32_t tile, uint32_t n, uint32_t max_dist, LzCtl* ctl,
@@ -356,123 +366,151 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
         }
         base0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)base0);
         if (base0 >= n) break;
-        if (prm.dbg == 1u) {   // measurement aid (ZMI_LZ_DBG=1 under ZMI_TUNING): the producers' pace alone -- the searchers claim, read
+#ifdef ZMI_LZ_MEASURE   // measurement builds only (variants/): the product's searcher loop carries no branch for it
+        if (prm.dbg == 1u) {   // ZMI_LZ_DBG=1 under ZMI_TUNING: the producers' pace alone -- the searchers claim, read
                                // one byte and store a literal (profiles/r03_lz77_experiments.txt)
             const uint32_t need = base0 + 64u < n ? base0 + 64u : n;
             while (lz_ld_acq(&ctl->ready) < need) lz_pause();
             if (base0 + lane < n) mout[base0 + lane] = win[(base0 + lane) & LZ_WMASK];
             continue;
         }
+#endif
       for (uint32_t half = 0; half * 64u < prm.claim; ++half) {
         const uint32_t base = base0 + half * 64u;
         if (base >= n) break;
         const uint32_t need = base + 64u < n ? base + 64u : n;
         while (lz_ld_acq(&ctl->ready) < need) lz_pause();
-
+#ifdef ZMI_EMU
+        if (lane == 0) emu_lz_count(4, 1);
+#endif
+        // Every lane runs the same straight-line code, also the lanes behind the end of the shard in its last claim (their ring
+        // addresses are valid whatever they hold; maxlen = 0 keeps them out of the probe, out of the walk and out of the store):
+        // a validity branch around the set-up cost a dozen instructions per claim for registers that had to be defined on both sides.
         const uint32_t p = base + lane;
-        uint32_t res = 0;
-        uint32_t mylo = 0, myhi = 0, my2 = 0, my3 = 0, maxlen = 0, delta = 0, lim = 0;
+        uint32_t mylo, myhi, my2, my3;
+        lz_ring64(win, p, mylo, myhi);
+        lz_ring64(win, p + 8u, my2, my3);
+        uint32_t maxlen = p < n ? n - p : 0u;
+        maxlen = maxlen > 258u ? 258u : maxlen;
+        // links are raw (lz_build_tile): alive if 1 <= distance <= lim
+        const uint32_t lim = p < prm.max_dist ? p : prm.max_dist;
+        uint32_t delta = prev[p & LZ_WMASK];
+        delta = delta - 1u < lim ? delta : 0u;
         uint32_t blen = 3u, bdist = 0u, tail = 0u;
-        if (p < n) {
-            lz_ring64(win, p, mylo, myhi);
-            lz_ring64(win, p + 8u, my2, my3);
-            res = mylo & 0xFFu;
-            maxlen = n - p;
-            if (maxlen > 258u) maxlen = 258u;
-            // links are raw (lz_build_tile): alive if 1 <= distance <= lim
-            lim = p < prm.max_dist ? p : prm.max_dist;
-            delta = prev[p & LZ_WMASK];
-            delta = delta - 1u < lim ? delta : 0u;
-            // H6: the most recent 4-byte match (no chain of its own) is looked at first, outside the chain loop and with an
-            // 8-byte compare only: what it is for are the 4- and 5-byte matches the 6-byte chain cannot see; a longer match
-            // is in the chain as well.  (Peeling a full-size step out of the loop was slower -- lanes without a probe idle
-            // through it -- but this one is a third of a chain step and takes the probe bookkeeping out of every step.)
-            if (H6) {
-                const uint32_t d4 = c4[p & (LZ_C4RING - 1u)];
-                if (d4 - 1u < lim && d4 != delta && maxlen >= 4u) {
-                    uint32_t a, b;
-                    lz_ring64(win, p - d4, a, b);
-                    const uint32_t c0 = zmi_ffbl(a ^ mylo), c1 = zmi_ffbl(b ^ myhi) | 32u;
-                    uint32_t l = (c0 < c1 ? c0 : c1) >> 3;
-                    l = l > 8u ? 8u : l;
-                    l = l > maxlen ? maxlen : l;
-                    if (l >= 4u) { blen = l; bdist = d4; }
-                }
+        // H6: the most recent 4-byte match (no chain of its own) is looked at first, outside the chain loop and with an
+        // 8-byte compare only: what it is for are the 4- and 5-byte matches the 6-byte chain cannot see; a longer match
+        // is in the chain as well.  (Peeling a full-size step out of the loop was slower -- lanes without a probe idle
+        // through it -- but this one is a third of a chain step and takes the probe bookkeeping out of every step.)
+        if (H6) {
+            const uint32_t d4 = c4[p & (LZ_C4RING - 1u)];
+            if (d4 - 1u < lim && d4 != delta && maxlen >= 4u) {
+                uint32_t a, b;
+                lz_ring64(win, p - d4, a, b);
+                const uint32_t c0 = zmi_ffbl(a ^ mylo), c1 = zmi_ffbl(b ^ myhi) | 32u;
+                uint32_t l = (c0 < c1 ? c0 : c1) >> 3;
+                l = l > 8u ? 8u : l;
+                l = l > maxlen ? maxlen : l;
+                if (l >= 4u) { blen = l; bdist = d4; }
             }
         }
-        const bool barren = H6 && __ballot(blen >= 4u) == 0ull;   // (all lanes vote: outside the bounds check)
-        if (p < n) {
-            // candidates per position: max_chain counts the probe.  In a claim where not one of the 64 probes hit (a
-            // stretch of incompressible data: every chain candidate there is a hash collision, and each costs a full step)
-            // the positions walk one link only.  (Decided from the claim's own data: the output does not depend on which
-            // wave ran which claim.)
-            uint32_t chain = H6 ? (prm.max_chain > 1u ? prm.max_chain - 1u : prm.max_chain) : prm.max_chain;
-            if (H6 && barren && chain > 1u) chain = 1u;
-            if (maxlen >= 4u && delta != 0u && prm.max_chain != 0u) {
-                uint32_t cand = p - delta;
-                // a match this long ends the walk: nice_len, the end of the input -- and, for the short budgets, good_len
-                // (the reference quarters the remaining chain there, longest_match.rs:60-66: of a budget of 3 nothing is left)
-                constexpr bool deep = DEEP;   // prm.max_chain > 8 (the launcher picks the instantiation): the short budgets never halve
-                                              // their chain, and the three instructions of that bookkeeping leave their loop
-                uint32_t stoplen = prm.nice_len < maxlen ? prm.nice_len : maxlen;
-                if (!deep && prm.good_len < stoplen) stoplen = prm.good_len;
-                const uint32_t goodlen = deep ? prm.good_len : 259u;
-                // The loop body is straight-line for the common case: a candidate is decided by its
-                // first 16 bytes (five aligned dwords, one LDS round trip together with the prev
-                // link).  Only matches of 16+ bytes enter the divergent extension loop, so the wave
-                // rarely pays for it (an 8-byte threshold made 2/3 of the steps on text execute the
-                // extension block for some lane).
-                for (;;) {
-                    const uint32_t r = cand & LZ_WMASK;
-                    const uint32_t* w = (const uint32_t*)(win + (r & ~3u));
-                    const uint32_t dn = prev[r];
-                    const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
-                    const uint32_t sh = r & 3u;
-                    // first differing byte of the 16: v_ffbl gives -1 for an all-equal dword, so OR-ing in the dword's
-                    // bit offset keeps that "infinite" and a three-way minimum picks the first mismatch
-                    const uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sh) ^ mylo, x1 = __builtin_amdgcn_alignbyte(w2, w1, sh) ^ myhi;
-                    const uint32_t x2 = __builtin_amdgcn_alignbyte(w3, w2, sh) ^ my2, x3 = __builtin_amdgcn_alignbyte(w4, w3, sh) ^ my3;
-                    const uint32_t c0 = zmi_ffbl(x0), c1 = zmi_ffbl(x1) | 32u;
-                    const uint32_t c2 = zmi_ffbl(x2) | 64u, c3 = zmi_ffbl(x3) | 96u;
-                    uint32_t m3 = c0 < c1 ? c0 : c1;
-                    m3 = m3 < c2 ? m3 : c2;
-                    m3 = m3 < c3 ? m3 : c3;
-                    uint32_t l = m3 >> 3;        // 0..15, or 0x1FFFFFFF when all 16 bytes are equal
-                    l = l > 16u ? 16u : l;
-                    // (a candidate that differs inside its first 16 bytes cannot beat a best match of 16+: nothing to do)
-                    // rare: all 16 bytes equal.  With a best match of 16+ already, the 4 bytes ending at the best length
-                    // decide first whether this candidate can be longer at all.
-                    if (l == 16u && blen >= 16u && lz_ring32(win, cand + blen - 3u) != tail) l = 0u;
-                    if (l == 16u && maxlen > 16u) {
-                        // extend 16 bytes per round
-                        for (;;) {
-                            uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
-                            lz_ring64(win, p + l, a0, a1);
-                            lz_ring64(win, p + l + 8u, a2, a3);
-                            lz_ring64(win, cand + l, b0, b1);
-                            lz_ring64(win, cand + l + 8u, b2, b3);
-                            uint32_t m = lz_match8(a0 ^ b0, a1 ^ b1);
-                            if (m == 8u) m += lz_match8(a2 ^ b2, a3 ^ b3);
-                            l += m;
-                            if (m < 16u || l >= maxlen) break;
-                        }
+        // candidates per position: max_chain counts the probe.  In a claim where not one of the 64 probes hit (a stretch of
+        // incompressible data: every chain candidate there is a hash collision, and each costs a full step) the positions walk
+        // prm.barren_chain links only.  (Decided from the claim's own data: the output does not depend on which wave ran
+        // which claim.)
+        const bool barren = H6 && __ballot(blen >= 4u) == 0ull;
+        uint32_t chain = H6 ? (prm.max_chain > 1u ? prm.max_chain - 1u : prm.max_chain) : prm.max_chain;
+        if (H6 && barren && chain > prm.barren_chain) chain = prm.barren_chain;
+        // a match this long ends the walk: nice_len, the end of the input -- and, for the short budgets, good_len
+        // (the reference quarters the remaining chain there, longest_match.rs:60-66: of a budget of 3 nothing is left)
+        constexpr bool deep = DEEP;   // prm.max_chain > 8 (the launcher picks the instantiation): the short budgets never halve
+                                      // their chain, and the three instructions of that bookkeeping leave their loop
+        uint32_t stoplen = prm.nice_len < maxlen ? prm.nice_len : maxlen;
+        if (!deep && prm.good_len < stoplen) stoplen = prm.good_len;
+        const uint32_t goodlen = deep ? prm.good_len : 259u;
+        uint32_t cand = p - delta;
+        bool walk = maxlen >= 4u && delta != 0u && prm.max_chain != 0u && chain != 0u;
+        uint32_t stepno = 0;
+        // The walk is a loop of the WAVE: every trip is one chain step of all positions still walking (one LDS round trip:
+        // the candidate's link and its first 16 bytes as five aligned dwords), and the wave decides together whether
+        // another trip pays -- with fewer than prm.min_live positions left it does not: the step would cost the wave
+        // what it costs with 64.  Only matches of 16+ bytes enter the divergent extension loop,
+        // so the wave rarely pays for it (an 8-byte threshold made 2/3 of the steps on text execute the extension block
+        // for some lane).
+        for (;;) {
+            const uint64_t live = __ballot(walk);
+            if (live == 0ull) break;
+            if (prm.min_live > 1u && stepno >= prm.live_from && (uint32_t)__popcll((unsigned long long)live) < prm.min_live) break;
+            ++stepno;
+#ifdef ZMI_EMU
+            uint32_t emu_xr = 0;
+            if (lane == 0) emu_lz_count(1, 1);
+#endif
+            if (walk) {
+#ifdef ZMI_EMU
+                emu_lz_count(0, 1);
+#endif
+                const uint32_t r = cand & LZ_WMASK;
+                const uint32_t* w = (const uint32_t*)(win + (r & ~3u));
+                const uint32_t dn = prev[r];
+                const uint32_t w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+                const uint32_t sh = r & 3u;
+                // first differing byte of the 16: v_ffbl gives -1 for an all-equal dword, so OR-ing in the dword's
+                // bit offset keeps that "infinite" and a three-way minimum picks the first mismatch
+                const uint32_t x0 = __builtin_amdgcn_alignbyte(w1, w0, sh) ^ mylo, x1 = __builtin_amdgcn_alignbyte(w2, w1, sh) ^ myhi;
+                const uint32_t x2 = __builtin_amdgcn_alignbyte(w3, w2, sh) ^ my2, x3 = __builtin_amdgcn_alignbyte(w4, w3, sh) ^ my3;
+                const uint32_t c0 = zmi_ffbl(x0), c1 = zmi_ffbl(x1) | 32u;
+                const uint32_t c2 = zmi_ffbl(x2) | 64u, c3 = zmi_ffbl(x3) | 96u;
+                uint32_t m3 = c0 < c1 ? c0 : c1;
+                m3 = m3 < c2 ? m3 : c2;
+                m3 = m3 < c3 ? m3 : c3;
+                uint32_t l = m3 >> 3;        // 0..15, or 0x1FFFFFFF when all 16 bytes are equal
+                l = l > 16u ? 16u : l;
+                // (a candidate that differs inside its first 16 bytes cannot beat a best match of 16+: nothing to do)
+                // rare: all 16 bytes equal.  With a best match of 16+ already, the 4 bytes ending at the best length
+                // decide first whether this candidate can be longer at all.
+                if (l == 16u && blen >= 16u && lz_ring32(win, cand + blen - 3u) != tail) l = 0u;
+                if (l == 16u && maxlen > 16u) {
+                    // extend 16 bytes per round
+                    for (;;) {
+#ifdef ZMI_EMU
+                        emu_lz_count(2, 1);
+                        ++emu_xr;
+#endif
+                        uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
+                        lz_ring64(win, p + l, a0, a1);
+                        lz_ring64(win, p + l + 8u, a2, a3);
+                        lz_ring64(win, cand + l, b0, b1);
+                        lz_ring64(win, cand + l + 8u, b2, b3);
+                        uint32_t m = lz_match8(a0 ^ b0, a1 ^ b1);
+                        if (m == 8u) m += lz_match8(a2 ^ b2, a3 ^ b3);
+                        l += m;
+                        if (m < 16u || l >= maxlen) break;
                     }
-                    l = l > maxlen ? maxlen : l;
-                    const bool better = l > blen;
-                    blen = better ? l : blen;
-                    bdist = better ? p - cand : bdist;
-                    if (better && l >= 16u) tail = lz_ring32(win, p + l - 3u);
-                    // deep walks: a good match halves the remaining budget (goodlen = 259 for the short budgets: never)
-                    if (deep) chain >>= (uint32_t)(better & (l >= goodlen));
-                    cand -= dn;
-                    chain -= 1u;   // may wrap below zero after the halving: compared as signed
-                    // (bitwise, not short-circuit: four compares and three ORs; as `||` the compiler built a branch per term)
-                    // (p - cand > lim: the raw link led out of the window, in front of the shard, or nowhere)
-                    const bool stop = (better & (l >= stoplen)) | (dn == 0u) | ((int32_t)chain <= 0) | (p - cand > lim);
-                    if (stop) break;
                 }
+                l = l > maxlen ? maxlen : l;
+                const bool better = l > blen;
+                blen = better ? l : blen;
+                bdist = better ? p - cand : bdist;
+                if (better && l >= 16u) tail = lz_ring32(win, p + l - 3u);
+                // deep walks: a good match halves the remaining budget (goodlen = 259 for the short budgets: never)
+                if (deep) chain >>= (uint32_t)(better & (l >= goodlen));
+                cand -= dn;
+                chain -= 1u;   // may wrap below zero after the halving: compared as signed
+                // (bitwise, not short-circuit: four compares and three ORs; as `||` the compiler built a branch per term)
+                // (p - cand > lim: the raw link led out of the window, in front of the shard, or nowhere)
+                const bool stop = (better & (l >= stoplen)) | (dn == 0u) | ((int32_t)chain <= 0) | (p - cand > lim);
+                walk = !stop;
             }
-            // (whether a short match far back is worth its codes is the encoder's call: it knows the prices, enc_far_limits)
+#ifdef ZMI_EMU
+            {
+                const uint32_t mx = zmi_wave_max(emu_xr);
+                if (lane == 0) emu_lz_count(3, mx);
+            }
+#endif
+        }
+        // (whether a short match far back is worth its codes is the encoder's call: it knows the prices, enc_far_limits)
+        if (p < n) {
+            uint32_t res = mylo & 0xFFu;
             if (blen >= 4u) res |= (blen << 8) | ((bdist - 1u) << 17);
             mout[p] = res;
         }

@@ -88,6 +88,18 @@ __global__ void __launch_bounds__(PK_T) zmi_copy_ranges_kernel(const uint8_t* __
   }
 }
 
+// out[i] = min(len[i], cap[i]): what a stream's output region really holds (inflate counts past a full region)
+__global__ void __launch_bounds__(256) zmi_clamp_lens_kernel(const uint32_t* __restrict__ len, const uint32_t* __restrict__ cap, uint32_t n,
+                                                             uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) out[i] = len[i] < cap[i] ? len[i] : cap[i];
+}
+extern "C" int zmi_launch_clamp_lens(const uint32_t* d_len, const uint32_t* d_cap, uint32_t n, uint32_t* d_out, hipStream_t stream) {
+    if (n == 0) return 0;
+    ZMI_LAUNCH(zmi_clamp_lens_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, d_len, d_cap, n, d_out);
+    return 0;
+}
+
 extern "C" int zmi_launch_scan_sizes(const uint32_t* d_len, uint32_t n, uint64_t* d_off, hipStream_t stream) {
     ZMI_LAUNCH(zmi_scan_sizes_kernel, dim3(1), dim3(1024), 0, stream, d_len, n, d_off);
     return 0;

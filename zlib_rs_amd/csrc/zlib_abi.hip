@@ -18,6 +18,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <new>
+#include <stdio.h>
 #include <stdlib.h>
 #include <limits.h>
 #include <string.h>
@@ -159,6 +160,18 @@ struct AbiLease {
         g_slots[slot].busy = true;
         ctx = g_slots[slot].ctx;
         stream = g_slots[slot].stream;
+        // More than four calls in flight while the HIP runtime runs with its default of 4 hardware queues: the streams of
+        // the extra calls share queues and the scaling stops (measured: 3.3x at 4 and at 8 threads; with 16 queues 6.4x at 8
+        // and 11.2x at 16).  Said once, and only to a caller that asked for diagnostics (ZMI_VERBOSE).
+        int busy = 0;
+        for (int i = 0; i < kAbiSlots; ++i) busy += g_slots[i].busy ? 1 : 0;
+        static bool hinted = false;
+        if (busy > 4 && !hinted) {
+            hinted = true;
+            if (getenv("ZMI_VERBOSE") && !getenv("GPU_MAX_HW_QUEUES"))
+                fprintf(stderr, "[libz_mi355] %d zlib streams are in flight but the HIP runtime multiplexes them onto 4 hardware queues: export "
+                                "GPU_MAX_HW_QUEUES=16 (or ZMI_HW_QUEUES=16) before the process starts for multi-threaded scaling\n", busy);
+        }
     }
     ~AbiLease() {
         if (slot < 0) return;
@@ -492,6 +505,7 @@ struct InflateState {
     uint8_t* back_window = nullptr;   // inflateBack: the caller's window
     // inflate(Z_BLOCK) / inflate(Z_TREES) (inflate.rs:1276-1284,1323,1369,1772,1856-1873): the device decode stops at the
     // next block boundary / behind the next block header; the call that reaches the stop reports it in data_type
+    uint32_t codes_used = 0;       // inflateCodesUsed: table entries of the most recent dynamic block the device decoded (0: none yet)
     int stop_state = 0;            // 0 none, 1 at a block boundary (the reference's Mode::Type), 2 behind a block header (Len_ / CopyBlock)
     bool stop_reported = false;    // a call has returned with the stop in data_type: the next one moves on
     bool hdr_seen = false;         // Z_TREES: the header of the block at the checkpoint has been reported
@@ -756,6 +770,7 @@ int inflate_attempt(InflateState* s, int stop_mode = 0) {   // stop_mode 1: deco
         std::vector<uint32_t> seg;
         if (stop_mode == 0 && take <= ((size_t)16 << 20)) find_flush_points(s->in.data(), take, seg);
         int rc;
+        (void)zmi_ctx_reset_codes_used(c);   // (contexts are leased per call: the figure belongs to this stream's attempt)
         if (!seg.empty()) {
             uint32_t used_seg = 0;
             rc = zmi_inflate_split(c, s->in.data(), (uint32_t)take, in_bit, s->hist.data(), (uint32_t)s->hist.size(), s->tmp.data(), (uint32_t)cap,
@@ -768,6 +783,10 @@ int inflate_attempt(InflateState* s, int stop_mode = 0) {   // stop_mode 1: deco
                                     (uint32_t)cap, &olen, &st, &det, &used, res);
         if (rc != 0) return Z_MEM_ERROR;
         if (st == Z_MEM_ERROR) return Z_MEM_ERROR;
+        {
+            uint32_t cu = 0;
+            if (zmi_ctx_last_codes_used(c, &cu) == 0 && cu != 0u) s->codes_used = cu;
+        }
         const size_t eff = olen < cap ? olen : cap;
         if (st == Z_BUF_ERROR && det == 3 && (res[3] & 2u)) {   // behind the block header: nothing decoded, the checkpoint stays
             s->hdr_seen = true;
@@ -1576,7 +1595,10 @@ int inflateValidate(z_streamp strm, int check) {   // inflate.rs:2595
     return Z_OK;
 }
 int inflateUndermine(z_streamp strm, int) { return istate(strm) ? Z_OK : Z_STREAM_ERROR; }   // inflate.rs:2588
-unsigned long inflateCodesUsed(z_streamp strm) { return istate(strm) ? 0ul : (unsigned long)-1; }   // decode tables live on the device
+// libz-rs-sys/src/lib.rs:1252 -> zlib-rs/src/inflate.rs:2372 (state.next: entries of the code tables in use).  The tables live on
+// the device (roots 9 / 8, exact-fit sub-tables -- other sizes than the reference's 10 / 9): the figure is theirs, for the most
+// recent dynamic block decoded; 0 before the first one and after a reset, (unsigned long)-1 for an invalid stream as in the reference.
+unsigned long inflateCodesUsed(z_streamp strm) { return istate(strm) ? (unsigned long)istate(strm)->codes_used : (unsigned long)-1; }
 
 // ---- inflateBack: raw deflate, input pulled and output pushed through callbacks (inflate/infback.rs:17-722)
 int inflateBackInit_(z_streamp strm, int windowBits, unsigned char* window, const char* version, int stream_size) {

@@ -87,6 +87,8 @@ struct zmi_ctx {
     zmi_buf hb_pin_in[ZMI_HB_SLOTS], hb_pin_out[ZMI_HB_SLOTS], hb_pin_meta[ZMI_HB_SLOTS];   // pinned host staging of the two slots
     hipStream_t hs_in = nullptr, hs_k = nullptr, hs_out = nullptr, hs_slab = nullptr;
     bool hb_live = false;
+    uint64_t pinned_limit = 8ull << 30;   // host-buffer pipelines: pinned staging this context may hold (chunk sizes follow it; env ZMI_PINNED_MB)
+    uint32_t last_codes_used = 0;    // zmi_inflate_resume: table entries of the most recent dynamic block of the last call (inflateCodesUsed)
     uint64_t inflate_out_limit = 0;  // output bytes one inflate batch may cover; 0 = scratch_limit
     hipStream_t host_stream = nullptr;  // zmi_ctx_set_stream: where the host-buffer wrappers copy and launch
     hipStream_t side = nullptr;         // deflate: the wrapper checksums run here, beside the match search (zmi_deflate_impl)
@@ -105,6 +107,8 @@ static int zmi_reserve(zmi_buf& b, size_t bytes) {
 
 extern "C" const char* zmi_version(void) { return "zmi355 0.1.0 (gfx950; zlib ABI 1.3.0-zlib-rs-0.6.7 compatible)"; }
 extern "C" const char* zmi_last_error(void) { return g_err.c_str(); }
+// the other translation units of this library (exchange.hip) report through the same thread-local message
+extern "C" void zmi_set_last_error(const char* what) { g_err = what ? what : ""; }
 
 extern "C" int zmi_ctx_create(zmi_ctx** out, int device) {
     if (!out) return zmi_fail(ZMI_E_ARG, "zmi_ctx_create: null out pointer");
@@ -116,6 +120,8 @@ extern "C" int zmi_ctx_create(zmi_ctx** out, int device) {
     c->device = device;
     const char* env = getenv("ZMI_SCRATCH_MB");
     if (env && atoll(env) > 0) c->scratch_limit = (uint64_t)atoll(env) << 20;
+    env = getenv("ZMI_PINNED_MB");
+    if (env && atoll(env) >= 64) c->pinned_limit = (uint64_t)atoll(env) << 20;
     *out = c;
     return ZMI_E_OK;
 }
@@ -180,6 +186,19 @@ extern "C" int zmi_ctx_device(const zmi_ctx* c) { return c ? c->device : -1; }
 extern "C" int zmi_ctx_set_stream(zmi_ctx* c, void* stream) {
     if (!c) return zmi_fail(ZMI_E_ARG, "null context");
     c->host_stream = (hipStream_t)stream;
+    return ZMI_E_OK;
+}
+
+// decode-table entries (literal / length + distance; roots 9 / 8, exact-fit sub-tables) the device built for the most recent
+// dynamic block met by zmi_inflate_resume calls on this context; 0 before the first one.  What inflateCodesUsed reports.
+extern "C" int zmi_ctx_last_codes_used(zmi_ctx* c, uint32_t* entries) {
+    if (!c || !entries) return zmi_fail(ZMI_E_ARG, "null argument");
+    *entries = c->last_codes_used;
+    return ZMI_E_OK;
+}
+extern "C" int zmi_ctx_reset_codes_used(zmi_ctx* c) {
+    if (!c) return zmi_fail(ZMI_E_ARG, "null context");
+    c->last_codes_used = 0;
     return ZMI_E_OK;
 }
 
@@ -458,6 +477,10 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     if (const char* pv = zmi_tune("ZMI_PRODUCERS")) lp.producers = (uint32_t)atoi(pv);
     lp.dbg = 0u;
     if (const char* dv = zmi_tune("ZMI_LZ_DBG")) lp.dbg = (uint32_t)atoi(dv);
+    lp.min_live = 0u; lp.live_from = 1u; lp.barren_chain = 1u;
+    if (const char* bv = zmi_tune("ZMI_BARREN_CHAIN")) lp.barren_chain = (uint32_t)atoi(bv);
+    if (const char* mv = zmi_tune("ZMI_MIN_LIVE")) lp.min_live = (uint32_t)atoi(mv);
+    if (const char* mv = zmi_tune("ZMI_LIVE_FROM")) lp.live_from = (uint32_t)atoi(mv);
     // short far matches are judged by the encoder, block by block, from the codes it just used (enc_far_limits); the
     // search reports every match of 4+ bytes
     lp.far4 = 32768u;
@@ -575,7 +598,9 @@ static int zmi_inflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     // the chip empty that way (a 1 MiB stream alone: 8 ms): their back-references are resolved by pointer jumping over all
     // output bytes at once (resolve_jump.hip), which costs 4 B of scratch per byte of capacity.
     // (below 256 KiB of capacity the serial pass takes less than the jump pass's two dozen launches)
-    bool jump = n <= 16u && out_limit <= (1ull << 30) && out_limit >= (256ull << 10);
+    // (the pass sweeps out_limit indices whatever the streams' real capacities are -- they are device data: a limit far above what n
+    // streams plausibly hold, 64 MiB each, says the caller did not size it for this call, and the serial pass is the safer choice)
+    bool jump = n <= 16u && out_limit <= (1ull << 30) && out_limit >= (256ull << 10) && out_limit <= (uint64_t)n * (64ull << 20) + (1ull << 20);
     if (!decode_only) {
     if (const char* jv = zmi_tune("ZMI_INF_JUMP")) jump = atoi(jv) != 0 && out_limit <= (1ull << 30);
     if (jump && zmi_reserve(c->inf_ptr, (size_t)bm_words * 256u + 512u) != 0) jump = false;   // (no room: the serial pass needs none)
@@ -730,6 +755,13 @@ extern "C" int zmi_launch_resolve_jump_segments(uint8_t* d_fin, const uint64_t* 
                                                 const uint64_t* d_bm_off, int32_t* d_ptr, uint64_t total, uint32_t hist_len,
                                                 uint32_t rounds, uint32_t* d_flags, uint32_t* d_err, const uint64_t* d_one_off,
                                                 const uint32_t* d_one_len, hipStream_t stream);
+// (this function copies asynchronously from vectors and locals of its own frame: an error return must not leave such a copy in
+// flight -- the stream is drained first)
+#define ZMI_HIPS(call)                                                                  \
+    do {                                                                                \
+        hipError_t e_ = (call);                                                         \
+        if (e_ != hipSuccess) { (void)hipStreamSynchronize(c->host_stream); return zmi_fail(ZMI_E_HIP, #call, e_); } \
+    } while (0)
 extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist,
                                  uint32_t hist_len, uint8_t* out, uint32_t out_cap, const uint32_t* seg_start, uint32_t nseg,
                                  uint32_t* out_len, int32_t* status, int32_t* detail, uint32_t* in_used, uint32_t* resume,
@@ -781,9 +813,9 @@ extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len,
     memcpy(hm.data() + o_ioff, ioff.data(), 8 * n); memcpy(hm.data() + o_ooff, ooff.data(), 8 * n);
     memcpy(hm.data() + o_ilen, ilen.data(), 4 * n); memcpy(hm.data() + o_ocap, ocap.data(), 4 * n);
     memcpy(hm.data() + o_hist, shist.data(), 4 * n); memcpy(hm.data() + o_bit, sbit.data(), 4 * n);
-    ZMI_HIP(hipMemcpyAsync(c->st_in.p, in, in_len, hipMemcpyHostToDevice, hs));
-    if (hist_len) ZMI_HIP(hipMemcpyAsync((uint8_t*)c->st_out.p + base - hist_len, hist, hist_len, hipMemcpyHostToDevice, hs));
-    ZMI_HIP(hipMemcpyAsync(d, hm.data(), meta_bytes, hipMemcpyHostToDevice, hs));
+    ZMI_HIPS(hipMemcpyAsync(c->st_in.p, in, in_len, hipMemcpyHostToDevice, hs));
+    if (hist_len) ZMI_HIPS(hipMemcpyAsync((uint8_t*)c->st_out.p + base - hist_len, hist, hist_len, hipMemcpyHostToDevice, hs));
+    ZMI_HIPS(hipMemcpyAsync(d, hm.data(), meta_bytes, hipMemcpyHostToDevice, hs));
     const uint64_t saved_limit = c->inflate_out_limit;
     c->inflate_out_limit = scratch + (1ull << 16);
     struct restore { zmi_ctx* c; uint64_t v; ~restore() { c->inflate_out_limit = v; } } restore_limit{c, saved_limit};
@@ -791,9 +823,11 @@ extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len,
                           (const uint64_t*)(d + o_ooff), (const uint32_t*)(d + o_ocap), (const uint32_t*)(d + o_hist), (uint32_t*)(d + o_olen),
                           (int32_t*)(d + o_st), (uint32_t*)(d + o_used), (int32_t*)(d + o_det), (const uint32_t*)(d + o_bit), (uint32_t*)(d + o_res), hs, true);
     if (rc) { (void)hipStreamSynchronize(hs); return rc; }
-    std::vector<uint32_t> r(8 * n);   // olen | status | used | detail | resume[4n]
-    ZMI_HIP(hipMemcpyAsync(r.data(), d + o_olen, 32 * n, hipMemcpyDeviceToHost, hs));
-    ZMI_HIP(hipStreamSynchronize(hs));
+    std::vector<uint32_t> r(8 * n), codes(nseg, 0u);   // olen | status | used | detail | resume[4n]
+    ZMI_HIPS(hipMemcpyAsync(r.data(), d + o_olen, 32 * n, hipMemcpyDeviceToHost, hs));
+    // (zmi_inflate_impl's scratch: bm_off u64[nseg] | used[nseg] | check[nseg] -- every segment's tables' size, see zmi_inflate_resume)
+    ZMI_HIPS(hipMemcpyAsync(codes.data(), (const uint8_t*)c->inf_tmp.p + 12u * (size_t)nseg, 4u * (size_t)nseg, hipMemcpyDeviceToHost, hs));
+    ZMI_HIPS(hipStreamSynchronize(hs));
     const double sp_t1 = sp_trace ? sp_now() : 0.0;
     const uint32_t *olen = r.data(), *used = r.data() + 2 * n, *res = r.data() + 4 * n;
     const int32_t *st = (const int32_t*)(r.data() + n), *det = (const int32_t*)(r.data() + 3 * n);
@@ -819,14 +853,16 @@ extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len,
         return zmi_inflate_resume(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume);
     if (tail_ok) total += olen[tail] < ocap[tail] ? olen[tail] : ocap[tail];
     soff[take] = total;
+    for (uint32_t j = take; j-- > 0u;)   // inflateCodesUsed: the last dynamic block of the part decoded here (a serial tail below overrides it)
+        if (codes[j] != 0u) { c->last_codes_used = codes[j]; break; }
     if (total == 0u)
         return zmi_inflate_resume(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume);
     // stitch: outputs back to back behind the history, then all back-references at once
     rc = zmi_reserve(c->inf_ptr, (size_t)total * 4u + 512u);
     if (rc) return rc;
     struct { uint64_t off; uint32_t len, err; } one = {0ull, (uint32_t)total, 0u};
-    ZMI_HIP(hipMemcpyAsync(d + o_soff, soff.data(), 8 * (take + 1u), hipMemcpyHostToDevice, hs));
-    ZMI_HIP(hipMemcpyAsync(d + o_one, &one, sizeof(one), hipMemcpyHostToDevice, hs));
+    ZMI_HIPS(hipMemcpyAsync(d + o_soff, soff.data(), 8 * (take + 1u), hipMemcpyHostToDevice, hs));
+    ZMI_HIPS(hipMemcpyAsync(d + o_one, &one, sizeof(one), hipMemcpyHostToDevice, hs));
     uint8_t* d_fin = (uint8_t*)c->st_out.p + base;
     zmi_launch_copy_ranges((const uint8_t*)c->sp_out.p, (const uint64_t*)(d + o_ooff), 0, (const uint32_t*)(d + o_olen), take, d_fin,
                            (const uint64_t*)(d + o_soff), total, 0xFFFFFFFFu, hs);
@@ -839,10 +875,10 @@ extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len,
                                          (uint32_t*)(d + o_one + 12), (const uint64_t*)(d + o_one), (const uint32_t*)(d + o_one + 8), hs);
     }
     uint32_t err = 0;
-    ZMI_HIP(hipMemcpyAsync(&err, d + o_one + 12, 4, hipMemcpyDeviceToHost, hs));
-    ZMI_HIP(hipMemcpyAsync(out, d_fin, (size_t)total, hipMemcpyDeviceToHost, hs));
-    ZMI_HIP(hipStreamSynchronize(hs));
-    ZMI_HIP(hipGetLastError());
+    ZMI_HIPS(hipMemcpyAsync(&err, d + o_one + 12, 4, hipMemcpyDeviceToHost, hs));
+    ZMI_HIPS(hipMemcpyAsync(out, d_fin, (size_t)total, hipMemcpyDeviceToHost, hs));
+    ZMI_HIPS(hipStreamSynchronize(hs));
+    ZMI_HIPS(hipGetLastError());
     if (sp_trace) fprintf(stderr, "[zmi split] %u segments, %u B in, %llu B out: copy-in + decode %.2f ms, stitch + resolve + copy-out %.2f ms\n", nseg, in_len, (unsigned long long)total, sp_t1 - sp_t0, sp_now() - sp_t1);
     if (err)   // a distance reaches in front of the history that is really there: let the serial decode find and name it
         return zmi_inflate_resume(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume);
@@ -874,6 +910,7 @@ extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len,
     return ZMI_E_OK;
 }
 
+#undef ZMI_HIPS
 // ---- host buffers, pipelined ----
 // A caller that hands over host memory pays PCIe both ways (the reference's own caller loop:
 // test-libz-rs-sys/examples/blogpost-compress.rs:43-122 -- every real zlib-rs user lives on this path).  Pageable memory is
@@ -920,6 +957,46 @@ static void zmi_parallel_copy(const std::vector<zmi_copy_job>& jobs, unsigned T)
     work(0);
     for (std::thread& x : th) x.join();
 }
+// gives back the cached staging of the host-buffer pipelines (pinned host memory and the device slots); the streams and events stay
+static void zmi_hb_release(zmi_ctx* c) {
+    for (int k = 0; k < ZMI_HB_SLOTS; ++k) {
+        if (c->hb_pin_in[k].p) { (void)hipHostFree(c->hb_pin_in[k].p); c->hb_pin_in[k] = zmi_buf(); }
+        if (c->hb_pin_out[k].p) { (void)hipHostFree(c->hb_pin_out[k].p); c->hb_pin_out[k] = zmi_buf(); }
+        if (c->hb_pin_meta[k].p) { (void)hipHostFree(c->hb_pin_meta[k].p); c->hb_pin_meta[k] = zmi_buf(); }
+        if (c->hb_slab[k].p) { (void)hipFree(c->hb_slab[k].p); c->hb_slab[k] = zmi_buf(); }
+        zmi_ctx::hb_slot& sl = c->hb[k];
+        if (sl.in.p) { (void)hipFree(sl.in.p); sl.in = zmi_buf(); }
+        if (sl.out.p) { (void)hipFree(sl.out.p); sl.out = zmi_buf(); }
+        if (sl.meta.p) { (void)hipFree(sl.meta.p); sl.meta = zmi_buf(); }
+    }
+}
+static size_t zmi_hb_pinned_bytes(const zmi_ctx* c) {
+    size_t t = 0;
+    for (int k = 0; k < ZMI_HB_SLOTS; ++k) t += c->hb_pin_in[k].cap + c->hb_pin_out[k].cap + c->hb_pin_meta[k].cap;
+    return t;
+}
+// zmi_ctx_trim: a long-lived context that once ran a very large host-buffer batch keeps ~6 GiB of pinned host memory and as much
+// HBM for the next one; this hands them back (also done automatically when a call leaves more pinned than the context's limit)
+extern "C" int zmi_ctx_trim(zmi_ctx* c) {
+    if (!c) return zmi_fail(ZMI_E_ARG, "null context");
+    ZMI_ON_DEVICE(c);
+    zmi_hb_release(c);
+    return ZMI_E_OK;
+}
+extern "C" int zmi_ctx_set_pinned_limit(zmi_ctx* c, uint64_t bytes) {
+    if (!c) return zmi_fail(ZMI_E_ARG, "null context");
+    c->pinned_limit = bytes < (64ull << 20) ? (64ull << 20) : bytes;
+    return ZMI_E_OK;
+}
+// joins the follower thread of a host-buffer pipeline on every way out of its scope -- also when stage_in / the std::thread
+// constructor / a vector throws (std::terminate on a joinable thread, and an exception through a C entry point, otherwise)
+struct zmi_joiner {
+    std::thread& t;
+    std::atomic<int>& failed;
+    ~zmi_joiner() {
+        if (t.joinable()) { failed.store(ZMI_E_NOMEM, std::memory_order_release); t.join(); }
+    }
+};
 static int zmi_reserve_pinned(zmi_buf& b, size_t bytes) {
     if (bytes <= b.cap) return 0;
     if (b.p) { (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
@@ -930,9 +1007,23 @@ static int zmi_reserve_pinned(zmi_buf& b, size_t bytes) {
     return 0;
 }
 
+static int zmi_deflate_batch_body(zmi_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
+                                  int level, int strategy, int wrap, uint8_t* out, uint64_t out_stride, uint32_t* out_len,
+                                  int32_t* status);
+// (a C entry point: nothing may unwind through it -- the reference builds with panic = abort for the same reason,
+// libz-rs-sys-cdylib/src/lib.rs:5-6)
 extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
                                  int level, int strategy, int wrap, uint8_t* out, uint64_t out_stride, uint32_t* out_len,
                                  int32_t* status) {
+    try {
+        return zmi_deflate_batch_body(c, in, in_off, in_len, n, level, strategy, wrap, out, out_stride, out_len, status);
+    } catch (...) {
+        return zmi_fail(ZMI_E_NOMEM, "zmi_deflate_batch: out of host memory (or a thread could not be started)");
+    }
+}
+static int zmi_deflate_batch_body(zmi_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
+                                  int level, int strategy, int wrap, uint8_t* out, uint64_t out_stride, uint32_t* out_len,
+                                  int32_t* status) {
     if (!c || (!in && n) || !in_off || !in_len || !out || !out_len || !status) return zmi_fail(ZMI_E_ARG, "null argument");
     if (n == 0) return ZMI_E_OK;
     uint32_t max_len = 0;
@@ -949,6 +1040,8 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     for (uint32_t i = 0; i < n; ++i) total_in += in_len[i];
     uint64_t budget = total_in / 8u;
     budget = budget < (512ull << 20) ? (512ull << 20) : (budget > (1024ull << 20) ? (1024ull << 20) : budget);
+    // three slots of pinned staging, each a chunk of input and its worst-case slab (~1.13x): 6.4 chunks in all
+    if (budget > c->pinned_limit / 7u) budget = c->pinned_limit / 7u;
     uint32_t min_count = 384u;
     if (const char* e = zmi_tune("ZMI_HOST_CHUNK")) { if (atoll(e) > 0) { budget = (uint64_t)atoll(e); min_count = 1u; } }
     struct chunk { uint32_t first, count; uint64_t bytes; std::vector<uint64_t> doff; };
@@ -998,7 +1091,12 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         if (!rc) rc = zmi_reserve_pinned(c->hb_pin_in[k], (size_t)max_bytes + 64u);
         if (!rc) rc = zmi_reserve_pinned(c->hb_pin_out[k], (size_t)max_slab + 64u);
         if (!rc) rc = zmi_reserve_pinned(c->hb_pin_meta[k], meta_bytes);
-        if (rc) return rc;
+        if (rc) {
+            // no room for the staging (memlock / container limit, HBM): the plain copy-in / kernels / copy-out sequence needs no
+            // pinned memory and a batch that worked before the pipeline existed keeps working
+            zmi_hb_release(c);
+            return zmi_deflate_batch_simple(c, in, in_off, in_len, n, level, strategy, wrap, out, out_stride, out_len, status);
+        }
     }
     const unsigned T = zmi_host_threads();
     const size_t K = chunks.size();
@@ -1136,7 +1234,9 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         }
     };
     (void)T_in; (void)T_out;
-    std::thread follower(consumer);
+    std::thread follower;
+    zmi_joiner join_guard{follower, failed};
+    follower = std::thread(consumer);
     int rc = 0;
     for (size_t k = 0; k < K && !rc; ++k) {
         while (finished.load(std::memory_order_acquire) + ZMI_HB_SLOTS <= (int)k && !failed.load(std::memory_order_acquire)) std::this_thread::yield();   // slot free
@@ -1166,6 +1266,7 @@ extern "C" int zmi_deflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         for (size_t k = 0; k < K; ++k)
             fprintf(stderr, "[zmi hb]   chunk %zu (%u shards): stage_in %.1f..%.1f, sizes known %.1f, slab on host %.1f, scattered %.1f\n", k, chunks[k].count,
                     tl[k * 6u], tl[k * 6u + 1u], tl[k * 6u + 2u], tl[k * 6u + 3u], tl[k * 6u + 4u]);
+    if (zmi_hb_pinned_bytes(c) > c->pinned_limit) zmi_hb_release(c);
     if (rc) return rc;
     ZMI_HIP(hipGetLastError());
     return ZMI_E_OK;
@@ -1230,9 +1331,21 @@ static int zmi_inflate_batch_simple(zmi_ctx* c, const uint8_t* in, const uint64_
 // (PCIe writes from the shader run beside the copy engine's H2D traffic; two copy-engine directions were served one after
 // the other, see zmi_deflate_batch), and a second thread scatters every finished chunk into the caller's regions --
 // min(out_len, out_cap) bytes of every stream.
+static int zmi_inflate_batch_body(zmi_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
+                                  int wrap, uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len,
+                                  int32_t* status);
 extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
                                  int wrap, uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len,
                                  int32_t* status) {
+    try {
+        return zmi_inflate_batch_body(c, in, in_off, in_len, n, wrap, out, out_off, out_cap, out_len, status);
+    } catch (...) {
+        return zmi_fail(ZMI_E_NOMEM, "zmi_inflate_batch: out of host memory (or a thread could not be started)");
+    }
+}
+static int zmi_inflate_batch_body(zmi_ctx* c, const uint8_t* in, const uint64_t* in_off, const uint32_t* in_len, uint32_t n,
+                                  int wrap, uint8_t* out, const uint64_t* out_off, const uint32_t* out_cap, uint32_t* out_len,
+                                  int32_t* status) {
     if (!c || (!in && n) || !in_off || !in_len || !out_off || !out_cap || !out_len || !status)
         return zmi_fail(ZMI_E_ARG, "null argument");
     if (n == 0) return ZMI_E_OK;
@@ -1240,12 +1353,13 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     // GiB/s, above what PCIe carries), and a chunk's output has to fit the pinned staging: 2 GiB of capacity per chunk.
     // ZMI_HOST_CHUNK (bytes) overrides both bounds (tests).
     uint64_t budget = 2ull << 30;
+    if (budget > c->pinned_limit / 4u) budget = c->pinned_limit / 4u;   // three slots of output staging + their (smaller) input
     uint32_t min_count = 2048u;
     if (const char* e = zmi_tune("ZMI_HOST_CHUNK")) { if (atoll(e) > 0) { budget = (uint64_t)atoll(e); min_count = 1u; } }
-    struct chunk { uint32_t first, count; uint64_t in_bytes, out_bytes; std::vector<uint64_t> ioff, ooff; };
+    struct chunk { uint32_t first, count; uint64_t in_bytes, out_bytes; std::vector<uint64_t> ioff, ooff; uint32_t max_cap; };
     std::vector<chunk> chunks;
     for (uint32_t i = 0; i < n;) {
-        chunk ck{i, 0, 0, 0, {}, {}};
+        chunk ck{i, 0, 0, 0, {}, {}, 0u};
         while (i < n) {
             const uint64_t ai = ((uint64_t)in_len[i] + 15u) & ~15ull, ao = ((uint64_t)out_cap[i] + 15u) & ~15ull;
             if (ck.count != 0u && (ck.out_bytes + ao > 0xFFFFF000ull || ck.in_bytes + ai > 0xFFFFF000ull)) break;   // (one copy range, u32 length)
@@ -1254,6 +1368,7 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
             ck.ooff.push_back(ck.out_bytes);
             ck.in_bytes += ai;
             ck.out_bytes += ao;
+            if (out_cap[i] > ck.max_cap) ck.max_cap = out_cap[i];
             ++ck.count;
             ++i;
         }
@@ -1275,8 +1390,8 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         if (ck.count > max_count) max_count = ck.count;
     }
     // meta (device and pinned twin): in_off u64 | out_off u64 | in_len | out_cap | out_len | status (u32 each) per stream, then the
-    // copy-out job: one range {offset 0 (u64), length (u32)}
-    const size_t meta_bytes = (size_t)max_count * 32u + 32u;
+    // clamped length min(out_len, out_cap) (what travels back: the decoded bytes, not the capacity)
+    const size_t meta_bytes = (size_t)max_count * 36u + 32u;
     for (int k = 0; k < ZMI_HB_SLOTS; ++k) {
         zmi_ctx::hb_slot& sl = c->hb[k];
         rc = zmi_reserve(sl.in, (size_t)max_in + 64u);
@@ -1285,7 +1400,10 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         if (!rc) rc = zmi_reserve_pinned(c->hb_pin_in[k], (size_t)max_in + 64u);
         if (!rc) rc = zmi_reserve_pinned(c->hb_pin_out[k], (size_t)max_out + 64u);
         if (!rc) rc = zmi_reserve_pinned(c->hb_pin_meta[k], meta_bytes);
-        if (rc) return rc;
+        if (rc) {   // as in zmi_deflate_batch: without the staging the plain path still works
+            zmi_hb_release(c);
+            return zmi_inflate_batch_simple(c, in, in_off, in_len, n, wrap, out, out_off, out_cap, out_len, status);
+        }
     }
     const uint64_t saved_limit = c->inflate_out_limit;
     c->inflate_out_limit = max_out + (1ull << 20);   // bitmap scratch for the largest chunk, once
@@ -1296,8 +1414,7 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     auto m_ocap = [&](void* b) { return (uint32_t*)((uint8_t*)b + (size_t)max_count * 20u); };
     auto m_olen = [&](void* b) { return (uint32_t*)((uint8_t*)b + (size_t)max_count * 24u); };
     auto m_st = [&](void* b) { return (int32_t*)((uint8_t*)b + (size_t)max_count * 28u); };
-    auto m_job_off = [&](void* b) { return (uint64_t*)((uint8_t*)b + (size_t)max_count * 32u); };
-    auto m_job_len = [&](void* b) { return (uint32_t*)((uint8_t*)b + (size_t)max_count * 32u + 8u); };
+    auto m_clen = [&](void* b) { return (uint32_t*)((uint8_t*)b + (size_t)max_count * 32u); };
     const unsigned T = zmi_host_threads();
     const size_t K = chunks.size();
     std::vector<hipEvent_t> out_done(ZMI_HB_SLOTS);
@@ -1319,8 +1436,6 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         memcpy(m_ooff(pm), ck.ooff.data(), (size_t)ck.count * 8u);
         memcpy(m_ilen(pm), in_len + ck.first, (size_t)ck.count * 4u);
         memcpy(m_ocap(pm), out_cap + ck.first, (size_t)ck.count * 4u);
-        *m_job_off(pm) = 0ull;
-        *m_job_len(pm) = (uint32_t)ck.out_bytes;
         return 0;
     };
     auto issue_dev = [&](size_t k) -> int {
@@ -1334,7 +1449,6 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         ZMI_HIP(hipMemcpyAsync(sl.in.p, c->hb_pin_in[s2].p, (size_t)ck.in_bytes, hipMemcpyHostToDevice, c->hs_in));
         // (two pieces: the results in the middle of the pinned twin belong to the follower thread until it has read them)
         ZMI_HIP(hipMemcpyAsync(sl.meta.p, c->hb_pin_meta[s2].p, (size_t)max_count * 24u, hipMemcpyHostToDevice, c->hs_in));
-        ZMI_HIP(hipMemcpyAsync(m_job_off(sl.meta.p), m_job_off(c->hb_pin_meta[s2].p), 16u, hipMemcpyHostToDevice, c->hs_in));
         ZMI_HIP(hipEventRecord(sl.in_done, c->hs_in));
         ZMI_HIP(hipStreamWaitEvent(c->hs_k, sl.in_done, 0));
         if (k >= ZMI_HB_SLOTS) ZMI_HIP(hipStreamWaitEvent(c->hs_k, out_done[s2], 0));   // the slot's output has left the device
@@ -1345,8 +1459,10 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
         ZMI_HIP(hipStreamWaitEvent(c->hs_slab, sl.k_done, 0));
         {
             zmi_scope_timer tm(c, ZMI_K_PACK, c->hs_slab);
-            zmi_launch_copy_ranges_few((const uint8_t*)sl.out.p, m_job_off(sl.meta.p), 0, m_job_len(sl.meta.p), 1u, (uint8_t*)c->hb_pin_out[s2].p,
-                                       m_job_off(sl.meta.p), c->hb_pin_out[s2].cap, (uint32_t)ck.out_bytes, pack_groups, c->hs_slab);
+            // every stream's decoded bytes (min(out_len, out_cap): a stream given four times the room it needs sends a quarter)
+            zmi_launch_clamp_lens(m_olen(sl.meta.p), m_ocap(sl.meta.p), ck.count, m_clen(sl.meta.p), c->hs_slab);
+            zmi_launch_copy_ranges_few((const uint8_t*)sl.out.p, m_ooff(sl.meta.p), 0, m_clen(sl.meta.p), ck.count, (uint8_t*)c->hb_pin_out[s2].p,
+                                       m_ooff(sl.meta.p), c->hb_pin_out[s2].cap, ck.max_cap, pack_groups, c->hs_slab);
         }
         ZMI_HIP(hipMemcpyAsync(m_olen(c->hb_pin_meta[s2].p), m_olen(sl.meta.p), (size_t)max_count * 8u, hipMemcpyDeviceToHost, c->hs_slab));
         ZMI_HIP(hipEventRecord(out_done[s2], c->hs_slab));
@@ -1384,7 +1500,9 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
             finished.store((int)k + 1, std::memory_order_release);
         }
     };
-    std::thread follower(consumer);
+    std::thread follower;
+    zmi_joiner join_guard{follower, failed};
+    follower = std::thread(consumer);
     rc = 0;
     for (size_t k = 0; k < K && !rc; ++k) {
         while (finished.load(std::memory_order_acquire) + ZMI_HB_SLOTS <= (int)k && !failed.load(std::memory_order_acquire)) std::this_thread::yield();   // slot free
@@ -1399,6 +1517,7 @@ extern "C" int zmi_inflate_batch(zmi_ctx* c, const uint8_t* in, const uint64_t* 
     (void)hipStreamSynchronize(c->hs_in);
     (void)hipStreamSynchronize(c->hs_k);
     (void)hipStreamSynchronize(c->hs_slab);
+    if (zmi_hb_pinned_bytes(c) > c->pinned_limit) zmi_hb_release(c);
     if (rc) return rc;
     ZMI_HIP(hipGetLastError());
     return ZMI_E_OK;
@@ -1434,9 +1553,12 @@ extern "C" int zmi_inflate_resume(zmi_ctx* c, const uint8_t* in, uint32_t in_len
                                 (const uint64_t*)(d + 8), (const uint32_t*)(d + 20), (const uint32_t*)(d + 24), (uint32_t*)(d + 32),
                                 (int32_t*)(d + 36), (uint32_t*)(d + 40), (int32_t*)(d + 44), (uint32_t*)(d + 48), hs);
     if (rc) { (void)hipStreamSynchronize(hs); return rc; }
-    uint32_t r[8];
+    uint32_t r[8], codes = 0;
     ZMI_HIP(hipMemcpyAsync(r, d + 32, sizeof(r), hipMemcpyDeviceToHost, hs));
+    // (zmi_inflate_impl's scratch for one stream: bm_off u64 | used | check -- a resumable decode leaves its tables' size in `check`)
+    ZMI_HIP(hipMemcpyAsync(&codes, (const uint8_t*)c->inf_tmp.p + 12, 4, hipMemcpyDeviceToHost, hs));
     ZMI_HIP(hipStreamSynchronize(hs));   // this stream only: other contexts keep running
+    if (codes != 0u) c->last_codes_used = codes;   // (a call that met no dynamic block header keeps the earlier figure)
     *out_len = r[0];
     *status = (int32_t)r[1];
     *in_used = r[2];

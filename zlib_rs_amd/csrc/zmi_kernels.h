@@ -22,6 +22,9 @@ struct zmi_lz_params {
     uint32_t carry;      // 1: the shards are consecutive segments of one stream; a segment may match into the up to 27 KiB
                          // in front of it (window carry-over, what a preset dictionary is in deflate.rs:499-564)
     uint32_t dict_len;   // carry only: bytes in front of shard 0 that are history too (preset dictionary / earlier input)
+    uint32_t min_live;   // a claim takes another chain step only while at least this many of its 64 positions still walk (0: off)
+    uint32_t live_from;  // ... from this chain step on (1 = the rule already applies behind the first candidate)
+    uint32_t barren_chain; // chain links walked in a claim whose 64 probes all missed (incompressible stretch): 1 until round 4
     uint32_t far4, far5; // a 4- (5-) byte match further back than this costs more bits than its literals: dropped
                          // (classic zlib's TOO_FAR idea; the reference itself only drops matches <= 5 under
                          // Z_FILTERED, zlib-rs/src/deflate/algorithm/slow.rs:69-74)
@@ -61,6 +64,7 @@ int zmi_launch_scan_sizes(const uint32_t* d_len, uint32_t n, uint64_t* d_off, hi
 int zmi_launch_copy_ranges(const uint8_t* d_src, const uint64_t* d_src_off, uint64_t src_stride, const uint32_t* d_len,
                            uint32_t n, uint8_t* d_dst, const uint64_t* d_dst_off, uint64_t dst_cap, uint32_t max_len,
                            hipStream_t stream);
+int zmi_launch_clamp_lens(const uint32_t* d_len, const uint32_t* d_cap, uint32_t n, uint32_t* d_out, hipStream_t stream);
 int zmi_launch_copy_ranges_few(const uint8_t* d_src, const uint64_t* d_src_off, uint64_t src_stride, const uint32_t* d_len,
                                uint32_t n, uint8_t* d_dst, const uint64_t* d_dst_off, uint64_t dst_cap, uint32_t max_len,
                                uint32_t groups, hipStream_t stream);

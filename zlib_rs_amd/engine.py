@@ -82,6 +82,54 @@ class Engine:
                                               dst_off.data_ptr(), int(dst.numel()), _stream_ptr()), "zmi_copy_ranges_dev")
         return dst
 
+    # ---- the stitch across GPUs (csrc/exchange.hip: RCCL behind the C ABI) ----
+    def comm_unique_id(self):
+        """128 bytes made by one rank and carried to the others by whatever the host has (here: torch's process group)"""
+        import ctypes as C
+        buf = C.create_string_buffer(128)
+        _lib.check(self.L.zmi_comm_unique_id(buf), "zmi_comm_unique_id")
+        return buf.raw
+
+    def comm_create(self, world, rank, uid):
+        import ctypes as C
+        comm = C.c_void_p()
+        _lib.check(self.L.zmi_comm_create(C.byref(comm), self._ctx, int(world), int(rank), C.create_string_buffer(bytes(uid), 128)),
+                   "zmi_comm_create")
+        return comm
+
+    def comm_destroy(self, comm, abort=False):
+        (self.L.zmi_comm_abort if abort else self.L.zmi_comm_destroy)(comm)
+
+    def exchange_sizes(self, comm, sizes, world):
+        """all-gather of the int32 size tables -> [world, n_local] on every rank"""
+        table = torch.empty((world, int(sizes.numel())), dtype=torch.int32, device=self.device)
+        _lib.check(self.L.zmi_exchange_sizes(comm, sizes.data_ptr(), int(sizes.numel()), table.data_ptr(), _stream_ptr()),
+                   "zmi_exchange_sizes")
+        return table
+
+    def stitch_plan(self, table):
+        """table [world, n_local] -> (goff [world, n_local], soff [world, n_local + 1], totals: list of world + 1 ints;
+        the last one is the size of the stitched output).  Waits for the stream (the totals are host data)."""
+        import ctypes as C
+        world, n_local = int(table.shape[0]), int(table.shape[1])
+        goff = torch.empty((world, n_local), dtype=torch.int64, device=self.device)
+        soff = torch.empty((world, n_local + 1), dtype=torch.int64, device=self.device)
+        d_tot = torch.empty(world + 1, dtype=torch.int64, device=self.device)
+        host = (C.c_uint64 * (world + 1))()
+        _lib.check(self.L.zmi_stitch_plan_dev(self._ctx, table.data_ptr(), world, n_local, goff.data_ptr(), soff.data_ptr(),
+                                              d_tot.data_ptr(), host, _stream_ptr()), "zmi_stitch_plan_dev")
+        return goff, soff, [int(x) for x in host]
+
+    def exchange_round(self, comm, slab, totals, lo, chunk_bytes, stage, root=-1):
+        """one bounded round of the slab exchange: stage[p] (a uint8 tensor of chunk_bytes, None for this rank / peers not
+        wanted) receives peer p's slab bytes [lo, lo + chunk_bytes)"""
+        import ctypes as C
+        world = len(stage)
+        tb = (C.c_uint64 * world)(*[int(t) for t in totals[:world]])
+        ptrs = (C.c_void_p * world)(*[None if t is None else t.data_ptr() for t in stage])
+        _lib.check(self.L.zmi_exchange_slabs_round(comm, slab.data_ptr(), tb, int(lo), int(chunk_bytes), ptrs, int(root), _stream_ptr()),
+                   "zmi_exchange_slabs_round")
+
     # ---- deflate ----
     def deflate_batch(self, data, offsets, lengths, max_len, level=6, strategy=0, wrap=WRAP_ZLIB, out=None, out_len=None,
                       status=None):
