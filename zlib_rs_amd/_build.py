@@ -25,7 +25,11 @@ def build(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", LIB] + srcs + ["-ldl"]
+    # -amdgpu-atomic-optimizer-strategy=None: the kernels' LDS atomics are issued by one lane (the claim counter of lz77.hip) or go
+    # to per-lane addresses; the optimizer's wave reduction in front of every atomic in divergent code (ballot, mbcnt, a multiply,
+    # a readfirstlane) was ten instructions per claim in a kernel that is bound by its instruction count
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
+           "-o", LIB] + srcs + ["-ldl"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -160,10 +160,15 @@ static __device__ __forceinline__ void enc_flush(EncShared* S, EncWriter& W) {
     W.rel &= 31u;
 }
 
-// all lanes: lane i appends nbits (<= 48) of bits; lanes are concatenated in lane order
+// all lanes: lane i appends nbits (<= 48) of bits; lanes are concatenated in lane order.
+// The staging window (ENC_STG dwords) is written back when the group would not fit behind what it holds, not after every
+// group: a group of 64 tokens of text is ~800 bits, so a flush (store loop, carry, clearing: ~25 instructions) serves four
+// or five groups.  Callers that append with enc_put0 flush first (enc_flush_block, the end of a piece).
+#define ENC_STG_BITS (ENC_STG * 32u - 64u)   // (a group's last lane may touch the dword behind its last bit twice over)
 static __device__ __forceinline__ void enc_emit_group(EncShared* S, EncWriter& W, uint64_t bits, uint32_t nbits) {
-    uint32_t incl = zmi_wave_incl_scan(nbits);
-    uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    const uint32_t incl = zmi_wave_incl_scan(nbits);
+    const uint32_t total = zmi_readlane(incl, 63u);
+    if (W.rel + total > ENC_STG_BITS) enc_flush(S, W);   // (wave-uniform)
     if (nbits) {
         uint32_t o = W.rel + incl - nbits;
         uint32_t w = o >> 5, sh = o & 31u;
@@ -178,7 +183,20 @@ static __device__ __forceinline__ void enc_emit_group(EncShared* S, EncWriter& W
     }
     W.rel += total;
     zmi_wave_sync();
-    enc_flush(S, W);
+}
+// the same for codes of at most 16 bits (a group of literals, the run-length coded header): 32-bit arithmetic, two dwords at most
+static __device__ __forceinline__ void enc_emit_group16(EncShared* S, EncWriter& W, uint32_t bits, uint32_t nbits) {
+    const uint32_t incl = zmi_wave_incl_scan(nbits);
+    const uint32_t total = zmi_readlane(incl, 63u);
+    if (W.rel + total > ENC_STG_BITS) enc_flush(S, W);
+    if (nbits) {
+        const uint32_t o = W.rel + incl - nbits;
+        const uint32_t w = o >> 5, sh = o & 31u;
+        atomicOr(&S->stg[w], bits << sh);
+        if (sh + nbits > 32u) atomicOr(&S->stg[w + 1u], bits >> (32u - sh));
+    }
+    W.rel += total;
+    zmi_wave_sync();
 }
 
 // entry `idx` (wave-uniform, < 320) of a table held as five registers per lane (entry = lane + 64 * register)
@@ -513,6 +531,7 @@ static __device__ __noinline__ EncWriter enc_flush_block(EncShared* S, EncWriter
                                                          const uint8_t* src, uint32_t bstart, uint32_t bend, uint32_t is_final,
                                                          uint32_t strategy) {
     const uint32_t lane = zmi_lane();
+    enc_flush(S, W);   // the header is appended by lane 0 (enc_put0): the window must be near empty
     if (lane == 0) S->lfreq[256] += 1u;  // end-of-block
     zmi_wave_sync();
     enc_rank_sort(S, S->lfreq, 286u);
@@ -565,7 +584,7 @@ static __device__ __noinline__ EncWriter enc_flush_block(EncShared* S, EncWriter
         // the run-length coded code lengths, 64 symbols per step through the wave bit packer
         for (uint32_t base = 0; base < hc; base += 64u) {
             const uint32_t k = base + lane;
-            uint64_t bits = 0;
+            uint32_t bits = 0;
             uint32_t nb = 0;
             if (k < hc) {
                 const uint32_t hs = S->hsym[k];
@@ -573,10 +592,10 @@ static __device__ __noinline__ EncWriter enc_flush_block(EncShared* S, EncWriter
                 bits = c & 0xFFFFu;
                 nb = c >> 16;
                 const uint32_t xb = hs == 16u ? 2u : (hs == 17u ? 3u : (hs == 18u ? 7u : 0u));
-                bits |= (uint64_t)S->hext[k] << nb;
-                nb += xb;
+                bits |= (uint32_t)S->hext[k] << nb;
+                nb += xb;   // <= 7 + 7
             }
-            enc_emit_group(S, W, bits, nb);
+            enc_emit_group16(S, W, bits, nb);
         }
         enc_gen_codes_w(S, S->llen, 286u, 15u, S->lcode);
         enc_gen_codes_w(S, S->dlen, 30u, 15u, S->dcode);
@@ -602,6 +621,12 @@ static __device__ __noinline__ EncWriter enc_flush_block(EncShared* S, EncWriter
             uint32_t i = base + lane;
             const uint32_t tk = tk_next;
             tk_next = (i + 64u < ntok) ? tok[i + 64u] : 0u;
+            // a group of literals only (the common case on literal-dense data, a third of the groups of text): codes of <= 15 bits
+            if (__ballot(i < ntok && ((tk >> 8) & 0x1FFu) != 0u) == 0ull) {
+                const uint32_t c = i < ntok ? S->lcode[tk & 0xFFu] : (i == ntok ? S->lcode[256] : 0u);
+                enc_emit_group16(S, W, c & 0xFFFFu, c >> 16);
+                continue;
+            }
             uint64_t bits = 0;
             uint32_t nb = 0;
             if (i < ntok) {
@@ -942,6 +967,7 @@ __global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restric
     // end of piece: the last piece appends the wrapper trailer, every other piece an empty stored
     // block (00 00 FF FF after padding -- the Z_SYNC_FLUSH marker, zlib-rs/src/deflate.rs:2733-2738)
     // so that the next piece starts on a byte boundary and the pieces can simply be concatenated
+    enc_flush(S, W);
     if (lane == 0) {
         uint32_t rel = W.rel;
         if (!is_last) {

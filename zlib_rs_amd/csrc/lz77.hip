@@ -221,16 +221,6 @@ static __device__ __forceinline__ void lz_build_tile_t(const uint8_t* win, uint1
     }
 }
 
-#ifdef ZMI_EMU
-// emulator-only experiment counters (tools/emu_lz_probe.py): 0 lane chain steps, 1 wave chain steps, 2 lane extension rounds,
-// 3 wave extension rounds, 4 claims
-static uint64_t g_emu_lz[8];
-static inline void emu_lz_count(int k, uint64_t v) { __atomic_fetch_add(&g_emu_lz[k], v, __ATOMIC_RELAXED); }
-extern "C" void zmi_emu_lz_counts(uint64_t* out, int reset) {
-    for (int i = 0; i < 8; ++i) { out[i] = g_emu_lz[i]; if (reset) g_emu_lz[i] = 0; }
-}
-#endif
-
 template <bool H6>
 static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_t* prev, uint16_t* head, uint16_t* head4,
                                                      uint16_t* c4, uint32_t tile, uint32_t n, uint32_t max_dist, LzCtl* ctl,
@@ -380,9 +370,6 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
         if (base >= n) break;
         const uint32_t need = base + 64u < n ? base + 64u : n;
         while (lz_ld_acq(&ctl->ready) < need) lz_pause();
-#ifdef ZMI_EMU
-        if (lane == 0) emu_lz_count(4, 1);
-#endif
         // Every lane runs the same straight-line code, also the lanes behind the end of the shard in its last claim (their ring
         // addresses are valid whatever they hold; maxlen = 0 keeps them out of the probe, out of the walk and out of the store):
         // a validity branch around the set-up cost a dozen instructions per claim for registers that had to be defined on both sides.
@@ -427,28 +414,14 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
         uint32_t stoplen = prm.nice_len < maxlen ? prm.nice_len : maxlen;
         if (!deep && prm.good_len < stoplen) stoplen = prm.good_len;
         const uint32_t goodlen = deep ? prm.good_len : 259u;
-        uint32_t cand = p - delta;
-        bool walk = maxlen >= 4u && delta != 0u && prm.max_chain != 0u && chain != 0u;
-        uint32_t stepno = 0;
-        // The walk is a loop of the WAVE: every trip is one chain step of all positions still walking (one LDS round trip:
-        // the candidate's link and its first 16 bytes as five aligned dwords), and the wave decides together whether
-        // another trip pays -- with fewer than prm.min_live positions left it does not: the step would cost the wave
-        // what it costs with 64.  Only matches of 16+ bytes enter the divergent extension loop,
-        // so the wave rarely pays for it (an 8-byte threshold made 2/3 of the steps on text execute the extension block
-        // for some lane).
-        for (;;) {
-            const uint64_t live = __ballot(walk);
-            if (live == 0ull) break;
-            if (prm.min_live > 1u && stepno >= prm.live_from && (uint32_t)__popcll((unsigned long long)live) < prm.min_live) break;
-            ++stepno;
-#ifdef ZMI_EMU
-            uint32_t emu_xr = 0;
-            if (lane == 0) emu_lz_count(1, 1);
-#endif
-            if (walk) {
-#ifdef ZMI_EMU
-                emu_lz_count(0, 1);
-#endif
+        if (maxlen >= 4u && delta != 0u && chain != 0u && prm.max_chain != 0u) {
+            uint32_t cand = p - delta;
+            // The loop body is straight-line for the common case: a candidate is decided by its first 16 bytes (five aligned
+            // dwords, one LDS round trip together with the prev link).  Everything that concerns matches of 16+ bytes -- the
+            // check of the 4 bytes ending at the best length, the divergent extension loop, the new tail -- sits behind ONE
+            // branch that the wave rarely takes (an 8-byte threshold made 2/3 of the steps on text execute it for some lane;
+            // as three separate conditions it cost every step a dozen mask instructions).
+            for (;;) {
                 const uint32_t r = cand & LZ_WMASK;
                 const uint32_t* w = (const uint32_t*)(win + (r & ~3u));
                 const uint32_t dn = prev[r];
@@ -464,34 +437,33 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                 m3 = m3 < c2 ? m3 : c2;
                 m3 = m3 < c3 ? m3 : c3;
                 uint32_t l = m3 >> 3;        // 0..15, or 0x1FFFFFFF when all 16 bytes are equal
-                l = l > 16u ? 16u : l;
-                // (a candidate that differs inside its first 16 bytes cannot beat a best match of 16+: nothing to do)
-                // rare: all 16 bytes equal.  With a best match of 16+ already, the 4 bytes ending at the best length
-                // decide first whether this candidate can be longer at all.
-                if (l == 16u && blen >= 16u && lz_ring32(win, cand + blen - 3u) != tail) l = 0u;
-                if (l == 16u && maxlen > 16u) {
-                    // extend 16 bytes per round
-                    for (;;) {
-#ifdef ZMI_EMU
-                        emu_lz_count(2, 1);
-                        ++emu_xr;
-#endif
-                        uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
-                        lz_ring64(win, p + l, a0, a1);
-                        lz_ring64(win, p + l + 8u, a2, a3);
-                        lz_ring64(win, cand + l, b0, b1);
-                        lz_ring64(win, cand + l + 8u, b2, b3);
-                        uint32_t m = lz_match8(a0 ^ b0, a1 ^ b1);
-                        if (m == 8u) m += lz_match8(a2 ^ b2, a3 ^ b3);
-                        l += m;
-                        if (m < 16u || l >= maxlen) break;
+                if (m3 >= 128u) {
+                    // rare: all 16 bytes equal.  With a best match of 16+ already, the 4 bytes ending at the best length
+                    // decide first whether this candidate can be longer at all.
+                    l = 16u;
+                    if (blen >= 16u && lz_ring32(win, cand + blen - 3u) != tail) l = 0u;
+                    else if (maxlen > 16u) {
+                        // extend 16 bytes per round
+                        for (;;) {
+                            uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
+                            lz_ring64(win, p + l, a0, a1);
+                            lz_ring64(win, p + l + 8u, a2, a3);
+                            lz_ring64(win, cand + l, b0, b1);
+                            lz_ring64(win, cand + l + 8u, b2, b3);
+                            uint32_t m = lz_match8(a0 ^ b0, a1 ^ b1);
+                            if (m == 8u) m += lz_match8(a2 ^ b2, a3 ^ b3);
+                            l += m;
+                            if (m < 16u || l >= maxlen) break;
+                        }
                     }
+                    const uint32_t lc = l > maxlen ? maxlen : l;
+                    if (lc > blen && lc >= 16u) tail = lz_ring32(win, p + lc - 3u);
                 }
                 l = l > maxlen ? maxlen : l;
+                // (a candidate that differs inside its first 16 bytes cannot beat a best match of 16+: nothing to do)
                 const bool better = l > blen;
                 blen = better ? l : blen;
                 bdist = better ? p - cand : bdist;
-                if (better && l >= 16u) tail = lz_ring32(win, p + l - 3u);
                 // deep walks: a good match halves the remaining budget (goodlen = 259 for the short budgets: never)
                 if (deep) chain >>= (uint32_t)(better & (l >= goodlen));
                 cand -= dn;
@@ -499,14 +471,8 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                 // (bitwise, not short-circuit: four compares and three ORs; as `||` the compiler built a branch per term)
                 // (p - cand > lim: the raw link led out of the window, in front of the shard, or nowhere)
                 const bool stop = (better & (l >= stoplen)) | (dn == 0u) | ((int32_t)chain <= 0) | (p - cand > lim);
-                walk = !stop;
+                if (stop) break;
             }
-#ifdef ZMI_EMU
-            {
-                const uint32_t mx = zmi_wave_max(emu_xr);
-                if (lane == 0) emu_lz_count(3, mx);
-            }
-#endif
         }
         // (whether a short match far back is worth its codes is the encoder's call: it knows the prices, enc_far_limits)
         if (p < n) {

@@ -477,10 +477,8 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     if (const char* pv = zmi_tune("ZMI_PRODUCERS")) lp.producers = (uint32_t)atoi(pv);
     lp.dbg = 0u;
     if (const char* dv = zmi_tune("ZMI_LZ_DBG")) lp.dbg = (uint32_t)atoi(dv);
-    lp.min_live = 0u; lp.live_from = 1u; lp.barren_chain = 1u;
+    lp.barren_chain = 1u;
     if (const char* bv = zmi_tune("ZMI_BARREN_CHAIN")) lp.barren_chain = (uint32_t)atoi(bv);
-    if (const char* mv = zmi_tune("ZMI_MIN_LIVE")) lp.min_live = (uint32_t)atoi(mv);
-    if (const char* mv = zmi_tune("ZMI_LIVE_FROM")) lp.live_from = (uint32_t)atoi(mv);
     // short far matches are judged by the encoder, block by block, from the codes it just used (enc_far_limits); the
     // search reports every match of 4+ bytes
     lp.far4 = 32768u;

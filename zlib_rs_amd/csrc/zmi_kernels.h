@@ -22,9 +22,9 @@ struct zmi_lz_params {
     uint32_t carry;      // 1: the shards are consecutive segments of one stream; a segment may match into the up to 27 KiB
                          // in front of it (window carry-over, what a preset dictionary is in deflate.rs:499-564)
     uint32_t dict_len;   // carry only: bytes in front of shard 0 that are history too (preset dictionary / earlier input)
-    uint32_t min_live;   // a claim takes another chain step only while at least this many of its 64 positions still walk (0: off)
-    uint32_t live_from;  // ... from this chain step on (1 = the rule already applies behind the first candidate)
-    uint32_t barren_chain; // chain links walked in a claim whose 64 probes all missed (incompressible stretch): 1 until round 4
+    uint32_t barren_chain; // chain links walked in a claim whose 64 probes all missed (an incompressible stretch: whatever the 6-byte
+                           // chain holds there is mostly a hash collision).  1: with 0 the benchmark mix keeps its ratio but paper-100k.pdf loses 0.2 %
+                           // for 0.5 % of the kernel's time (round 4)
     uint32_t far4, far5; // a 4- (5-) byte match further back than this costs more bits than its literals: dropped
                          // (classic zlib's TOO_FAR idea; the reference itself only drops matches <= 5 under
                          // Z_FILTERED, zlib-rs/src/deflate/algorithm/slow.rs:69-74)
