@@ -748,7 +748,14 @@ static __device__ __forceinline__ uint32_t enc_seg_step(uint32_t& m, uint32_t nx
     return step;
 }
 
-__global__ void __launch_bounds__(64) zmi_encode_kernel(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off,
+#if defined(ZMI_EMU) || defined(ENC_NO_OCC)
+#define ENC_OCC
+#else
+// six waves per SIMD: at 82+ VGPRs the register file holds five, and this kernel lives on the waves that hide its LDS
+// round trips (measured: a wave per SIMD less costs ~3 %)
+#define ENC_OCC __attribute__((amdgpu_waves_per_eu(6, 8)))
+#endif
+__global__ void __launch_bounds__(64) ENC_OCC zmi_encode_kernel(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off,
                                                         const uint32_t* __restrict__ len, uint32_t first_shard,
                                                         uint32_t* match, uint64_t match_stride,
                                                         const uint32_t* __restrict__ adler, const uint32_t* __restrict__ crc,
