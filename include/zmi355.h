@@ -254,6 +254,18 @@ int zmi_inflate_split(zmi_ctx* ctx, const uint8_t* in, uint32_t in_len, uint32_t
                       uint32_t* out_len, int32_t* status, int32_t* detail, uint32_t* in_used, uint32_t* resume,
                       uint32_t* segments_used);
 
+/* The same call for a stream WITHOUT flush points -- what every ordinary compressor writes: nothing in it is byte aligned, but
+ * its dynamic blocks announce themselves.  The device tries every bit position of the stream for a block header (BTYPE 10, a
+ * complete code-length code, code lengths that decode exactly into two complete codes: csrc/blockscan.hip), the stretches
+ * between the boundaries found are decoded side by side and stitched as above; a cut counts only if the decode in front of
+ * it ended exactly there, at that bit.  Results are those of zmi_inflate_resume on the same arguments; *segments_used (may be
+ * NULL) = pieces decoded in parallel, 0 = the serial path ran (stream below 256 KiB, fewer than three boundaries found).
+ * Reference path it accelerates: the block loop of zlib-rs/src/inflate.rs:1276 ff. over blocks of 16 383 symbols
+ * (zlib-rs/src/deflate.rs:321), driven by test-libz-rs-sys/examples/blogpost-uncompress.rs:6-44. */
+int zmi_inflate_blocks(zmi_ctx* ctx, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist,
+                       uint32_t hist_len, uint8_t* out, uint32_t out_cap, uint32_t* out_len, int32_t* status, int32_t* detail,
+                       uint32_t* in_used, uint32_t* resume, uint32_t* segments_used);
+
 #ifdef __cplusplus
 }
 #endif

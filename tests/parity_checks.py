@@ -263,6 +263,86 @@ def split_inflate_checks(e, o, big=False):
     return len(cases)
 
 
+def blocks_inflate_checks(e, o, big=False):
+    """zmi_inflate_blocks (a stream WITHOUT flush points: the device scans every bit position for dynamic block headers, the
+    stretches between the boundaries found are decoded side by side and stitched) against zmi_inflate_resume on the same
+    arguments: identical output, status, detail, in_used and resume -- for streams of the system zlib at three levels and of the
+    oracle (blocks of 16 383 symbols, cuts at any bit), stored and fixed blocks between dynamic ones, history in front and
+    history missing, a truncated tail, a corrupt block, too little room, bytes behind the end, a start inside a byte, a stream
+    made of fixed blocks only (nothing to find: the serial path) and decoy headers planted inside a stored block."""
+    import os
+    import zlib
+    import random
+    rng = random.Random(5)
+    n = 1500000 if big else 200000
+
+    def raw(data, level=6, strategy=0):
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, 8, strategy)
+        return co.compress(data) + co.flush()
+
+    text = o.gen_shard(0, n)
+    mix = o.gen_shard(3, n // 3) + o.gen_shard(4, n // 3) + o.gen_shard(6, n // 3)
+    cases = []
+    for lvl in (1, 6, 9):
+        cases.append(("zlib-L%d" % lvl, raw(mix, lvl), b"", len(mix) + 100, 0, True))
+    otext = text if big else text + o.gen_shard(1, n) + o.gen_shard(2, n)   # (blocks of 16 383 symbols: enough of them to cut)
+    rc, oc = o.deflate(otext, 6, 0)
+    cases.append(("oracle", oc, b"", len(otext) + 100, 0, True))
+    comp = raw(text, 6)
+    # stored and fixed blocks between dynamic ones (Z_FULL_FLUSH / Z_BLOCK keep the pieces one stream)
+    co = zlib.compressobj(6, zlib.DEFLATED, -15)
+    part = co.compress(text[:n // 3]) + co.flush(zlib.Z_BLOCK if hasattr(zlib, "Z_BLOCK") else zlib.Z_SYNC_FLUSH)
+    st0 = zlib.compressobj(0, zlib.DEFLATED, -15)
+    # ... the stored part holds bytes that LOOK like block headers: real headers of another stream, at every bit offset
+    decoy = b"".join(bytes([rng.randrange(256)]) + raw(o.gen_shard(1, 20000), 6)[:400] for _ in range(24))
+    co2 = zlib.compressobj(6, zlib.DEFLATED, -15)
+    mid = co.compress(b"")   # (nothing: the pieces below are separate streams spliced at sync points)
+    a = zlib.compressobj(6, zlib.DEFLATED, -15)
+    pa = a.compress(text[:n // 3]) + a.flush(zlib.Z_SYNC_FLUSH)
+    pb = st0.compress(decoy) + st0.flush(zlib.Z_SYNC_FLUSH)
+    fx = zlib.compressobj(6, zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+    pc = fx.compress(mix[:n // 6]) + fx.flush(zlib.Z_SYNC_FLUSH)
+    pd = co2.compress(mix[n // 6:]) + co2.flush()
+    spliced = pa + pb + pc + pd
+    cases.append(("stored-fixed-decoys", spliced, b"", n // 3 + len(decoy) + len(mix) + 100, 0, False))   # (the decoys are found, and refused)
+    # history in front (the second part of a stream) and history missing
+    hs = zlib.compressobj(6, zlib.DEFLATED, -15)
+    head = hs.compress(text[:n // 4]) + hs.flush(zlib.Z_FULL_FLUSH if False else zlib.Z_SYNC_FLUSH)
+    rest = hs.compress(text[n // 4:]) + hs.flush()
+    cases.append(("history", rest, text[:n // 4][-32768:], n, 0, True))
+    cases.append(("history-missing", rest, text[:n // 4][-1500:], n, 0, False))
+    cases.append(("truncated", comp[:len(comp) - 1234], b"", len(text) + 100, 0, True))
+    bad = bytearray(comp); bad[len(bad) // 2] ^= 0x10
+    cases.append(("corrupt", bytes(bad), b"", len(text) + 100, 0, False))
+    cases.append(("small-room", comp, b"", len(text) // 2 + 77, 0, True))
+    cases.append(("behind-the-end", comp + b"trailing" * 50, b"", len(text) + 100, 0, True))
+    # a start inside a byte: three filler bits in front (an empty fixed block is 10 bits: use a stored-free shift instead)
+    shifted = bytearray(len(comp) + 1)
+    carry = 0
+    for i, b in enumerate(comp):
+        v = (b << 3) | carry
+        shifted[i] = v & 0xFF
+        carry = v >> 8
+    shifted[len(comp)] = carry
+    cases.append(("start-bit-3", bytes(shifted), b"", len(text) + 100, 3, True))
+    cases.append(("fixed-only", raw(text[:n // 2], 6, zlib.Z_FIXED), b"", n // 2 + 100, 0, None))
+    cases.append(("random-bytes", os.urandom(1) + bytes(rng.randrange(256) for _ in range(70000)), b"", 100000, 0, None))
+    used_any = 0
+    for name, stream, hist, cap, bit, expect_parallel in cases:
+        want = e.inflate_resume(stream, bit, hist, cap=cap)
+        got = e.inflate_blocks(stream, bit, hist, cap=cap)
+        assert got[:5] == want, (name, want[1:], got[1:], len(want[0]), len(got[0]))
+        used_any += got[5]
+        if expect_parallel and (big or name.startswith("zlib-L") or name == "oracle"):   # (the small streams of the emulator run hold few blocks)
+            assert got[5] >= 3, (name, got[5])
+        if name == "fixed-only":
+            assert got[5] == 0
+        if name.startswith("zlib-L") or name == "oracle":
+            assert got[1] == 0 and got[0] == (otext if name == "oracle" else mix)
+    assert used_any > 0
+    return len(cases)
+
+
 def truncated_stored_checks(inflate_fn, o):
     """a stored block that is cut off, or does not fit its room, through the batch kernel: the bytes and the code of the oracle
     (Mode::CopyBlock, inflate.rs:1374-1394: min(length, room, input) bytes are copied)"""

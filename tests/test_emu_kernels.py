@@ -395,6 +395,18 @@ def test_split_inflate_equals_serial_inflate():
     whatever the proposed cuts are (true markers, data that looks like one, random offsets)"""
     e = zmi_ctypes.Engine(zmi_ctypes.load_emu())
     assert parity_checks.split_inflate_checks(e, oracle_lib.load()) == 12
+
+
+def test_block_scan_inflate_equals_serial_decode(monkeypatch):
+    """zmi_inflate_blocks: restart points found by the device's scan for dynamic block headers (csrc/blockscan.hip)"""
+    monkeypatch.setenv("ZMI_TUNING", "1")
+    monkeypatch.setenv("ZMI_BLOCKS_MIN", "20000")
+    monkeypatch.setenv("ZMI_BLOCKS_GAP", "2000")
+    e = zmi_ctypes.Engine(zmi_ctypes.load_emu())
+    try:
+        assert parity_checks.blocks_inflate_checks(e, oracle_lib.load()) == 14
+    finally:
+        e.close()
     e.close()
 
 

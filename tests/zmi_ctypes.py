@@ -32,6 +32,7 @@ def _bind(lib):
     lib.zmi_inflate_resume.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, u32p, i32p, i32p, u32p, u32p]
     lib.zmi_inflate_split.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, u32p, i32p, i32p, u32p,
                                       u32p, u32p]
+    lib.zmi_inflate_blocks.argtypes = [vp, vp, C.c_uint32, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, u32p, i32p, i32p, u32p, u32p, u32p]
     # the multi-GPU stitch (csrc/exchange.hip)
     lib.zmi_comm_unique_id.argtypes = [vp]
     lib.zmi_comm_create.argtypes = [C.POINTER(vp), vp, C.c_int, C.c_int, vp]
@@ -172,6 +173,20 @@ class Engine:
         if rc != 0:
             raise RuntimeError("zmi_inflate_resume failed: %d %s" % (rc, self.lib.zmi_last_error().decode()))
         return bytes(out[:min(olen.value, cap)]), st.value, det.value, used.value, list(res)
+
+    def inflate_blocks(self, data, in_bit=0, hist=b"", cap=1 << 16):
+        """zmi_inflate_blocks: the same call, the restart points found by the device's block scan -> the same tuple + segments"""
+        src = np.frombuffer(bytes(data) + b"\0", dtype=np.uint8).copy()
+        h = np.frombuffer(bytes(hist) + b"\0", dtype=np.uint8).copy()
+        out = np.zeros(max(1, cap), dtype=np.uint8)
+        olen, used, nused = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        st, det = C.c_int32(0), C.c_int32(0)
+        res = (C.c_uint32 * 4)()
+        rc = self.lib.zmi_inflate_blocks(self.ctx, src.ctypes.data, len(data), in_bit, h.ctypes.data, len(hist), out.ctypes.data, cap,
+                                         C.byref(olen), C.byref(st), C.byref(det), C.byref(used), res, C.byref(nused))
+        if rc != 0:
+            raise RuntimeError("zmi_inflate_blocks failed: %d %s" % (rc, self.lib.zmi_last_error().decode()))
+        return bytes(out[:min(olen.value, cap)]), st.value, det.value, used.value, list(res), nused.value
 
     def inflate_split(self, data, seg_start, in_bit=0, hist=b"", cap=1 << 16):
         """zmi_inflate_split: the same call with proposed restart points -> the same tuple + segments decoded in parallel"""

@@ -48,6 +48,9 @@ extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len,
 extern "C" int zmi_inflate_resume(zmi_ctx* c, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist,
                                   uint32_t hist_len, uint8_t* out, uint32_t out_cap, uint32_t* out_len, int32_t* status,
                                   int32_t* detail, uint32_t* in_used, uint32_t* resume);
+extern "C" int zmi_inflate_blocks(zmi_ctx* c, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist, uint32_t hist_len,
+                                  uint8_t* out, uint32_t out_cap, uint32_t* out_len, int32_t* status, int32_t* detail, uint32_t* in_used,
+                                  uint32_t* resume, uint32_t* segments_used);
 extern "C" int zmi_inflate_batch_dev_ex(zmi_ctx* c, const void* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len,
                                         uint32_t n, int wrap, void* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                                         uint32_t* d_out_len, int32_t* d_status, uint32_t* d_in_used, int32_t* d_detail,
@@ -777,6 +780,15 @@ int inflate_attempt(InflateState* s, int stop_mode = 0) {   // stop_mode 1: deco
                                    seg.data(), (uint32_t)seg.size(), &olen, &st, &det, &used, res, &used_seg);
             static const bool trace = abi_tune("ZMI_ABI_TRACE") != nullptr;
             if (trace) fprintf(stderr, "[zmi abi] inflate: %zu bytes buffered, %zu cuts proposed, %u pieces decoded side by side\n", take, seg.size(), used_seg);
+        }
+        else if (stop_mode == 0 && split_enabled()) {
+            // no flush points (an ordinary compressor's stream): the device looks for the block headers itself and decodes the
+            // blocks side by side (zmi_inflate_blocks; below 256 KiB, or with nothing found, this IS zmi_inflate_resume)
+            uint32_t used_seg = 0;
+            rc = zmi_inflate_blocks(c, s->in.data(), (uint32_t)take, in_bit, s->hist.data(), (uint32_t)s->hist.size(), s->tmp.data(), (uint32_t)cap,
+                                    &olen, &st, &det, &used, res, &used_seg);
+            static const bool trace = abi_tune("ZMI_ABI_TRACE") != nullptr;
+            if (trace) fprintf(stderr, "[zmi abi] inflate: %zu bytes buffered, no flush points, %u blocks decoded side by side\n", take, used_seg);
         }
         else
             rc = zmi_inflate_resume(c, s->in.data(), (uint32_t)take, in_bit, s->hist.data(), (uint32_t)s->hist.size(), s->tmp.data(),
@@ -1678,10 +1690,34 @@ int inflateBackEnd(z_streamp strm) {
 int uncompress2_z(Bytef* dest, z_size_t* destLen, const Bytef* source, z_size_t* sourceLen) {
     ZMI_ABI_TRY
     if (!dest || !destLen || !source || !sourceLen) return Z_STREAM_ERROR;
+    const z_size_t room = *destLen;
+    // A large stream: the blocks are found on the device and decoded side by side, straight into the caller's buffer
+    // (zmi_inflate_blocks).  Only the plain outcome is taken from here -- a complete stream that fits, with its Adler-32 right;
+    // everything else (errors, short room, FDICT) goes the way it always went, which names the reference's codes.
+    if (*sourceLen >= ((z_size_t)256 << 10) && *sourceLen < ((z_size_t)1 << 28) && room >= 1 && room <= ((z_size_t)1 << 30) && split_enabled()) {
+        const uint32_t cmf = source[0], flg = source[1];
+        if ((cmf & 0x0Fu) == 8u && (cmf >> 4) <= 7u && ((cmf << 8) | flg) % 31u == 0u && !(flg & 0x20u)) {
+            AbiLease lease;
+            if (lease.ctx) {
+                uint32_t olen = 0, used2 = 0, res[4] = {0, 0, 0, 0}, segs = 0;
+                int32_t st2 = 0, det2 = 0;
+                const uint32_t n2 = (uint32_t)(*sourceLen - 2);
+                if (zmi_inflate_blocks(lease.ctx, source + 2, n2, 0u, nullptr, 0u, dest, (uint32_t)room, &olen, &st2, &det2, &used2, res, &segs) == 0 &&
+                    st2 == Z_OK && olen <= room && (uint64_t)used2 + 4u <= n2) {
+                    const uint8_t* t = source + 2 + used2;
+                    const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+                    if (host_adler32(1u, dest, olen) == want) {
+                        *sourceLen = (z_size_t)used2 + 6u;
+                        *destLen = olen;
+                        return Z_OK;
+                    }
+                }
+            }
+        }
+    }
     std::vector<uint8_t> out;
     uint32_t used = 0;
     int32_t st = 0, detail = 0;
-    const z_size_t room = *destLen;
     int rc = gpu_inflate_stream(source, *sourceLen, ZMI_WRAP_ZLIB, out, room, &used, &st, &detail);
     if (rc != Z_OK) return rc;
     *sourceLen = used;

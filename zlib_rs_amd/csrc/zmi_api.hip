@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -81,6 +82,10 @@ struct zmi_ctx {
     zmi_buf inf_ptr;  // inflate of few streams: 4 B per output byte, the pointers of the jump resolve (resolve_jump.hip)
     zmi_buf st_in, st_out, st_meta;  // zmi_inflate_resume: staging of one host stream (kept across calls)
     zmi_buf sp_out;                  // zmi_inflate_split: the segments' decode regions
+    zmi_buf st_scan;                 // zmi_inflate_blocks: the block scan's counter and list
+    zmi_buf st_pin[2];               // zmi_d2h: two pinned 4 MiB pieces the decoded bytes of a single stream leave through
+    hipEvent_t st_pin_ev[2]{};
+    bool st_pin_ev_live = false;
     // host-buffer batches (zmi_deflate_batch): two slots cycle through copy-in / kernels / copy-out on three streams
     struct hb_slot { zmi_buf in, out, meta; hipEvent_t in_done, k_done, out_done; } hb[ZMI_HB_SLOTS];
     zmi_buf hb_slab[ZMI_HB_SLOTS];                              // device: the chunk's compressed streams packed densely (what travels back)
@@ -140,6 +145,9 @@ extern "C" int zmi_ctx_destroy(zmi_ctx* c) {
     if (c->st_meta.p) (void)hipFree(c->st_meta.p);
     if (c->side) { (void)hipStreamDestroy(c->side); (void)hipEventDestroy(c->ev_fork); (void)hipEventDestroy(c->ev_join); }
     if (c->sp_out.p) (void)hipFree(c->sp_out.p);
+    if (c->st_scan.p) (void)hipFree(c->st_scan.p);
+    for (int k = 0; k < 2; ++k) if (c->st_pin[k].p) (void)hipHostFree(c->st_pin[k].p);
+    if (c->st_pin_ev_live) { (void)hipEventDestroy(c->st_pin_ev[0]); (void)hipEventDestroy(c->st_pin_ev[1]); }
     if (c->hb_live) {
         for (auto& sl : c->hb) {
             if (sl.in.p) (void)hipFree(sl.in.p);
@@ -606,8 +614,8 @@ static int zmi_inflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
         zmi_scope_timer tm(c, ZMI_K_RESOLVE, stream);
         int lrc;
         if (jump) {
-            uint32_t rounds = 2u;
-            while (rounds < 34u && (1ull << (rounds - 1u)) < out_limit) ++rounds;   // ceil(log2(capacity)) + 1
+            uint32_t rounds = 2u;   // ceil(log3(capacity)) + 1: a round follows two pointers (resolve_jump.hip)
+            for (uint64_t span = 3u; rounds < 34u && span < out_limit; span *= 3u) ++rounds;
             lrc = zmi_launch_resolve_jump((uint8_t*)d_out, d_out_off, d_out_len, n, (const uint64_t*)c->inf_bm.p, d_bm_off, (int32_t*)c->inf_ptr.p,
                                           bm_words * 64ull, rounds, (uint32_t*)((uint8_t*)c->inf_ptr.p + (size_t)bm_words * 256u), stream);
         } else {
@@ -753,6 +761,16 @@ extern "C" int zmi_launch_resolve_jump_segments(uint8_t* d_fin, const uint64_t* 
                                                 const uint64_t* d_bm_off, int32_t* d_ptr, uint64_t total, uint32_t hist_len,
                                                 uint32_t rounds, uint32_t* d_flags, uint32_t* d_err, const uint64_t* d_one_off,
                                                 const uint32_t* d_one_len, hipStream_t stream);
+// Device -> caller's (pageable) memory for the single-stream paths.  hipMemcpy into pageable memory is the runtime's own bounce
+// through a small pinned buffer, one thread, 2-4 GB/s: the 15 MiB of a decoded stream took longer to leave the device than to
+// decode (measured: 6.4 of 7.5 ms).  Here the bytes go out in 4 MiB pieces through two pinned buffers of the context -- the DMA of
+// a piece runs while a few host threads copy the piece before it to where it belongs.  Without pinned memory: the plain copy.
+struct zmi_copy_job;
+static void zmi_parallel_copy(const std::vector<zmi_copy_job>& jobs, unsigned T);
+static int zmi_reserve_pinned(zmi_buf& b, size_t bytes);
+static unsigned zmi_host_threads();
+static int zmi_d2h(zmi_ctx* c, void* dst, const void* src, size_t n, hipStream_t hs);
+
 // (this function copies asynchronously from vectors and locals of its own frame: an error return must not leave such a copy in
 // flight -- the stream is drained first)
 #define ZMI_HIPS(call)                                                                  \
@@ -760,17 +778,19 @@ extern "C" int zmi_launch_resolve_jump_segments(uint8_t* d_fin, const uint64_t* 
         hipError_t e_ = (call);                                                         \
         if (e_ != hipSuccess) { (void)hipStreamSynchronize(c->host_stream); return zmi_fail(ZMI_E_HIP, #call, e_); } \
     } while (0)
-extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist,
-                                 uint32_t hist_len, uint8_t* out, uint32_t out_cap, const uint32_t* seg_start, uint32_t nseg,
-                                 uint32_t* out_len, int32_t* status, int32_t* detail, uint32_t* in_used, uint32_t* resume,
-                                 uint32_t* segments_used) {
+// seg_bit (may be null: all zero): segment j starts at bit seg_bit[j] of byte seg_start[j] -- block boundaries found by the scan
+// of zmi_inflate_blocks lie anywhere; in_on_device: c->st_in already holds the stream (that scan has copied it)
+static int zmi_split_core(zmi_ctx* c, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist,
+                          uint32_t hist_len, uint8_t* out, uint32_t out_cap, const uint32_t* seg_start, const uint32_t* seg_bit, uint32_t nseg,
+                          bool in_on_device, uint32_t* out_len, int32_t* status, int32_t* detail, uint32_t* in_used, uint32_t* resume,
+                          uint32_t* segments_used) {
     if (segments_used) *segments_used = 0;
     if (!c || (!in && in_len) || (!hist && hist_len) || (!out && out_cap) || !out_len || !status || !detail || !in_used || !resume || !seg_start)
         return zmi_fail(ZMI_E_ARG, "null argument");
     if (nseg < 2u || in_bit > 7u || out_cap > (1u << 30) || in_len > 0xFFFFFF00u || seg_start[0] != 0u)
         return zmi_inflate_resume(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume);
     for (uint32_t j = 1; j < nseg; ++j)
-        if (seg_start[j] <= seg_start[j - 1u] || seg_start[j] >= in_len)
+        if (seg_start[j] <= seg_start[j - 1u] || seg_start[j] >= in_len || (seg_bit && seg_bit[j] > 7u))
             return zmi_inflate_resume(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume);
     ZMI_ON_DEVICE(c);
     const bool sp_trace = zmi_tune("ZMI_SPLIT_TRACE") != nullptr;
@@ -785,14 +805,15 @@ extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len,
     uint64_t scratch = 0;
     for (uint32_t j = 0; j < nseg; ++j) {
         ioff[j] = seg_start[j];
-        ilen[j] = (j + 1u < nseg ? seg_start[j + 1u] : in_len) - seg_start[j];
+        // (a cut inside a byte: the segment in front of it sees that byte too -- its decode must stop AT the cut, for want of input)
+        ilen[j] = (j + 1u < nseg ? seg_start[j + 1u] + ((seg_bit && seg_bit[j + 1u]) ? 1u : 0u) : in_len) - seg_start[j];
         uint64_t room = (uint64_t)ilen[j] * 16u + 4096u;
         if (room > out_cap) room = out_cap;
         ocap[j] = (uint32_t)room;
         ooff[j] = scratch;
         scratch += (room + 1023u) & ~1023ull;
         shist[j] = j == 0u ? hist_len : 32768u;   // (taken on trust by the decode pass, which reads no history; checked at the stitch)
-        sbit[j] = j == 0u ? in_bit : 0u;
+        sbit[j] = j == 0u ? in_bit : (seg_bit ? seg_bit[j] : 0u);
     }
     if (scratch > (3ull << 30)) return zmi_inflate_resume(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume);
     // meta: ioff u64[n] | ooff u64[n] | soff u64[n + 1] | ilen | ocap | hist | bit | olen | status | used | detail (u32[n] each) | resume u32[4n] | one_off u64, one_len u32, err u32
@@ -811,7 +832,7 @@ extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len,
     memcpy(hm.data() + o_ioff, ioff.data(), 8 * n); memcpy(hm.data() + o_ooff, ooff.data(), 8 * n);
     memcpy(hm.data() + o_ilen, ilen.data(), 4 * n); memcpy(hm.data() + o_ocap, ocap.data(), 4 * n);
     memcpy(hm.data() + o_hist, shist.data(), 4 * n); memcpy(hm.data() + o_bit, sbit.data(), 4 * n);
-    ZMI_HIPS(hipMemcpyAsync(c->st_in.p, in, in_len, hipMemcpyHostToDevice, hs));
+    if (!in_on_device) ZMI_HIPS(hipMemcpyAsync(c->st_in.p, in, in_len, hipMemcpyHostToDevice, hs));
     if (hist_len) ZMI_HIPS(hipMemcpyAsync((uint8_t*)c->st_out.p + base - hist_len, hist, hist_len, hipMemcpyHostToDevice, hs));
     ZMI_HIPS(hipMemcpyAsync(d, hm.data(), meta_bytes, hipMemcpyHostToDevice, hs));
     const uint64_t saved_limit = c->inflate_out_limit;
@@ -827,18 +848,25 @@ extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len,
     ZMI_HIPS(hipMemcpyAsync(codes.data(), (const uint8_t*)c->inf_tmp.p + 12u * (size_t)nseg, 4u * (size_t)nseg, hipMemcpyDeviceToHost, hs));
     ZMI_HIPS(hipStreamSynchronize(hs));
     const double sp_t1 = sp_trace ? sp_now() : 0.0;
-    const uint32_t *olen = r.data(), *used = r.data() + 2 * n, *res = r.data() + 4 * n;
+    uint32_t* olen = r.data();
+    const uint32_t *used = r.data() + 2 * n, *res = r.data() + 4 * n;
     const int32_t *st = (const int32_t*)(r.data() + n), *det = (const int32_t*)(r.data() + 3 * n);
     // the chain: segment j is CLEAN if its decode ended exactly at its last byte, on a block boundary, with all output complete
+    bool trimmed = false;   // a clean segment produced bytes behind its checkpoint: the device copy of the lengths is corrected
     uint32_t tail = 0;   // the first segment that is not clean (or the last one): its result is "the serial decode of the rest"
     std::vector<uint64_t> soff(n + 1, 0);
     uint64_t total = 0;
     for (uint32_t j = 0; j < nseg; ++j) {
         tail = j;
         soff[j] = total;
-        const bool clean = j + 1u < nseg && st[j] == ZMI_BUF_ERROR && det[j] == 1 && res[4 * j] == ilen[j] && res[4 * j + 1] == 0u &&
-                           res[4 * j + 2] == olen[j] && olen[j] <= ocap[j] && total + olen[j] <= out_cap;
+        // (a cut inside a byte: the decode stops at that bit for want of input, having seen the next block's first bits at most --
+        // whatever it made of them lies behind the checkpoint and is dropped)
+        const uint32_t cut_byte = j + 1u < nseg ? seg_start[j + 1u] - seg_start[j] : 0u, cut_bit = (j + 1u < nseg && seg_bit) ? seg_bit[j + 1u] : 0u;
+        const bool clean = j + 1u < nseg && st[j] == ZMI_BUF_ERROR && det[j] == 1 && res[4 * j] == cut_byte && res[4 * j + 1] == cut_bit &&
+                           (cut_bit != 0u || res[4 * j + 2] == olen[j]) && res[4 * j + 2] <= olen[j] && olen[j] <= ocap[j] &&
+                           total + res[4 * j + 2] <= out_cap;
         if (!clean) break;
+        if (olen[j] != res[4 * j + 2]) { olen[j] = res[4 * j + 2]; trimmed = true; }
         total += olen[j];
     }
     // the tail counts as it stands if it is the stream's real tail (the last segment) or ended the stream; a tail that stopped
@@ -861,11 +889,12 @@ extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len,
     struct { uint64_t off; uint32_t len, err; } one = {0ull, (uint32_t)total, 0u};
     ZMI_HIPS(hipMemcpyAsync(d + o_soff, soff.data(), 8 * (take + 1u), hipMemcpyHostToDevice, hs));
     ZMI_HIPS(hipMemcpyAsync(d + o_one, &one, sizeof(one), hipMemcpyHostToDevice, hs));
+    if (trimmed) ZMI_HIPS(hipMemcpyAsync(d + o_olen, olen, 4 * (size_t)take, hipMemcpyHostToDevice, hs));
     uint8_t* d_fin = (uint8_t*)c->st_out.p + base;
     zmi_launch_copy_ranges((const uint8_t*)c->sp_out.p, (const uint64_t*)(d + o_ooff), 0, (const uint32_t*)(d + o_olen), take, d_fin,
                            (const uint64_t*)(d + o_soff), total, 0xFFFFFFFFu, hs);
-    uint32_t rounds = 2u;
-    while (rounds < 34u && (1ull << (rounds - 1u)) < total) ++rounds;
+    uint32_t rounds = 2u;   // ceil(log3(total)) + 1
+    for (uint64_t span = 3u; rounds < 34u && span < total; span *= 3u) ++rounds;
     {
         zmi_scope_timer tm(c, ZMI_K_RESOLVE, hs);
         zmi_launch_resolve_jump_segments(d_fin, (const uint64_t*)(d + o_soff), take, (const uint64_t*)c->inf_bm.p, (const uint64_t*)c->inf_tmp.p,
@@ -874,10 +903,12 @@ extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len,
     }
     uint32_t err = 0;
     ZMI_HIPS(hipMemcpyAsync(&err, d + o_one + 12, 4, hipMemcpyDeviceToHost, hs));
-    ZMI_HIPS(hipMemcpyAsync(out, d_fin, (size_t)total, hipMemcpyDeviceToHost, hs));
+    double sp_t2 = 0.0;
+    if (sp_trace) { ZMI_HIPS(hipStreamSynchronize(hs)); sp_t2 = sp_now(); }
+    { const int crc = zmi_d2h(c, out, d_fin, (size_t)total, hs); if (crc) return crc; }
     ZMI_HIPS(hipStreamSynchronize(hs));
     ZMI_HIPS(hipGetLastError());
-    if (sp_trace) fprintf(stderr, "[zmi split] %u segments, %u B in, %llu B out: copy-in + decode %.2f ms, stitch + resolve + copy-out %.2f ms\n", nseg, in_len, (unsigned long long)total, sp_t1 - sp_t0, sp_now() - sp_t1);
+    if (sp_trace) fprintf(stderr, "[zmi split] %u segments, %u B in, %llu B out: copy-in + decode %.2f ms, stitch + resolve %.2f ms, copy-out %.2f ms\n", nseg, in_len, (unsigned long long)total, sp_t1 - sp_t0, sp_t2 - sp_t1, sp_now() - sp_t2);
     if (err)   // a distance reaches in front of the history that is really there: let the serial decode find and name it
         return zmi_inflate_resume(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume);
     if (segments_used) *segments_used = take;
@@ -909,6 +940,90 @@ extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len,
 }
 
 #undef ZMI_HIPS
+extern "C" int zmi_inflate_split(zmi_ctx* c, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist,
+                                 uint32_t hist_len, uint8_t* out, uint32_t out_cap, const uint32_t* seg_start, uint32_t nseg,
+                                 uint32_t* out_len, int32_t* status, int32_t* detail, uint32_t* in_used, uint32_t* resume,
+                                 uint32_t* segments_used) {
+    try {
+        return zmi_split_core(c, in, in_len, in_bit, hist, hist_len, out, out_cap, seg_start, nullptr, nseg, false, out_len, status, detail,
+                              in_used, resume, segments_used);
+    } catch (...) { return zmi_fail(ZMI_E_NOMEM, "zmi_inflate_split: out of host memory"); }
+}
+
+// One raw deflate stream WITHOUT flush points, decoded as parallel segments all the same: the device looks for the stream's
+// dynamic block headers at every bit position (blockscan.hip), the stretches between the boundaries found are decoded side by
+// side and stitched as zmi_inflate_split does -- with the same discipline: a cut counts only if the decode in front of it
+// ended exactly there.  Results equal zmi_inflate_resume on the same arguments; *segments_used = 0 says the serial path ran
+// (too few boundaries found, or the first cut did not check out).
+extern "C" int zmi_launch_block_scan(const uint8_t* d_in, uint32_t n, uint64_t first_bit, uint32_t* d_pre, uint32_t pre_cap, uint32_t* d_list,
+                                     uint32_t cap, uint32_t* d_count, hipStream_t stream);
+static int zmi_inflate_blocks_body(zmi_ctx* c, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist, uint32_t hist_len,
+                                   uint8_t* out, uint32_t out_cap, uint32_t* out_len, int32_t* status, int32_t* detail, uint32_t* in_used,
+                                   uint32_t* resume, uint32_t* segments_used) {
+    if (segments_used) *segments_used = 0;
+    if (!c || (!in && in_len) || (!hist && hist_len) || (!out && out_cap) || !out_len || !status || !detail || !in_used || !resume)
+        return zmi_fail(ZMI_E_ARG, "null argument");
+    // (below 256 KiB the scan and the stitch cost more than the serial decode of the few blocks there are)
+    uint32_t min_len = 256u << 10, gap = 8192u;
+    if (const char* e = zmi_tune("ZMI_BLOCKS_MIN")) { if (atoi(e) > 0) min_len = (uint32_t)atoi(e); }
+    if (const char* e = zmi_tune("ZMI_BLOCKS_GAP")) { if (atoi(e) > 0) gap = (uint32_t)atoi(e); }
+    if (in_len < min_len || in_bit > 7u || out_cap > (1u << 30) || in_len > (1u << 28))
+        return zmi_inflate_resume(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume);
+    ZMI_ON_DEVICE(c);
+    const uint32_t cap = 65536u;
+    // stage-1 survivors: one bit position in ~250 of ordinary compressed data; room for one in 64 (more: the scan reports an
+    // overflow and the serial decode runs)
+    const uint32_t pre_cap = in_len / 8u + 4096u;
+    int rc = zmi_reserve(c->st_in, (size_t)in_len + 64u);
+    if (!rc) rc = zmi_reserve(c->st_scan, ((size_t)cap + pre_cap) * 4u + 64u);
+    if (rc) return rc;
+    hipStream_t hs = c->host_stream;
+    uint32_t* d_count = (uint32_t*)c->st_scan.p;
+    uint32_t* d_list = d_count + 16;
+    uint32_t* d_pre = d_list + cap;
+    std::vector<uint32_t> found;
+    uint32_t count = 0, counts[4] = {0, 0, 0, 0};
+    {
+        hipError_t e = hipMemcpyAsync(c->st_in.p, in, in_len, hipMemcpyHostToDevice, hs);
+        if (e == hipSuccess) e = hipMemsetAsync(d_count, 0, 64, hs);
+        if (e != hipSuccess) { (void)hipStreamSynchronize(hs); return zmi_fail(ZMI_E_HIP, "zmi_inflate_blocks: copy-in", e); }
+        // (the first block starts at in_bit: it needs no finding; the scan starts behind its header bits)
+        zmi_launch_block_scan((const uint8_t*)c->st_in.p, in_len, (uint64_t)in_bit + 3u, d_pre, pre_cap, d_list, cap, d_count, hs);
+        e = hipMemcpyAsync(counts, d_count, 16, hipMemcpyDeviceToHost, hs);
+        if (e == hipSuccess) e = hipStreamSynchronize(hs);
+        if (e != hipSuccess) return zmi_fail(ZMI_E_HIP, "zmi_inflate_blocks: scan", e);
+        count = counts[2] ? 0u : counts[0];   // (an incomplete survivor list: nothing is taken from it)
+        if (count != 0u && count <= cap) {
+            found.resize(count);
+            e = hipMemcpyAsync(found.data(), d_list, (size_t)count * 4u, hipMemcpyDeviceToHost, hs);
+            if (e == hipSuccess) e = hipStreamSynchronize(hs);
+            if (e != hipSuccess) return zmi_fail(ZMI_E_HIP, "zmi_inflate_blocks: list", e);
+        }
+    }
+    std::sort(found.begin(), found.end());
+    // cuts: boundaries at least `gap` compressed bytes apart (a segment is one wave's work: it should be worth a wave)
+    std::vector<uint32_t> seg_start{0u}, seg_bit{in_bit};
+    uint64_t last = 0;
+    for (uint32_t pos : found) {
+        if ((uint64_t)pos < last + 8ull * gap || (pos >> 3) == 0u) continue;
+        seg_start.push_back(pos >> 3);
+        seg_bit.push_back(pos & 7u);
+        last = pos;
+        if (seg_start.size() >= 8192u) break;
+    }
+    if (zmi_tune("ZMI_SPLIT_TRACE")) fprintf(stderr, "[zmi blocks] %u B: %u of %u stage-1 survivors are block headers, %zu segments\n", in_len, count, counts[3], seg_start.size());
+    if (seg_start.size() < 4u)
+        return zmi_inflate_resume(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume);
+    return zmi_split_core(c, in, in_len, in_bit, hist, hist_len, out, out_cap, seg_start.data(), seg_bit.data(), (uint32_t)seg_start.size(), true,
+                          out_len, status, detail, in_used, resume, segments_used);
+}
+extern "C" int zmi_inflate_blocks(zmi_ctx* c, const uint8_t* in, uint32_t in_len, uint32_t in_bit, const uint8_t* hist, uint32_t hist_len,
+                                  uint8_t* out, uint32_t out_cap, uint32_t* out_len, int32_t* status, int32_t* detail, uint32_t* in_used,
+                                  uint32_t* resume, uint32_t* segments_used) {
+    try {
+        return zmi_inflate_blocks_body(c, in, in_len, in_bit, hist, hist_len, out, out_cap, out_len, status, detail, in_used, resume, segments_used);
+    } catch (...) { return zmi_fail(ZMI_E_NOMEM, "zmi_inflate_blocks: out of host memory"); }
+}
 // ---- host buffers, pipelined ----
 // A caller that hands over host memory pays PCIe both ways (the reference's own caller loop:
 // test-libz-rs-sys/examples/blogpost-compress.rs:43-122 -- every real zlib-rs user lives on this path).  Pageable memory is
@@ -995,6 +1110,38 @@ struct zmi_joiner {
         if (t.joinable()) { failed.store(ZMI_E_NOMEM, std::memory_order_release); t.join(); }
     }
 };
+static int zmi_d2h(zmi_ctx* c, void* dst, const void* src, size_t n, hipStream_t hs) {
+    const size_t CH = (size_t)4 << 20;
+    bool bounce = n >= ((size_t)1 << 20);
+    if (bounce && (zmi_reserve_pinned(c->st_pin[0], CH) != 0 || zmi_reserve_pinned(c->st_pin[1], CH) != 0)) bounce = false;
+    if (bounce && !c->st_pin_ev_live) {
+        if (hipEventCreateWithFlags(&c->st_pin_ev[0], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->st_pin_ev[1], hipEventDisableTiming) != hipSuccess) bounce = false;
+        else c->st_pin_ev_live = true;
+    }
+    if (!bounce) {
+        ZMI_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, hs));
+        ZMI_HIP(hipStreamSynchronize(hs));
+        return 0;
+    }
+    const unsigned T = zmi_host_threads() < 4u ? zmi_host_threads() : 4u;
+    const size_t K = (n + CH - 1) / CH;
+    for (size_t k = 0; k <= K; ++k) {
+        if (k < K) {
+            const size_t len = n - k * CH < CH ? n - k * CH : CH;
+            hipError_t e = hipMemcpyAsync(c->st_pin[k & 1].p, (const uint8_t*)src + k * CH, len, hipMemcpyDeviceToHost, hs);
+            if (e == hipSuccess) e = hipEventRecord(c->st_pin_ev[k & 1], hs);
+            if (e != hipSuccess) { (void)hipStreamSynchronize(hs); return zmi_fail(ZMI_E_HIP, "zmi_d2h", e); }
+        }
+        if (k >= 1) {   // the piece before: wait for its DMA, copy it out (the DMA of piece k runs meanwhile)
+            const size_t j = k - 1, len = n - j * CH < CH ? n - j * CH : CH;
+            ZMI_HIP(hipEventSynchronize(c->st_pin_ev[j & 1]));
+            std::vector<zmi_copy_job> jobs{{(uint8_t*)dst + j * CH, c->st_pin[j & 1].p, len}};
+            zmi_parallel_copy(jobs, T);
+        }
+    }
+    return 0;
+}
 static int zmi_reserve_pinned(zmi_buf& b, size_t bytes) {
     if (bytes <= b.cap) return 0;
     if (b.p) { (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
@@ -1564,8 +1711,8 @@ extern "C" int zmi_inflate_resume(zmi_ctx* c, const uint8_t* in, uint32_t in_len
     for (int i = 0; i < 4; ++i) resume[i] = r[4 + i];
     const uint32_t n = r[0] < out_cap ? r[0] : out_cap;
     if (n) {
-        ZMI_HIP(hipMemcpyAsync(out, (const uint8_t*)c->st_out.p + base, n, hipMemcpyDeviceToHost, hs));
-        ZMI_HIP(hipStreamSynchronize(hs));
+        const int crc = zmi_d2h(c, out, (const uint8_t*)c->st_out.p + base, n, hs);
+        if (crc) return crc;
     }
     return ZMI_E_OK;
 }
