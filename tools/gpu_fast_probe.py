@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--host-verify", type=int, default=4)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--groups", type=int, default=1, help="cut the batch into this many launch groups (scratch = 1/groups of the batch)")
     ap.add_argument("--no-check", action="store_true", help="ablation builds (output invalid on purpose): times only, no status / round-trip checks")
     ap.add_argument("--class-times", action="store_true", help="also time the eight data classes of the generator separately (level 6 unless --levels has one entry)")
     a = ap.parse_args()
@@ -108,7 +109,7 @@ def main():
     S = a.shards
     fx = real_fixtures(B) if a.real else []
     NT = S + len(fx)
-    L.zmi_ctx_set_scratch_limit(ctx, max(64 << 20, NT * B * 4))
+    L.zmi_ctx_set_scratch_limit(ctx, max(64 << 20, NT * B * 4 // max(1, a.groups)))
     L.zmi_ctx_set_inflate_out_limit(ctx, NT * B + (1 << 20))
     L.zmi_ctx_set_timing(ctx, 1)
     stride = int(L.zmi_deflate_bound(B, 1))
@@ -143,7 +144,7 @@ def main():
             hip.hipDeviceSynchronize()
             dt = time.perf_counter() - t
             tm = timing(L, ctx)
-            if best is None or tm[1] + tm[2] < best[1][1] + best[1][2]:
+            if best is None or dt < best[0]:
                 best = (dt, tm)
         dt, tm = best
         olen = d2h_u32(d_olen, NT)
@@ -170,8 +171,8 @@ def main():
             comp = d2h(d_out + i * stride, olen[i])
             ok = ok and zlib.adler32(zlib.decompress(comp)) == want[i]
         ratio = S * B / float(sum(olen[:S])) if S else 0.0
-        line = "L%d: lz77 %.2f ms  encode %.2f ms  (%.1f GiB/s kernels)  ratio %.4f  roundtrip %s  [inflate decode %.2f resolve %.2f ms]" % (
-            lvl, tm[1], tm[2], NT * B / 2**30 / ((tm[1] + tm[2]) / 1e3), ratio, "ok" if ok else "FAILED", itm[3], itm[6])
+        line = "L%d: lz77 %.2f ms  encode %.2f ms  wall %.2f ms (%.1f GiB/s)  ratio %.4f  roundtrip %s  [inflate decode %.2f resolve %.2f ms]" % (
+            lvl, tm[1], tm[2], dt * 1e3, NT * B / 2**30 / dt, ratio, "ok" if ok else "FAILED", itm[3], itm[6])
         r = {"lz77_ms": tm[1], "encode_ms": tm[2], "ratio": ratio, "ok": ok, "decode_ms": itm[3], "resolve_ms": itm[6]}
         if a.classes and S >= 8:
             r["class_ratio"] = [B * len(olen[c:S:8]) / float(sum(olen[c:S:8])) for c in range(8)]
