@@ -800,7 +800,7 @@ def stitch_leg_multi(e, dist, torch, out, olen, dev, world, rank, chunk_bytes=1 
     pack_s = time.perf_counter() - t0
     # what every peer must see in round 0 of this rank's slab
     first = min(chunk_bytes, totals[rank])
-    mysum = slab[:first].to(torch.int64).sum().reshape(1)
+    mysum = slab[:first].sum(dtype=torch.int64).reshape(1)   # (no int64 copy of half a GiB)
     sums = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
     dist.all_gather(sums, mysum)
     stage = [None if p == rank else torch.empty(min(chunk_bytes, max(16, totals[p])), dtype=torch.uint8, device=dev) for p in range(world)]
@@ -818,7 +818,7 @@ def stitch_leg_multi(e, dist, torch, out, olen, dev, world, rank, chunk_bytes=1 
             n = min(chunk_bytes, totals[p] - lo)
             got += n
             if lo == 0:
-                assert int(stage[p][:n].to(torch.int64).sum().item()) == int(sums[p].item()), "slab bytes of rank %d arrived damaged" % p
+                assert int(stage[p][:n].sum(dtype=torch.int64).item()) == int(sums[p].item()), "slab bytes of rank %d arrived damaged" % p
                 checked += 1
         lo += chunk_bytes
     torch.cuda.synchronize()

@@ -14,6 +14,6 @@ for spec in "$@"; do
   E=$(echo "$envs" | tr ',' ' ')
   F=${flags:---shards 16384 --levels 6 --reps 2 --host-verify 2}
   echo "== [$i] $lib $E $F"
-  env $L $E python tools/gpu_fast_probe.py $F --tag "$lib $E" > "$O/probe_$i.log" 2>&1
+  env $L $E timeout 150 python tools/gpu_fast_probe.py $F --tag "$lib $E" > "$O/probe_$i.log" 2>&1 || echo "   (probe $i: rc $? -- timed out or failed)"
   grep -v "^JSON\|^# lib" "$O/probe_$i.log" | tail -14
 done
