@@ -61,7 +61,7 @@ int zmi_ctx_set_inflate_out_limit(zmi_ctx* ctx, uint64_t bytes);
 
 /* Host-buffer batches (zmi_deflate_batch / zmi_inflate_batch) stage their chunks through pinned host memory and device slots
  * that the context keeps for the next call (three slots; up to ~6.4 GiB pinned + as much HBM after a multi-GiB batch).
- * zmi_ctx_set_pinned_limit bounds the pinned part (default 8 GiB, env ZMI_PINNED_MB; >= 64 MiB): chunk sizes follow it and a
+ * zmi_ctx_set_pinned_limit bounds the pinned part (default 10 GiB, env ZMI_PINNED_MB; >= 64 MiB): chunk sizes follow it and a
  * call that ends above it releases the staging.  zmi_ctx_trim releases it now.  If pinned memory cannot be had at all
  * (memlock / container limits) the calls fall back to plain copies instead of failing. */
 int zmi_ctx_set_pinned_limit(zmi_ctx* ctx, uint64_t bytes);

@@ -92,7 +92,7 @@ struct zmi_ctx {
     zmi_buf hb_pin_in[ZMI_HB_SLOTS], hb_pin_out[ZMI_HB_SLOTS], hb_pin_meta[ZMI_HB_SLOTS];   // pinned host staging of the two slots
     hipStream_t hs_in = nullptr, hs_k = nullptr, hs_out = nullptr, hs_slab = nullptr;
     bool hb_live = false;
-    uint64_t pinned_limit = 8ull << 30;   // host-buffer pipelines: pinned staging this context may hold (chunk sizes follow it; env ZMI_PINNED_MB)
+    uint64_t pinned_limit = 10ull << 30;   // host-buffer pipelines: pinned staging this context may hold (chunk sizes follow it; env ZMI_PINNED_MB)
     uint32_t last_codes_used = 0;    // zmi_inflate_resume: table entries of the most recent dynamic block of the last call (inflateCodesUsed)
     uint64_t inflate_out_limit = 0;  // output bytes one inflate batch may cover; 0 = scratch_limit
     hipStream_t host_stream = nullptr;  // zmi_ctx_set_stream: where the host-buffer wrappers copy and launch
@@ -1498,7 +1498,10 @@ static int zmi_inflate_batch_body(zmi_ctx* c, const uint8_t* in, const uint64_t*
     // GiB/s, above what PCIe carries), and a chunk's output has to fit the pinned staging: 2 GiB of capacity per chunk.
     // ZMI_HOST_CHUNK (bytes) overrides both bounds (tests).
     uint64_t budget = 2ull << 30;
-    if (budget > c->pinned_limit / 4u) budget = c->pinned_limit / 4u;   // three slots of output staging + their (smaller) input
+    if (budget > c->pinned_limit / 5u) budget = c->pinned_limit / 5u;   // three slots of output staging + their (smaller) input: 4.4 chunks
+                                                                         // (the default limit leaves the 2 GiB chunks as they are: a call that
+                                                                         // ends above the limit releases the staging, and re-pinning 9 GiB
+                                                                         // costs seconds -- measured: 19 -> 3 GiB/s with a limit of 8 GiB)
     uint32_t min_count = 2048u;
     if (const char* e = zmi_tune("ZMI_HOST_CHUNK")) { if (atoll(e) > 0) { budget = (uint64_t)atoll(e); min_count = 1u; } }
     struct chunk { uint32_t first, count; uint64_t in_bytes, out_bytes; std::vector<uint64_t> ioff, ooff; uint32_t max_cap; };
