@@ -105,6 +105,18 @@ static __device__ __forceinline__ void lz_ring64(const uint8_t* win, uint32_t po
     lo = __builtin_amdgcn_alignbyte(b, a, r & 3u);
     hi = __builtin_amdgcn_alignbyte(c, b, r & 3u);
 }
+// 16 bytes at ring position pos (unaligned): FIVE aligned dwords + four v_alignbyte -- what a gather costs follows the dwords it
+// fetches (profiles/r04_deflate_experiments.txt), and two lz_ring64 fetch six
+static __device__ __forceinline__ void lz_ring128(const uint8_t* win, uint32_t pos, uint32_t& o0, uint32_t& o1, uint32_t& o2, uint32_t& o3) {
+    const uint32_t r = pos & LZ_WMASK;
+    const uint32_t* w = (const uint32_t*)(win + (r & ~3u));
+    const uint32_t a = w[0], b = w[1], c = w[2], d = w[3], e = w[4];
+    const uint32_t sh = r & 3u;
+    o0 = __builtin_amdgcn_alignbyte(b, a, sh);
+    o1 = __builtin_amdgcn_alignbyte(c, b, sh);
+    o2 = __builtin_amdgcn_alignbyte(d, c, sh);
+    o3 = __builtin_amdgcn_alignbyte(e, d, sh);
+}
 // number of equal leading bytes (0..8) given the XOR of two 8-byte strings
 static __device__ __forceinline__ uint32_t lz_match8(uint32_t xlo, uint32_t xhi) {
     if (xlo) return (uint32_t)(__ffs(xlo) - 1) >> 3;
@@ -375,8 +387,7 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
         // a validity branch around the set-up cost a dozen instructions per claim for registers that had to be defined on both sides.
         const uint32_t p = base + lane;
         uint32_t mylo, myhi, my2, my3;
-        lz_ring64(win, p, mylo, myhi);
-        lz_ring64(win, p + 8u, my2, my3);
+        lz_ring128(win, p, mylo, myhi, my2, my3);
         uint32_t maxlen = p < n ? n - p : 0u;
         maxlen = maxlen > 258u ? 258u : maxlen;
         // links are raw (lz_build_tile): alive if 1 <= distance <= lim
@@ -446,10 +457,8 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                         // extend 16 bytes per round
                         for (;;) {
                             uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
-                            lz_ring64(win, p + l, a0, a1);
-                            lz_ring64(win, p + l + 8u, a2, a3);
-                            lz_ring64(win, cand + l, b0, b1);
-                            lz_ring64(win, cand + l + 8u, b2, b3);
+                            lz_ring128(win, p + l, a0, a1, a2, a3);
+                            lz_ring128(win, cand + l, b0, b1, b2, b3);
                             uint32_t m = lz_match8(a0 ^ b0, a1 ^ b1);
                             if (m == 8u) m += lz_match8(a2 ^ b2, a3 ^ b3);
                             l += m;
