@@ -7,7 +7,9 @@
 # 3. SQ counters of the same launch
 # Everything lands under gpurun_out/TAG; the summaries are printed to stdout (-> profiles/TAG_rocprofv3_summary.csv).
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=${1:-r03}
+# bench.py as the rank itself (WORLD_SIZE set: no launcher in between -- rocprofv3 follows the process it starts)
+export WORLD_SIZE=1 RANK=0 LOCAL_RANK=0
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=${1:-r04}
 cd $R
 mkdir -p $O/$TAG/trace $O/$TAG/fetch $O/$TAG/write $O/$TAG/sq
 rocprofv3 --kernel-trace --stats -d $O/$TAG/trace -o t -- python bench.py --steps 2 --warmup 1 --no-cpu --verify 0 > $O/$TAG/trace_bench.json 2> $O/$TAG/trace.log
