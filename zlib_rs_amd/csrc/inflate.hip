@@ -46,9 +46,12 @@
 enum { DE_STORED_LEN = 1, DE_BLOCK_TYPE, DE_TOO_MANY_SYMS, DE_CODE_LENGTHS_SET, DE_BIT_LENGTH_REPEAT, DE_MISSING_EOB,
        DE_LITLEN_SET, DE_DIST_SET, DE_TOO_FAR_BACK, DE_HEADER_CHECK, DE_CODE };
 #define INF_CHUNK 1024u
-#define RES_RING 6144u               // resolve pass: output history kept in LDS: RES_NEAR + RES_SPAN + 258 + RES_BLK and slack; a
-                                     // multiple of RES_BLK; with the chunk tables 7.75 KiB per stream, twenty streams per CU
-#define RES_NEAR 2560u               // resolve pass: a back-reference further than this reads its source from HBM (final there:
+#define RES_RING 5120u               // resolve pass: output history kept in LDS: RES_NEAR + RES_SPAN + 258 + RES_BLK and slack; a
+                                     // multiple of RES_BLK; with the chunk tables 6.75 KiB per stream, 23 streams per CU.  (Round 4:
+                                     // what this kernel lacks is waves to hide its round trips behind, not ring -- 6144 / 2560 ran at
+                                     // 35.0 ms per 16 Ki streams, 8192 / 4608 at 37.2, 10240 / 6656 at 45.9, this at 31.7; 4096 / 1152
+                                     // with batches of 512 bytes at 33.4: profiles/r04_inflate_experiments.txt)
+#define RES_NEAR 1664u               // resolve pass: a back-reference further than this reads its source from HBM (final there:
                                      // everything in front of the batch has been written back), a nearer one from the ring
 #define RES_BLK 1024u                // resolve pass: bytes staged per load step
 #define RES_SPAN 1024u               // resolve pass: output bytes one batch of holes may span
