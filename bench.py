@@ -424,6 +424,39 @@ def main():
             assert torch.equal(back[t0_ * B:(t0_ + cnt_) * B], data[:cnt_ * B])
         inflate_obj["small_launch"] = {"streams": small, "value": small * B / GIB / small_s, "unit": "GiB/s of output", "ms": small_s * 1e3}
         del d_members
+        # ... and members made by the oracle's level 1: the reference's deflate_quick (deflate/algorithm/quick.rs:12-158) emits nothing but
+        # FIXED-Huffman blocks (inflate/inffixed_tbl.rs:7), which do not re-synchronise -- the fast pass finds its lanes' starts by
+        # walking every bit phase there (inflate.hip inf_fixed_tracks; round 3 decoded such streams 6-8x slower than dynamic ones)
+        M1 = max(1, min(2048, M))
+        members1, mlen1, prod1_s = oracle_members(M1, B, 1, 2, cores)
+        d_m1 = torch.from_numpy(members1).to(dev)
+        d_l1 = torch.from_numpy(mlen1.astype(np.int32)).to(dev)
+        tiles1 = max(1, LS // M1)
+        cnt1 = tiles1 * M1 if LS >= M1 else LS
+        sel1 = torch.arange(cnt1, dtype=torch.int64, device=dev) % M1
+        coff1 = sel1 * members1.shape[1]
+        clen1 = d_l1[sel1].contiguous()
+        e.inflate_batch(d_m1, coff1[:wcount].contiguous(), clen1[:wcount].contiguous(), back, ooff[:wcount].contiguous(), cap[:wcount].contiguous(),
+                        wrap=WRAP_GZIP)
+        torch.cuda.synchronize()
+        back.zero_()
+        timing(True)
+        torch.cuda.synchronize()
+        ti = time.perf_counter()
+        e.inflate_batch(d_m1, coff1, clen1, back, ooff[:cnt1].contiguous(), cap[:cnt1].contiguous(), wrap=WRAP_GZIP, out_len=blen, status=bst)
+        torch.cuda.synchronize()
+        f_s = time.perf_counter() - ti
+        fsums, fcnts = take_timing()
+        timing(False)
+        assert int((bst[:cnt1] != 0).sum().item()) == 0 and int((blen[:cnt1] != B).sum().item()) == 0
+        for t in range(max(1, cnt1 // M1)):
+            assert torch.equal(back[t * M1 * B:(t + 1) * M1 * B], data[:M1 * B]), "inflate of the oracle's level-1 members differs"
+        inflate_obj["level1_fixed_blocks"] = {
+            "streams": cnt1, "value": cnt1 * B / GIB / f_s, "unit": "GiB/s of output", "ratio": M1 * B / float(mlen1.astype(np.int64).sum()),
+            "kernel_ms_per_launch": {"decode": fsums[3] / max(1, fcnts[3]), "resolve": fsums[6] / max(1, fcnts[6])},
+            "input": "%d distinct 1 MiB gzip members made by the CPU oracle at level 1 (the reference's deflate_quick: fixed-Huffman blocks only), "
+                     "tiled to %d streams, one launch; every stream bit-exact on device" % (M1, cnt1)}
+        del d_m1
         # ---- configs[3]: level 1 and level 9 ----
         SW = max(1, min(args.sweep_shards, S))
         out2 = torch.empty((SW, stride), dtype=torch.uint8, device=dev)

@@ -138,6 +138,56 @@ def large_stream_checks(inflate_fn, o, deflate_fn=None, size=1 << 17):
     return n
 
 
+def fixed_code_checks(inflate_fn, o, size=1 << 16):
+    """Streams of FIXED-Huffman blocks (BTYPE 01: Z_FIXED, and what the reference's level 1 emits, deflate/algorithm/quick.rs:12-158)
+    through the batch kernel's fast pass, whose lanes find their starts by walking every bit phase (inflate.hip inf_fixed_tracks):
+    every data class at two levels in one launch of more than 16 streams (the one-wave-per-stream kernel) and one by one (the
+    16-wave kernel), then corrupt and truncated variants with the oracle's exact code per stream, short capacities, and a mix
+    of fixed and dynamic blocks in one stream."""
+    blobs = [o.gen_shard(c, size + 1000 * c) for c in range(8)] + [bytes(size), o.prng_bytes(9, size // 2, 1), b"abcdefgh" * (size // 8)]
+    streams, want = [], []
+    for lvl in (1, 6):
+        for b in blobs:
+            co = zlib.compressobj(lvl, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+            streams.append(co.compress(b) + co.flush()); want.append(b)
+    # fixed and dynamic blocks alternating in one stream (full flush between parts)
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+    part1 = co.compress(blobs[0]) + co.flush(zlib.Z_FULL_FLUSH)
+    mixed = bytearray(part1)
+    rawd = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = rawd.compress(blobs[3]) + rawd.flush(zlib.Z_FULL_FLUSH)
+    rawf = zlib.compressobj(1, zlib.DEFLATED, -15, 8, zlib.Z_FIXED)
+    tail = rawf.compress(blobs[6]) + rawf.flush()
+    whole = blobs[0] + blobs[3] + blobs[6]
+    mixed += body + tail + zlib.adler32(whole).to_bytes(4, "big")
+    streams.append(bytes(mixed)); want.append(whole)
+    outs, st = inflate_fn(streams, [len(w) for w in want], 1)
+    assert [int(x) for x in st] == [0] * len(streams), list(st)
+    assert outs == want
+    for s_, w in list(zip(streams, want))[:4]:          # the 16-wave kernel (launches of a few streams)
+        o1, s1 = inflate_fn([s_], [len(w)], 1)
+        assert int(s1[0]) == 0 and o1[0] == w
+    # corrupt / truncated / short of room: the oracle's code for the exact stream
+    good, d = streams[2], want[2]
+    bad, caps = [], []
+    for at in (3, 100, len(good) // 3, len(good) // 2, len(good) - 9, len(good) - 2):
+        for mask in (0x01, 0x40):
+            b = bytearray(good); b[at] ^= mask
+            bad.append(bytes(b)); caps.append(len(d))
+    for cut in (5, 3000, 4200, 9000, len(good) - 4, len(good) - 1):
+        bad.append(good[:cut]); caps.append(len(d))
+    for cap in (len(d) - 1, len(d) // 2, 1):
+        bad.append(good); caps.append(cap)
+    bad += streams[:8]; caps += [len(w) for w in want[:8]]          # (filling the launch beyond 16 streams)
+    outs, st = inflate_fn(bad, caps, 1)
+    for i, (s_, c) in enumerate(zip(bad, caps)):
+        rc, w, msg = _want(o, s_, c, 1)
+        assert int(st[i]) == rc, (i, int(st[i]), rc, msg)
+        if rc == 0:
+            assert outs[i] == w
+    return len(streams) + len(bad)
+
+
 def jump_resolve_checks(e, o, big=False):
     """the resolve pass for few streams (csrc/resolve_jump.hip: pointer jumping over all output bytes) against the serial
     one-wave-per-stream pass, on the same compressed streams: runs that feed on themselves (dist < len), a 300 KB run of

@@ -145,6 +145,37 @@ def test_streams_with_flush_points_are_decoded_as_segments():
     assert used and max(used) >= 4, used   # the parallel path ran
 
 
+def test_streams_without_flush_points_are_decoded_as_blocks():
+    """inflate() and uncompress() of ordinary streams (no flush points): the device finds the dynamic block headers and decodes the
+    blocks side by side (zmi_inflate_blocks); results and error codes are those of the serial path.  (A process of its own: the
+    library reads its tuning variables once.)"""
+    import re
+    import subprocess
+    import sys
+    code = ("import ctypes as C, os, sys, zlib\n"
+            "sys.path.insert(0, %r)\n"
+            "import oracle_lib, zlib_abi_harness as H, zmi_ctypes\n"
+            "zmi_ctypes.load_emu(rebuild=False)\n"
+            "lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, 'tests', 'emu', 'libzmi355_emu.so')))\n"
+            "o = oracle_lib.load()\n"
+            "print('uncompress cases', H.uncompress_large_checks(lib, o, 1 << 16))\n"
+            "data = b''.join(o.gen_shard(c, 1 << 16) for c in (1, 3, 6, 0))\n"
+            "for wb, comp in ((31, zlib.compressobj(6, zlib.DEFLATED, 31)), (15, zlib.compressobj(9, zlib.DEFLATED, 15)), (-15, zlib.compressobj(1, zlib.DEFLATED, -15))):\n"
+            "    blob = comp.compress(data) + comp.flush()\n"
+            "    for chunk in (len(blob), 50000):\n"
+            "        rc, back, unused = H.inflate_stream(lib, blob + b'xyz', wb, chunk_in=chunk, chunk_out=1 << 17)\n"
+            "        assert rc == 1 and back == data and unused == 3, (wb, chunk, rc, len(back), unused)\n"
+            "print('streams ok')\n") % os.path.join(zmi_ctypes.ROOT, "tests")
+    zmi_ctypes.load_emu()
+    env = dict(os.environ, ZMI_TUNING="1", ZMI_BLOCKS_MIN="20000", ZMI_BLOCKS_GAP="1500", ZMI_ABI_BLOCKS_MIN="20000", ZMI_ABI_TRACE="1", ZMI_SPLIT_TRACE="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "uncompress cases 6" in r.stdout and "streams ok" in r.stdout, (r.stdout[-400:], r.stderr[-1200:])
+    used = [int(m) for m in re.findall(r"(\d+) blocks decoded side by side", r.stderr)]
+    assert used and max(used) >= 4, used   # the parallel path ran through inflate()
+    segs = [int(m) for m in re.findall(r"are block headers, (\d+) segments", r.stderr)]
+    assert segs and max(segs) >= 4, segs
+
+
 def test_host_checksums_match_zlib_at_every_length_and_alignment():
     """crc32() / adler32() of the drop-in library (csrc/host_sums.cpp: carry-less-multiply folding and SSSE3 sums with scalar
     heads and tails) against Python's zlib: lengths around the block sizes of the vector paths, odd offsets, running values"""

@@ -384,6 +384,11 @@ def test_inflate_large_streams_fast_pass(eng, o):
     assert parity_checks.large_stream_checks(eng.inflate, o, lambda blobs, lvl, wrap: eng.deflate(blobs, level=lvl, wrap=wrap)) > 60
 
 
+def test_fixed_code_streams_through_the_fast_pass(eng, o):
+    """BTYPE 01 blocks: the fast pass finds its lanes' starts by walking every bit phase (no self-synchronisation to live on)"""
+    assert parity_checks.fixed_code_checks(eng.inflate, o) > 40
+
+
 def test_truncated_stored_blocks_match_the_oracle():
     e = zmi_ctypes.Engine(zmi_ctypes.load_emu())
     assert parity_checks.truncated_stored_checks(lambda streams, caps, wrap: e.inflate(streams, caps, wrap=wrap), oracle_lib.load()) == 8

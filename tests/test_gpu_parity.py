@@ -442,6 +442,13 @@ def test_truncated_stored_blocks_match_the_oracle_on_gpu(engine):
     assert parity_checks.truncated_stored_checks(_inflate_fn(engine), oracle_lib.load(rebuild=False)) == 8
 
 
+def test_fixed_code_streams_through_the_fast_pass_on_gpu(engine):
+    """BTYPE 01 blocks (Z_FIXED, the reference's level 1): every class, corrupt / truncated variants with the oracle's codes"""
+    import oracle_lib
+    import parity_checks
+    assert parity_checks.fixed_code_checks(_inflate_fn(engine), oracle_lib.load(rebuild=False), size=1 << 19) > 40
+
+
 def test_split_inflate_equals_serial_inflate_on_gpu():
     """one stream decoded as segments cut at its flush points, on the whole chip (zmi_inflate_split): the results of the
     serial zmi_inflate_resume for true markers, false ones, history, corruption, short room"""
@@ -451,6 +458,28 @@ def test_split_inflate_equals_serial_inflate_on_gpu():
     eng = zmi_ctypes.Engine(zmi_ctypes.load_product())
     assert parity_checks.split_inflate_checks(eng, oracle_lib.load(rebuild=False), big=True) == 12
     eng.close()
+
+
+def test_block_scan_inflate_equals_serial_inflate_on_gpu():
+    """one stream WITHOUT flush points: the device finds its dynamic block headers (csrc/blockscan.hip) and decodes the blocks
+    side by side (zmi_inflate_blocks) -- the results of the serial zmi_inflate_resume for streams of the system zlib and of the
+    oracle, stored / fixed blocks and decoy headers in between, history, truncation, corruption, short room, a start inside a byte"""
+    import oracle_lib
+    import parity_checks
+    import zmi_ctypes
+    eng = zmi_ctypes.Engine(zmi_ctypes.load_product())
+    assert parity_checks.blocks_inflate_checks(eng, oracle_lib.load(rebuild=False), big=True) == 14
+    eng.close()
+
+
+def test_uncompress_of_a_large_stream_takes_the_parallel_path_and_keeps_the_reference_codes():
+    """uncompress() of streams of 256 KiB and more goes through zmi_inflate_blocks (tests/zlib_abi_harness.py::uncompress_large_checks)"""
+    import ctypes as C
+    import oracle_lib
+    import zlib_abi_harness as H
+    from zlib_rs_amd import _build
+    lib = H.bind(C.CDLL(_build.ABI_LIB))
+    assert H.uncompress_large_checks(lib, oracle_lib.load(rebuild=False), 1 << 20) == 6
 
 
 def test_jump_resolve_equals_serial_resolve_on_gpu():

@@ -1482,3 +1482,38 @@ def flush_point_stream_checks(lib, o, seeds, big=False):
             assert back == want and rc in (Z_OK, Z_STREAM_END, Z_BUF_ERROR), (seed, "corrupt-but-valid", rc)
         n_cases += 3
     return n_cases
+
+
+def uncompress_large_checks(lib, o, n_each):
+    """uncompress() on the parallel-blocks path (zlib_abi.hip uncompress2_z -> zmi_inflate_blocks): what does not come back as a
+    plain complete stream -- short room, a wrong Adler-32, corrupt data, truncation -- reports what the reference reports
+    (zlib-rs/src/inflate.rs:202-284); shared by the emulator and the MI355X test"""
+    import zlib
+    data = b"".join(o.gen_shard(c, n_each) for c in (0, 3, 4, 6))
+    z = zlib.compress(data, 6)
+
+    def run(blob, room):
+        dst = C.create_string_buffer(max(1, room))
+        dl = C.c_ulong(room)
+        rc = lib.uncompress(dst, C.byref(dl), blob, len(blob))
+        return rc, dst.raw[:dl.value]
+
+    rc, out = run(z, len(data))
+    assert rc == Z_OK and out == data
+    rc, out = run(z + b"trailing garbage", len(data) + 100)          # bytes behind the stream are not an error for uncompress
+    assert rc == Z_OK and out == data
+    rc, out = run(z, len(data) - 1)                                  # one byte short of room
+    assert rc == Z_BUF_ERROR
+    bad = bytearray(z); bad[-1] ^= 1                                  # wrong check value
+    rc, out = run(bytes(bad), len(data))
+    assert rc == Z_DATA_ERROR
+    bad = bytearray(z); bad[len(z) // 2] ^= 0x20                      # corrupt data: whatever the system zlib makes of it
+    try:
+        zlib.decompress(bytes(bad)); ok = True
+    except zlib.error:
+        ok = False
+    rc, out = run(bytes(bad), len(data))
+    assert (rc == Z_OK) == ok and (ok or rc == Z_DATA_ERROR), rc
+    rc, out = run(z[:len(z) * 2 // 3], len(data))                    # truncated
+    assert rc == Z_DATA_ERROR
+    return 6

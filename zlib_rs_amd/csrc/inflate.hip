@@ -555,11 +555,168 @@ static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, co
     return R;
 }
 
+
+// ---- blocks coded with the FIXED Huffman code (BTYPE 01; inflate/inffixed_tbl.rs:7): where do the lanes of a fast pass start?
+// The warm-up walk of inf_fast_pass lives on the self-synchronisation of a prefix code, and the fixed code over literal-dense
+// data has next to none: its literals are 8 (or 9) bits long, so a walk started off the true token chain reads 8-bit codes of
+// a shifted alphabet and keeps its phase error for thousands of bits (measured on Z_FIXED streams of the benchmark classes:
+// median > 20 000 bits; round 3: few lanes committed per pass, 6-8x the time of the same data with dynamic codes -- and the
+// reference's own level 1, deflate/algorithm/quick.rs:12-158, emits nothing but such blocks).  But the fixed code needs no
+// tables to be DELIMITED: a token's length follows from its first bits by a handful of compares.  So every lane walks its
+// sub-sequence from every bit offset at which the chain could enter it, with a table-free walker that only counts bits, and
+// notes (a) which of its walks (tracks) passes through each of the first 32 bit offsets and (b) where each track leaves the
+// sub-sequence.  The true chain is then a walk over the lanes with two small lookups per lane -- "the token chain enters
+// lane k at offset o: track map_k[o] is on it, and leaves at exit_k[track]" -- after which every lane knows its true first
+// token and the pass continues as for a dynamic block, with nothing to fix.
+// Cost: 8-10 bit-counting walks (~12 instructions a token against ~62 of the table walk) instead of a warm-up and the restart rounds.
+struct InfFixedStep { uint32_t adv; uint32_t stop; };   // bits of the token at the low end of `lo` (>= 32 significant bits); stop: 1 invalid, 2 end of block
+static __device__ __forceinline__ InfFixedStep inf_fixed_step(uint32_t lo, uint32_t hi) {
+    InfFixedStep R;
+    const uint32_t r = __brev(lo);                 // the code's bits, first bit on top
+    const uint32_t c7 = r >> 25, c8 = r >> 24;
+    // 7 bits 0000000 .. 0010111: symbols 256 .. 279; 8 bits 00110000 .. 10111111: literals 0 .. 143; 11000000 .. 11000111: 280 .. 287;
+    // 9 bits 110010000 .. 111111111: literals 144 .. 255
+    const bool s7 = c7 < 24u, l8 = c8 >= 0x30u && c8 < 0xC0u, s8 = c8 >= 0xC0u && c8 < 0xC8u;
+    const uint32_t bits = s7 ? 7u : ((l8 || s8) ? 8u : 9u);
+    const uint32_t sym = s7 ? 256u + c7 : (s8 ? 280u + (c8 - 0xC0u) : 0u);   // 0: a literal
+    R.stop = sym == 256u ? 2u : (sym >= 286u ? 1u : 0u);
+    uint32_t adv = bits;
+    if (sym > 256u && sym < 286u) {
+        const uint32_t idx = sym - 257u;
+        const uint32_t xb = (idx < 8u || idx == 28u) ? 0u : (idx >> 2) - 1u;
+        adv += xb;
+        // the distance code: 5 bits, first bit on top, then its extra bits
+        const uint64_t w = ((uint64_t)hi << 32) | lo;
+        const uint32_t d = __brev((uint32_t)(w >> adv)) >> 27;
+        if (d >= 30u) R.stop = 1u;
+        adv += 5u + (d < 4u ? 0u : (d >> 1) - 1u);
+    }
+    R.adv = adv;
+    return R;
+}
+// all lanes: the true first token of every lane's sub-sequence [p_rel + lane * sub, p_rel + (lane + 1) * sub) of a fixed-code
+// block staged in fb, given that a token starts at p_rel.  Returns the number of leading lanes whose start is known (the
+// chain ends early where the walkers met an invalid code / an end of block, or where a lane has more than 15 distinct tracks:
+// the lanes behind it start at a guess, as in a dynamic block); *start receives the lane's start.
+// TRACKS: a token of the fixed code has at most 31 bits, so the chain enters a sub-sequence at one of its first 31 bit offsets.
+// A lane walks from every offset 0 .. 31 that no earlier walk of its own has passed through (a walk that steps on a visited
+// offset has merged into that track: same exit) -- in the 8-bit regime of literal-dense data that is eight walks (offsets
+// j, j + 8, j + 16, j + 24 are one track), around matches a few more that merge within a token or two.
+// (four named registers and selects: an array indexed with a lane-varying offset would be placed in scratch memory)
+struct InfQuad { uint32_t a, b, c, d; };
+static __device__ __forceinline__ uint32_t quad_pick(const InfQuad& q, uint32_t r) { return r == 0u ? q.a : (r == 1u ? q.b : (r == 2u ? q.c : q.d)); }
+static __device__ __forceinline__ void quad_or(InfQuad& q, uint32_t r, uint32_t v) {
+    q.a |= r == 0u ? v : 0u; q.b |= r == 1u ? v : 0u; q.c |= r == 2u ? v : 0u; q.d |= r == 3u ? v : 0u;
+}
+struct InfFixedMaps {
+    InfQuad map;   // 32 offsets x 4 bits: the track that passes through the offset (1 .. 15; 0: none)
+    InfQuad ex;    // 16 tracks x 8 bits: the offset behind the boundary at which the track leaves (0xFF: it stopped inside)
+};
+static __device__ __forceinline__ InfFixedMaps inf_fixed_tracks(const uint8_t* fb, uint32_t p_rel, uint32_t sub, bool active) {
+    const uint32_t lane = zmi_lane();
+    const uint32_t* fw = (const uint32_t*)fb;
+    const uint32_t nominal = p_rel + lane * sub, boundary = nominal + sub;
+    InfFixedMaps F;
+    F.map.a = F.map.b = F.map.c = F.map.d = 0u;
+    F.ex.a = F.ex.b = F.ex.c = F.ex.d = 0u;
+    bool busy = active;
+    for (uint32_t t = 1; t < 16u; ++t) {
+        // the lowest offset that no track has passed through yet (a zero nibble of the map)
+        uint32_t o = 32u;
+        if (busy) {
+#pragma unroll
+            for (int r = 3; r >= 0; --r) {
+                const uint32_t x = r == 3 ? F.map.d : (r == 2 ? F.map.c : (r == 1 ? F.map.b : F.map.a));
+                const uint32_t z = ~(x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u;   // bit 4 n set: nibble n is zero
+                o = z ? 8u * (uint32_t)r + ((uint32_t)(__ffs((int)z) - 1) >> 2) : o;
+            }
+            // (offset 31 is never entered: the longest token has 31 bits, a token that started inside the lane below ends at offset 30 at the latest)
+            busy = o < 31u;
+        }
+        if (__ballot(busy) == 0ull) break;
+        if (busy) {
+            uint32_t pos = nominal + o, code = 0xFFu;
+            bool open = true;
+            // the first 32 bits: token by token, every offset passed is claimed for this track (or found claimed: merged)
+            while (pos - nominal < 32u) {
+                const uint32_t oo = pos - nominal;
+                const uint32_t u = (quad_pick(F.map, oo >> 3) >> (4u * (oo & 7u))) & 15u;
+                if (u != 0u) { code = (quad_pick(F.ex, u >> 2) >> (8u * (u & 3u))) & 0xFFu; open = false; break; }   // merged into track u: its exit
+                quad_or(F.map, oo >> 3, t << (4u * (oo & 7u)));
+                if (pos >= boundary) { code = pos - boundary; open = false; break; }
+                const uint32_t wi = pos >> 5, sh = pos & 31u;
+                const uint32_t d0 = fw[wi], d1 = fw[wi + 1u], d2 = fw[wi + 2u];
+                const InfFixedStep T = inf_fixed_step(__builtin_amdgcn_alignbit(d1, d0, sh), __builtin_amdgcn_alignbit(d2, d1, sh));
+                if (T.stop != 0u) { open = false; break; }
+                pos += T.adv;
+            }
+            // the rest of the sub-sequence: nothing to note but where the walk leaves it.  Literals -- the bulk of the tokens where
+            // this code is used -- are taken up to three from one 32-bit window (8 or 9 bits each, told apart by one compare)
+            while (open) {
+                if (pos >= boundary) { code = pos - boundary; break; }
+                const uint32_t wi = pos >> 5, sh = pos & 31u;
+                const uint32_t d0 = fw[wi], d1 = fw[wi + 1u];
+                const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, sh);
+                const uint32_t r = __brev(lo);
+                uint32_t c8 = r >> 24;
+                if (c8 >= 0x30u && (c8 < 0xC0u || c8 >= 0xC8u)) {
+                    uint32_t used = c8 >= 0xC8u ? 9u : 8u;
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        c8 = (r << used) >> 24;
+                        const bool lit = c8 >= 0x30u && (c8 < 0xC0u || c8 >= 0xC8u);
+                        if (!lit || pos + used >= boundary) break;
+                        used += c8 >= 0xC8u ? 9u : 8u;
+                    }
+                    pos += used;
+                    continue;
+                }
+                const uint32_t d2 = fw[wi + 2u];
+                const InfFixedStep T = inf_fixed_step(lo, __builtin_amdgcn_alignbit(d2, d1, sh));
+                if (T.stop != 0u) break;
+                pos += T.adv;
+            }
+            quad_or(F.ex, t >> 2, code << (8u * (t & 3u)));
+        }
+    }
+    return F;
+}
+// the chain over the 64 lanes of a wave, entered at bit offset `off` of lane 0 (wave-uniform): *mine = the offset at which it
+// enters this lane, *out = the offset at which it leaves lane 63 (0xFF: it ended inside the wave); returns the number of leading
+// lanes whose entry is known
+static __device__ __forceinline__ uint32_t inf_fixed_chain(const InfFixedMaps& F, uint32_t off, uint32_t* mine_out, uint32_t* out) {
+    const uint32_t lane = zmi_lane();
+    uint32_t known = 0u, mine = 0u;
+    *out = 0xFFu;
+    for (uint32_t k = 0; k < 64u; ++k) {
+        if (lane == k) mine = off;
+        known = k + 1u;
+        if (off >= 31u) break;
+        const uint32_t mw = off < 8u ? zmi_readlane(F.map.a, k) : (off < 16u ? zmi_readlane(F.map.b, k) : (off < 24u ? zmi_readlane(F.map.c, k) : zmi_readlane(F.map.d, k)));
+        const uint32_t u = (mw >> (4u * (off & 7u))) & 15u;
+        if (u == 0u) break;                                   // (more than 15 tracks in lane k: the lanes behind it start at a guess)
+        const uint32_t ew = u < 4u ? zmi_readlane(F.ex.a, k) : (u < 8u ? zmi_readlane(F.ex.b, k) : (u < 12u ? zmi_readlane(F.ex.c, k) : zmi_readlane(F.ex.d, k)));
+        const uint32_t e = (ew >> (8u * (u & 3u))) & 0xFFu;
+        if (e == 0xFFu) break;                                // an end of block / invalid code inside lane k: the chain ends there
+        off = e;
+        if (k == 63u) *out = e;
+    }
+    *mine_out = mine;
+    return known;
+}
+static __device__ __forceinline__ uint32_t inf_fixed_sync(const uint8_t* fb, uint32_t p_rel, uint32_t sub, uint32_t* start) {
+    const InfFixedMaps F = inf_fixed_tracks(fb, p_rel, sub, true);
+    uint32_t mine = 0u, out = 0u;
+    const uint32_t known = inf_fixed_chain(F, 0u, &mine, &out);
+    *start = p_rel + zmi_lane() * sub + mine;
+    return known;
+}
+
 // One fast pass from bit P of the stream.  Returns the number of lanes committed (0: nothing done); *bits_used / *out_made
 // / *hit_eob describe what was committed.  All lanes call.
 static __device__ __forceinline__ uint32_t inf_fast_pass(InfShared* S, const uint8_t* src, uint64_t P, uint8_t* dst,
                                                       uint32_t* bm32, uint32_t opos, uint32_t cap, uint32_t hist, uint32_t sub,
-                                                      uint32_t* bits_used, uint32_t* out_made, uint32_t* hit_eob) {
+                                                      uint32_t* bits_used, uint32_t* out_made, uint32_t* hit_eob, bool fixed_code) {
     // sub: bits per lane, 96 .. INF_SUB_BITS (wave-uniform; see the caller for how it is chosen)
     const uint32_t lane = zmi_lane();
     // stage the input: from the 16-byte line holding bit P, 4 KiB, four coalesced loads
@@ -576,7 +733,12 @@ static __device__ __forceinline__ uint32_t inf_fast_pass(InfShared* S, const uin
     // through the tail of the sub-sequence below: after INF_WARM_BITS most walks are in step already, so the first full
     // walk is usually the right one and the restart round below has few (often no) lanes to fix.
     uint32_t start = p_rel + lane * sub;
-    {
+    if (fixed_code) {
+        // the fixed code does not re-synchronise, but it can be delimited without tables: the lanes' true starts (inf_fixed_sync)
+        uint32_t fs = start;
+        const uint32_t known = inf_fixed_sync(S->fb, p_rel, sub, &fs);
+        if (lane < known) start = fs;
+    } else {
         // (lane 0 rides along switched off: it must still hold a position inside the staged bytes, its reads happen; with
         // short sub-sequences the lowest lanes warm up from the pass's own first bit, which is a true token start)
         const uint32_t wfrom = start - p_rel > INF_WARM_BITS ? start - INF_WARM_BITS : p_rel;
@@ -650,6 +812,8 @@ struct InfMulti {
     uint32_t nsum[INF_MW];     // output bytes of the lanes it would commit,
     uint32_t cut[INF_MW];      // first of those lanes that must not be committed (64: none)
     uint32_t res_lanes, res_bits, res_out, res_eob;
+    uint32_t fixed;            // the block is coded with the fixed code: the lanes' starts come from inf_fixed_tracks / inf_fixed_chain
+    uint32_t fx_off[INF_MW + 1u];   // ... the offset at which the token chain enters wave w (0xFF: not known)
 };
 __shared__ InfMulti g_inf_mw;
 
@@ -684,6 +848,26 @@ static __device__ __noinline__ void inf_pass_mw(const uint8_t* src, uint8_t* dst
         p_rel = ((mis + back) << 3) | ((uint32_t)Pw & 7u);
         boundary = p_rel + (lane + 1u) * sub;
         start = p_rel + lane * sub;
+    }
+    const bool fixed_code = zmi_uniform(M->fixed) != 0u;
+    if (fixed_code) {
+        // fixed code: every wave finds its tracks at once; the chain then runs through the waves in order (a wave's turn is a few
+        // hundred scalar reads: the walks above it are what costs), each wave handing the next the offset it enters at
+        InfFixedMaps F = inf_fixed_tracks(fb, p_rel, sub, act);
+        if (wave == 0u && lane == 0u) M->fx_off[0] = 0u;
+        for (uint32_t w = 0; w < nact; ++w) {
+            __syncthreads();
+            if (wave == w) {
+                const uint32_t entry = zmi_uniform(M->fx_off[w]);
+                uint32_t mine = 0u, out = 0xFFu, known = 0u;
+                if (entry != 0xFFu) known = inf_fixed_chain(F, entry, &mine, &out);
+                if (lane < known) start += mine;
+                if (lane == 0u) M->fx_off[w + 1u] = known == 64u ? out : 0xFFu;
+            }
+        }
+        __syncthreads();
+        if (act) R = inf_lane_decode<false>(S, fb, start, boundary, true, nullptr, nullptr, 0u, 0u);
+    } else if (act) {
         {
             const bool warm = lane != 0u || wave != 0u;
             const uint32_t wfrom = (wave != 0u || start - p_rel > INF_WARM_BITS) ? start - INF_WARM_BITS : p_rel;
@@ -1137,14 +1321,14 @@ __global__ void __launch_bounds__(64 * NW) zmi_inflate_kernel(const uint8_t* __r
                             if (lane == 0) {
                                 InfMulti* M = &g_inf_mw;
                                 M->cmd = 1u; M->nact = nact; M->sub = sub; M->Plo = (uint32_t)P; M->Phi = (uint32_t)(P >> 32);
-                                M->opos = opos; M->cap = cap; M->hist = hist;
+                                M->opos = opos; M->cap = cap; M->hist = hist; M->fixed = fixed_ready;
                             }
                             __syncthreads();
                             inf_pass_mw(B.src, dst, bm32);
                             lanes = zmi_uniform(g_inf_mw.res_lanes);
                             if (lanes != 0u) { fbits = zmi_uniform(g_inf_mw.res_bits); fout = zmi_uniform(g_inf_mw.res_out); feob = zmi_uniform(g_inf_mw.res_eob); }
                         } else
-                        lanes = zmi_uniform(inf_fast_pass(S, B.src, P, dst, bm32, opos, cap, hist, sub, &fbits, &fout, &feob));
+                        lanes = zmi_uniform(inf_fast_pass(S, B.src, P, dst, bm32, opos, cap, hist, sub, &fbits, &fout, &feob, fixed_ready != 0u));
                         B.cbase = -(int32_t)(2u * INF_CHUNK);   // the pass staged its input over the token rounds' chunk
                         if (lanes < 8u && sub >= 288u) { fskip_len = fskip_len == 0u ? 4u : (fskip_len < 64u ? fskip_len * 2u : 64u); fskip = fskip_len; }
                         else if (lanes >= 32u) fskip_len = 0u;

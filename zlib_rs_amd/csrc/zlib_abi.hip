@@ -1694,7 +1694,8 @@ int uncompress2_z(Bytef* dest, z_size_t* destLen, const Bytef* source, z_size_t*
     // A large stream: the blocks are found on the device and decoded side by side, straight into the caller's buffer
     // (zmi_inflate_blocks).  Only the plain outcome is taken from here -- a complete stream that fits, with its Adler-32 right;
     // everything else (errors, short room, FDICT) goes the way it always went, which names the reference's codes.
-    if (*sourceLen >= ((z_size_t)256 << 10) && *sourceLen < ((z_size_t)1 << 28) && room >= 1 && room <= ((z_size_t)1 << 30) && split_enabled()) {
+    static const z_size_t kBlocksMin = [] { const char* e = abi_tune("ZMI_ABI_BLOCKS_MIN"); return e && atol(e) > 0 ? (z_size_t)atol(e) : (z_size_t)256 << 10; }();
+    if (*sourceLen >= kBlocksMin && *sourceLen < ((z_size_t)1 << 28) && room >= 1 && room <= ((z_size_t)1 << 30) && split_enabled()) {
         const uint32_t cmf = source[0], flg = source[1];
         if ((cmf & 0x0Fu) == 8u && (cmf >> 4) <= 7u && ((cmf << 8) | flg) % 31u == 0u && !(flg & 0x20u)) {
             AbiLease lease;
