@@ -932,7 +932,9 @@ static int zmi_split_core(zmi_ctx* c, const uint8_t* in, uint32_t in_len, uint32
     }
     uint32_t ol2 = 0, used2 = 0, res2[4] = {0, 0, 0, 0};
     int32_t st2 = 0, det2 = 0;
-    rc = zmi_inflate_resume(c, in + at, in_len - at, 0u, h2.data(), (uint32_t)h2.size(), out + done, out_cap - done, &ol2, &st2, &det2, &used2, res2);
+    // (a cut found by the block scan lies at a bit: the rest starts there)
+    rc = zmi_inflate_resume(c, in + at, in_len - at, tail == 0u ? in_bit : (seg_bit ? seg_bit[tail] : 0u), h2.data(), (uint32_t)h2.size(), out + done,
+                            out_cap - done, &ol2, &st2, &det2, &used2, res2);
     if (rc) return rc;
     *out_len = done + ol2; *status = st2; *detail = det2; *in_used = at + used2;
     resume[0] = at + res2[0]; resume[1] = res2[1]; resume[2] = done + res2[2]; resume[3] = res2[3];
