@@ -373,39 +373,36 @@ static __device__ void enc_huff_lengths_w(EncShared* S, const uint32_t* freq, ui
     zmi_wave_sync();
 }
 
-// ---- all lanes: canonical codes (bit-reversed for LSB-first emission), as gen_codes ----
-// A symbol's code is next[len] + its rank among the lower-indexed symbols of the same length: ballot + mbcnt per
-// length and chunk of 64 symbols (LDS atomics would not do: a wave's same-address atomics are not applied in lane order).
-static __device__ void enc_gen_codes_w(EncShared* S, const uint8_t* lens, uint32_t nsym, uint32_t maxbits, uint32_t* table) {
+// ---- all lanes: canonical codes (bit-reversed for LSB-first emission), as gen_codes (trees.rs) ----
+// A symbol's code is next[len] + its rank among the lower-indexed symbols of the same length.  Everything stays in registers
+// and wave-uniform masks: per length one ballot per chunk of 64 symbols gives the rank (mbcnt) and the count (popcount) that
+// moves next[] on -- no histogram in LDS, no serial pass of lane 0 (round 4).
+template <uint32_t NCH>
+static __device__ void enc_gen_codes_w(const uint8_t* lens, uint32_t nsym, uint32_t maxbits, uint32_t* table) {
     const uint32_t lane = zmi_lane();
-    if (lane < 16u) S->cnt[lane] = 0;
-    zmi_wave_sync();
-    for (uint32_t i = lane; i < nsym; i += 64u) atomicAdd(&S->cnt[lens[i]], 1u);
-    zmi_wave_sync();
-    if (lane == 0) {
-        S->cnt[0] = 0;
-        uint32_t code = 0;
-        for (uint32_t d = 1; d <= maxbits; ++d) {
-            code = (code + S->cnt[d - 1u]) << 1;
-            S->next[d] = code;
-        }
+    uint32_t l[NCH], code[NCH];
+#pragma unroll
+    for (uint32_t c = 0; c < NCH; ++c) {
+        const uint32_t i = lane + 64u * c;
+        l[c] = i < nsym ? lens[i] : 0u;
+        code[c] = 0;
     }
-    zmi_wave_sync();
-    for (uint32_t base = 0; base < nsym; base += 64u) {
-        const uint32_t i = base + lane;
-        const uint32_t l = i < nsym ? lens[i] : 0u;
-        uint32_t code = 0;
-        for (uint32_t d = 1; d <= maxbits; ++d) {
-            const uint64_t m = __ballot(l == d);
-            if (m) {   // uniform
-                const uint32_t nx = zmi_uniform(S->next[d]);
-                if (l == d) code = nx + zmi_mbcnt(m);
-                zmi_wave_sync();
-                if (lane == 0) S->next[d] = nx + (uint32_t)__popcll(m);
-                zmi_wave_sync();
-            }
+    uint32_t next = 0, count = 0;
+    for (uint32_t d = 1; d <= maxbits; ++d) {
+        next = (next + count) << 1;
+        uint32_t at = next;
+#pragma unroll
+        for (uint32_t c = 0; c < NCH; ++c) {
+            const uint64_t m = __ballot(l[c] == d);
+            if (l[c] == d) code[c] = at + zmi_mbcnt(m);
+            at += (uint32_t)__popcll(m);
         }
-        if (i < nsym) table[i] = l ? ((__brev(code) >> (32u - l)) | (l << 16)) : 0u;
+        count = at - next;
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < NCH; ++c) {
+        const uint32_t i = lane + 64u * c;
+        if (i < nsym) table[i] = l[c] ? ((__brev(code[c]) >> (32u - l[c])) | (l[c] << 16)) : 0u;
     }
     zmi_wave_sync();
 }
@@ -434,25 +431,59 @@ static __device__ void enc_header_plan_w(EncShared* S) {
         const uint32_t i = lane + 64u * c;
         lr[c] = i < hlit ? S->llen[i] : (i < total ? S->dlen[i - hlit] : 0xFFu);
     }
-    uint32_t hc = 0;
+    // Run-length coding, all runs at once (round 4; a scalar walk over the ~300 lengths was a tenth of the kernel): an entry
+    // opens a run if it differs from the one in front of it (ballots: 5 x 64 wave-uniform bits, entry `total` closes the last
+    // run), the run's length is the distance to the next set bit, the number of header symbols a run becomes has a closed form,
+    // a prefix sum places it, and each run's lane writes its symbols.  Same symbols as trees.rs `scan_tree` would produce for the
+    // two codes written as one sequence (RFC 1951 3.2.7 allows runs across the boundary).
+    uint64_t sm[5];
     {
-        uint32_t v = enc_rd5(lr, 0), run = 1;
-        for (uint32_t i = 1; i <= total; ++i) {
-            const uint32_t u = i < total ? enc_rd5(lr, i) : 0x100u;   // 0x100: no length has this value, closes the last run
-            if (u == v) { ++run; continue; }
-            // emit the run of `run` lengths of value v (stores by lane 0; the scan itself is wave-uniform)
-            if (v == 0u) {
-                while (run >= 11u) { uint32_t r = run > 138u ? 138u : run; if (lane == 0) { S->hsym[hc] = 18; S->hext[hc] = (uint8_t)(r - 11u); } ++hc; run -= r; }
-                if (run >= 3u) { if (lane == 0) { S->hsym[hc] = 17; S->hext[hc] = (uint8_t)(run - 3u); } ++hc; run = 0; }
-                while (run > 0u) { if (lane == 0) { S->hsym[hc] = 0; S->hext[hc] = 0; } ++hc; --run; }
-            } else {
-                if (lane == 0) { S->hsym[hc] = (uint8_t)v; S->hext[hc] = 0; }
-                ++hc; --run;
-                while (run >= 3u) { uint32_t r = run > 6u ? 6u : run; if (lane == 0) { S->hsym[hc] = 16; S->hext[hc] = (uint8_t)(r - 3u); } ++hc; run -= r; }
-                while (run > 0u) { if (lane == 0) { S->hsym[hc] = (uint8_t)v; S->hext[hc] = 0; } ++hc; --run; }
-            }
-            v = u;
-            run = 1;
+        uint32_t carry = 0x1FFu;   // "the length in front of entry 0": equal to none
+#pragma unroll
+        for (uint32_t c = 0; c < 5u; ++c) {
+            uint32_t pv = zmi_lane_up1(lr[c]);
+            if (lane == 0u) pv = carry;
+            sm[c] = __ballot(lr[c] != pv);   // (entries past `total` all read 0xFF: no run starts behind the closing one)
+            carry = zmi_readlane(lr[c], 63u);
+        }
+    }
+    uint32_t fa[5];   // first run start in the chunks behind chunk c
+    fa[4] = 320u;
+#pragma unroll
+    for (int c = 3; c >= 0; --c) fa[c] = sm[c + 1] ? 64u * (uint32_t)(c + 1) + (uint32_t)__ffsll((unsigned long long)sm[c + 1]) - 1u : fa[c + 1];
+    uint32_t run[5], cnt[5], off[5];
+    uint32_t hc = 0;
+#pragma unroll
+    for (uint32_t c = 0; c < 5u; ++c) {
+        const uint32_t i = lane + 64u * c;
+        const bool start = ((sm[c] >> lane) & 1ull) != 0ull && i < total;
+        const uint64_t above = lane < 63u ? sm[c] >> (lane + 1u) : 0ull;
+        const uint32_t nxt = above ? i + (uint32_t)__ffsll((unsigned long long)above) : fa[c];
+        const uint32_t r = start ? nxt - i : 0u;
+        uint32_t n = 0;
+        if (start) {
+            if (lr[c] == 0u) { const uint32_t q = r / 138u, m = r - 138u * q; n = q + (m >= 3u ? 1u : m); }
+            else { const uint32_t q = (r - 1u) / 6u, m = (r - 1u) - 6u * q; n = 1u + q + (m >= 3u ? 1u : m); }
+        }
+        run[c] = r;
+        cnt[c] = n;
+        const uint32_t incl = zmi_wave_incl_scan(n);
+        off[c] = hc + incl - n;
+        hc += zmi_readlane(incl, 63u);
+    }
+#pragma unroll
+    for (uint32_t c = 0; c < 5u; ++c) {
+        if (cnt[c] == 0u) continue;
+        const uint32_t v = lr[c];
+        uint32_t r = run[c], o = off[c];
+        if (v == 0u) {
+            while (r >= 11u) { const uint32_t t = r > 138u ? 138u : r; S->hsym[o] = 18; S->hext[o] = (uint8_t)(t - 11u); ++o; r -= t; }
+            if (r >= 3u) { S->hsym[o] = 17; S->hext[o] = (uint8_t)(r - 3u); ++o; r = 0; }
+            while (r > 0u) { S->hsym[o] = 0; S->hext[o] = 0; ++o; --r; }
+        } else {
+            S->hsym[o] = (uint8_t)v; S->hext[o] = 0; ++o; --r;
+            while (r >= 3u) { const uint32_t t = r > 6u ? 6u : r; S->hsym[o] = 16; S->hext[o] = (uint8_t)(t - 3u); ++o; r -= t; }
+            while (r > 0u) { S->hsym[o] = (uint8_t)v; S->hext[o] = 0; ++o; --r; }
         }
     }
     if (lane < 32u) S->blfreq[lane] = 0;
@@ -461,7 +492,7 @@ static __device__ void enc_header_plan_w(EncShared* S) {
     zmi_wave_sync();
     enc_rank_sort(S, S->blfreq, ENC_NBL);
     enc_huff_lengths_w(S, S->blfreq, ENC_NBL, zmi_uniform(S->misc[M_NNZ]), 7u, S->bllen);
-    enc_gen_codes_w(S, S->bllen, ENC_NBL, 7u, S->blcode);
+    enc_gen_codes_w<1>(S->bllen, ENC_NBL, 7u, S->blcode);
     const uint8_t blorder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
     const uint64_t used = __ballot(lane < 19u && S->bllen[blorder[lane < 19u ? lane : 0u]] != 0);
     uint32_t hclen = used ? 64u - (uint32_t)__clzll((unsigned long long)used) : 0u;
@@ -597,8 +628,8 @@ static __device__ __noinline__ EncWriter enc_flush_block(EncShared* S, EncWriter
             }
             enc_emit_group16(S, W, bits, nb);
         }
-        enc_gen_codes_w(S, S->llen, 286u, 15u, S->lcode);
-        enc_gen_codes_w(S, S->dlen, 30u, 15u, S->dcode);
+        enc_gen_codes_w<5>(S->llen, 286u, 15u, S->lcode);
+        enc_gen_codes_w<1>(S->dlen, 30u, 15u, S->dcode);
     } else if (choice == 1u) {
         if (lane == 0) {
             uint32_t rel = W.rel;
@@ -610,8 +641,8 @@ static __device__ __noinline__ EncWriter enc_flush_block(EncShared* S, EncWriter
         zmi_wave_sync();
         W.rel = zmi_uniform(S->misc[M_REL]);
         enc_flush(S, W);
-        enc_gen_codes_w(S, S->llen, ENC_NL, 15u, S->lcode);
-        enc_gen_codes_w(S, S->dlen, 30u, 15u, S->dcode);
+        enc_gen_codes_w<5>(S->llen, ENC_NL, 15u, S->lcode);
+        enc_gen_codes_w<1>(S->dlen, 30u, 15u, S->dcode);
     }
     if (choice != 0u) {
         // tokens + the end-of-block symbol as virtual token index ntok; the next group's tokens are
