@@ -60,14 +60,14 @@ struct EncShared {
             uint32_t dcode[ENC_ND];
         };
     };
+    uint8_t hsym[ENC_NL + ENC_ND];   // (directly behind idep: the tree builder's node queue runs on from idep into these two)
+    uint8_t hext[ENC_NL + ENC_ND];
     uint32_t stg[ENC_STG];
     uint8_t llen[ENC_NL];
     uint8_t dlen[ENC_ND];
     uint8_t bllen[32];
     uint32_t blfreq[32];
     uint32_t blcode[32];
-    uint8_t hsym[ENC_NL + ENC_ND];
-    uint8_t hext[ENC_NL + ENC_ND];
     uint32_t cnt[16];
     uint32_t next[16];
     uint32_t misc[16];
@@ -277,10 +277,12 @@ static __device__ void enc_huff_lengths_w(EncShared* S, const uint32_t* freq, ui
         return;
     }
     // The sorted leaf weights live in five registers per lane (the head of the leaf queue is a scalar lane read); the weights
-    // of the nodes made so far are a FIFO in LDS -- the scratch of the steps that come later (idep, and the header's symbol
-    // list for queues longer than 144) -- written by lane 0 and read back by all lanes at one address.  (Round 2 kept the node
-    // queue in five registers too: indexing a register array with a wave-uniform index is a switch, ~60 instructions per merge
-    // against ~28 with the LDS round trip; the merge is a third of a block's ~30 K instructions and the kernel is issue-bound.)
+    // of the nodes made so far are a FIFO in LDS -- the scratch of the steps that come later: idep and, behind it in the
+    // struct, the header's symbol list (1216 bytes for up to 285 nodes).  Every store of the loop is wave-uniform (all lanes
+    // write the same value to the same address: no exec masking around it) and plain LDS traffic.  (Round 2 kept the node
+    // queue in five registers too: indexing a register array with a wave-uniform index is a switch, ~60 instructions per merge.
+    // Rounds 2-4 had the queue in two separate arrays behind a volatile pointer: the compiler made FLAT accesses with
+    // system scope and a full wait of them, a memory round trip per merge -- 10 of the kernel's 88 ms.)
     uint32_t swr[5];
 #pragma unroll
     for (uint32_t c = 0; c < 5u; ++c) {
@@ -288,8 +290,9 @@ static __device__ void enc_huff_lengths_w(EncShared* S, const uint32_t* freq, ui
         swr[c] = k < nnz ? freq[S->order[k]] : 0xFFFFFFFFu;
     }
     zmi_wave_sync();   // (the weights have been read through S->order: the node queue may now reuse what lies behind it)
-    volatile uint32_t* const nq_lo = (volatile uint32_t*)S->idep;   // nodes 0..143
-    volatile uint32_t* const nq_hi = (volatile uint32_t*)S->hsym;   // nodes 144.. (hsym + hext: 160 words)
+    static_assert(offsetof(EncShared, hsym) == offsetof(EncShared, idep) + sizeof(uint16_t) * ENC_NL, "node queue: idep, hsym, hext in a row");
+    static_assert(offsetof(EncShared, hext) == offsetof(EncShared, hsym) + ENC_NL + ENC_ND, "node queue: idep, hsym, hext in a row");
+    uint32_t* const nq = (uint32_t*)S->idep;
     {
         uint32_t li = 0, ii = 0;
         uint32_t cur = swr[0];              // the register holding the leaf queue's current 64 entries
@@ -301,18 +304,18 @@ static __device__ void enc_huff_lengths_w(EncShared* S, const uint32_t* freq, ui
             for (int pick = 0; pick < 2; ++pick) {
                 if (lw <= nw) {
                     w += lw;
-                    if (lane == 0) S->lpar[li] = (uint16_t)ni;
+                    S->lpar[li] = (uint16_t)ni;
                     ++li;
                     if ((li & 63u) == 0u) cur = li == 64u ? swr[1] : (li == 128u ? swr[2] : (li == 192u ? swr[3] : swr[4]));
                     lw = zmi_readlane(cur, li & 63u);   // entries past nnz hold all ones
                 } else {
                     w += nw;
-                    if (lane == 0) S->ipar[ii] = (uint16_t)ni;
+                    S->ipar[ii] = (uint16_t)ni;
                     ++ii;
-                    nw = ii < ni ? zmi_uniform(ii < 144u ? nq_lo[ii] : nq_hi[ii - 144u]) : 0xFFFFFFFFu;
+                    nw = ii < ni ? zmi_uniform(nq[ii]) : 0xFFFFFFFFu;
                 }
             }
-            if (lane == 0) { if (ni < 144u) nq_lo[ni] = w; else nq_hi[ni - 144u] = w; }
+            nq[ni] = w;
             if (ii == ni) nw = w;   // the node just made is the head of its queue
         }
     }
