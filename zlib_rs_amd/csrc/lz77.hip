@@ -424,6 +424,7 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                                       // their chain, and the three instructions of that bookkeeping leave their loop
         uint32_t stoplen = prm.nice_len < maxlen ? prm.nice_len : maxlen;
         if (!deep && prm.good_len < stoplen) stoplen = prm.good_len;
+        if (!deep && stoplen > 16u) stoplen = 16u;   // (the launcher keeps good_len <= 16 for the short budgets anyway)
         const uint32_t goodlen = deep ? prm.good_len : 259u;
         if (maxlen >= 4u && delta != 0u && chain != 0u && prm.max_chain != 0u) {
             uint32_t cand = p - delta;
@@ -448,7 +449,7 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                 m3 = m3 < c2 ? m3 : c2;
                 m3 = m3 < c3 ? m3 : c3;
                 uint32_t l = m3 >> 3;        // 0..15, or 0x1FFFFFFF when all 16 bytes are equal
-                if (m3 >= 128u) {
+                if (deep && m3 >= 128u) {
                     // rare: all 16 bytes equal.  With a best match of 16+ already, the 4 bytes ending at the best length
                     // decide first whether this candidate can be longer at all.
                     l = 16u;
@@ -468,6 +469,9 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                     const uint32_t lc = l > maxlen ? maxlen : l;
                     if (lc > blen && lc >= 16u) tail = lz_ring32(win, p + lc - 3u);
                 }
+                // (the short budgets stop at the first candidate equal in 16 bytes -- stoplen <= 16 -- and find out how long it really
+                // is after the walk, see below: their loop has no branch at all)
+                if (!deep) l = l > 16u ? 16u : l;
                 l = l > maxlen ? maxlen : l;
                 // (a candidate that differs inside its first 16 bytes cannot beat a best match of 16+: nothing to do)
                 const bool better = l > blen;
@@ -481,6 +485,51 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                 // (p - cand > lim: the raw link led out of the window, in front of the shard, or nowhere)
                 const bool stop = (better & (l >= stoplen)) | (dn == 0u) | ((int32_t)chain <= 0) | (p - cand > lim);
                 if (stop) break;
+            }
+        }
+        if (!deep) {
+            // The short budgets' walk ended at the first candidate equal in 16 bytes; its real length is found here, the wave
+            // together: NEIGHBOURING positions mostly hold the same match one byte further on -- the same distance, one byte
+            // shorter -- so of a run of lanes with one distance only the lowest (the leader) compares bytes, and lane leader + k
+            // takes the leader's length - k (exact: both stop at the same mismatching byte).  A leader that ran into its cap
+            // (258 or the end of the shard) says nothing about its followers: those compare for themselves, as does a follower
+            // whose inherited length would fall below the 16 bytes it has seen.  On XML- and record-like data this is most of
+            // the bytes the extension used to compare (every lane of a 60-byte match walked the same 60 bytes).
+            bool pend = blen >= 16u && maxlen > 16u;
+            if (__ballot(pend) != 0ull) {
+                const uint32_t dprev = zmi_lane_up1(pend ? bdist : 0u);
+                bool work = pend && dprev != bdist;   // leaders first
+                const uint64_t lm = __ballot(work);
+                uint32_t L = 16u;
+                for (int round = 0; round < 2; ++round) {
+                    if (work) {
+                        const uint32_t cand = p - bdist;
+                        uint32_t l = 16u;
+                        for (;;) {
+                            uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
+                            lz_ring128(win, p + l, a0, a1, a2, a3);
+                            lz_ring128(win, cand + l, b0, b1, b2, b3);
+                            uint32_t m = lz_match8(a0 ^ b0, a1 ^ b1);
+                            if (m == 8u) m += lz_match8(a2 ^ b2, a3 ^ b3);
+                            l += m;
+                            if (m < 16u || l >= maxlen) break;
+                        }
+                        L = l;
+                    }
+                    if (round == 1) break;
+                    // followers: the leader is the highest leader lane at or below this one
+                    const uint64_t below = lm & ((2ull << lane) - 1ull);
+                    const uint32_t j = below ? 63u - (uint32_t)__clzll((unsigned long long)below) : lane;
+                    const uint32_t capped = (work && L >= maxlen) ? 0x10000u : 0u;
+                    const uint32_t Lj = (uint32_t)__shfl((int)(L | capped), (int)j);
+                    const uint32_t inh = (Lj & 0xFFFFu) - (lane - j);
+                    const bool follower = pend && !work;
+                    const bool take = follower && (Lj & 0x10000u) == 0u && (Lj & 0xFFFFu) >= 16u + (lane - j);
+                    if (take) L = inh;
+                    work = follower && !take;
+                    if (__ballot(work) == 0ull) break;
+                }
+                if (pend) blen = L > maxlen ? maxlen : L;
             }
         }
         // (whether a short match far back is worth its codes is the encoder's call: it knows the prices, enc_far_limits)

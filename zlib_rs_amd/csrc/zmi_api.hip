@@ -271,9 +271,9 @@ static const zmi_level_cfg kLevels[10] = {
     {3, 32, 8, 0, 8192},         // 2
     {3, 32, 8, 4, 4096},         // 3
     {3, 64, 16, 8, 4096},        // 4
-    {3, 128, 32, 16, 4096},      // 5
-    {4, 128, 32, 32, 4096},      // 6
-    {6, 128, 32, 32, 4096},      // 7
+    {3, 128, 16, 16, 4096},      // 5
+    {4, 128, 16, 32, 4096},      // 6  (good 32 -> 16 in round 4: lz77 138.7 -> 130.1 ms, ratio 2.2550 -> 2.2532, lcet10.txt -0.04 %)
+    {6, 128, 16, 32, 4096},      // 7
     {14, 258, 64, 128, 2048},    // 8
     // 9: the ratio curve is flat beyond ~24 candidates (lcet10.txt 2.8776 at 24, 2.8802 at 128; benchmark shards 2.2726 /
     // 2.2807, the reference's level 9: 2.2735) while every candidate costs the same: round 1's 128 ran at 5.6 GiB/s
