@@ -519,6 +519,14 @@ static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, co
             lit2 = two ? (e2 >> 16) << 8 : 0u;
             adv += two ? (e2 & 0xFFu) : 0u;
             n_lit = two ? 2u : 1u;
+            // ... and a third one, if 9 bits are left behind the two (then the third code, a first-level entry, is in them whole)
+            if (__ballot(two)) {
+                const uint32_t e3 = S->ltab[(lo >> adv) & ((1u << INF_LROOT) - 1u)];
+                const bool three = two && adv <= 32u - INF_LROOT && (e3 & 0xFF00u) == 0u && pos + adv < boundary;
+                lit2 |= three ? (e3 >> 16) << 16 : 0u;
+                adv += three ? (e3 & 0xFFu) : 0u;
+                n_lit = three ? 3u : n_lit;
+            }
         }
         if (WRITE) {
             const uint32_t rec = (dist - 1u) | ((val - 3u) << 15);         // the record the resolve pass reads (inf_emit)
