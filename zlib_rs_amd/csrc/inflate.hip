@@ -519,13 +519,21 @@ static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, co
             lit2 = two ? (e2 >> 16) << 8 : 0u;
             adv += two ? (e2 & 0xFFu) : 0u;
             n_lit = two ? 2u : 1u;
-            // ... and a third one, if 9 bits are left behind the two (then the third code, a first-level entry, is in them whole)
+            // ... a third and a fourth one out of the 64-bit window (the codes of first-level entries are <= 9 bits)
             if (__ballot(two)) {
-                const uint32_t e3 = S->ltab[(lo >> adv) & ((1u << INF_LROOT) - 1u)];
-                const bool three = two && adv <= 32u - INF_LROOT && (e3 & 0xFF00u) == 0u && pos + adv < boundary;
+                const uint32_t hi2 = __builtin_amdgcn_alignbit(d2, d1, pos & 31u);
+                const uint32_t e3 = S->ltab[__builtin_amdgcn_alignbit(hi2, lo, adv) & ((1u << INF_LROOT) - 1u)];   // (adv <= 24)
+                const bool three = two && (e3 & 0xFF00u) == 0u && pos + adv < boundary;
                 lit2 |= three ? (e3 >> 16) << 16 : 0u;
                 adv += three ? (e3 & 0xFFu) : 0u;
                 n_lit = three ? 3u : n_lit;
+                if (__ballot(three)) {
+                    const uint32_t e4 = S->ltab[__builtin_amdgcn_alignbit(hi2, lo, adv & 31u) & ((1u << INF_LROOT) - 1u)];
+                    const bool four = three && adv < 32u && (e4 & 0xFF00u) == 0u && pos + adv < boundary;
+                    lit2 |= four ? (e4 >> 16) << 24 : 0u;
+                    adv += four ? (e4 & 0xFFu) : 0u;
+                    n_lit = four ? 4u : n_lit;
+                }
             }
         }
         if (WRITE) {
