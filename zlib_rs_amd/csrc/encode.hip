@@ -775,9 +775,10 @@ static __device__ __forceinline__ uint32_t enc_seg_step(uint32_t& m, uint32_t nx
     // two / three positions on that is longer by more than the literals in between cost (all matches are known
     // here, so looking further than the reference's one-position lazy rule, algorithm/medium.rs / slow.rs, is a
     // shuffle, not a search: lcet10.txt +0.8 %, benchmark shards +0.6 % for ~12 instructions per 64 positions)
-    const bool defer = mlen < prm.max_lazy && (mlen1 > mlen || mlen2 > mlen + prm.lazy2 || mlen3 > mlen + prm.lazy3);
+    // (bitwise on purpose: as && / || the compiler builds two nested divergent branches per segment, eight scalar instructions each)
+    const bool defer = (mlen < prm.max_lazy) & ((mlen1 > mlen) | (mlen2 > mlen + prm.lazy2) | (mlen3 > mlen + prm.lazy3));
     uint32_t step = 1u;
-    if (valid && mlen >= 4u && !defer) step = mlen;
+    if (valid & (mlen >= 4u) & !defer) step = mlen;
     // a token may not cross the end of the piece (the next piece starts a fresh parse there)
     if (valid && pos + step > pend) { step = pend - pos; if (step < 3u) step = 1u; }
     return step;
@@ -899,8 +900,11 @@ __global__ void __launch_bounds__(64) ENC_OCC zmi_encode_kernel(const uint8_t* _
     uint32_t m_c = (pstart + 128u + lane < pend) ? tokbuf[pstart + 128u + lane] : 0u;
     for (uint32_t seg = seg0; seg < nseg; seg += 2u) {
         const uint32_t posA = seg * 64u + lane, posB = posA + 64u;
-        const uint32_t m_d = (posA + 192u < pend) ? tokbuf[posA + 192u] : 0u;
-        const uint32_t m_e = (posA + 256u < pend) ? tokbuf[posA + 256u] : 0u;
+        // (loads at a clamped index + a select: a guarded load is a divergent branch, six scalar instructions around one load)
+        const uint32_t plast = pend - 1u;   // (pend > 0 here: an empty shard has no segments)
+        const uint32_t ld_d = tokbuf[posA + 192u < plast ? posA + 192u : plast], ld_e = tokbuf[posA + 256u < plast ? posA + 256u : plast];
+        const uint32_t m_d = (posA + 192u < pend) ? ld_d : 0u;
+        const uint32_t m_e = (posA + 256u < pend) ? ld_e : 0u;
         const uint32_t stepA = enc_seg_step(m_a, m_b, posA, pend, prm, far4, far5, far6);
         const uint32_t stepB = enc_seg_step(m_b, m_c, posB, pend, prm, far4, far5, far6);
         const uint64_t validA = __ballot(posA < pend), validB = __ballot(posB < pend);
@@ -942,12 +946,11 @@ __global__ void __launch_bounds__(64) ENC_OCC zmi_encode_kernel(const uint8_t* _
                 if (in) {
                     uint32_t tk = step > 1u ? ((mw & ~(0x1FFu << 8)) | (step << 8)) : (mw & 0xFFu);
                     tokbuf[tok0 + ntok + zmi_mbcnt(mask)] = tk;
-                    if (step > 1u) {
-                        atomicAdd(&S->lfreq2[257u + enc_len_idx(step)], 1u);
-                        atomicAdd(&S->dfreq2[enc_dist_idx((mw >> 17) + 1u)], 1u);
-                    } else {
-                        atomicAdd(&S->lfreq2[mw & 0xFFu], 1u);
-                    }
+                    // (one count for every token, a second one for the matches: as if / else the literal and the length count were
+                    // two divergent regions)
+                    const bool mt = step > 1u;
+                    atomicAdd(&S->lfreq2[mt ? 257u + enc_len_idx(step) : (mw & 0xFFu)], 1u);
+                    if (mt) atomicAdd(&S->dfreq2[enc_dist_idx((mw >> 17) + 1u)], 1u);
                 }
                 ntok += (uint32_t)__popcll(mask);
             } else {

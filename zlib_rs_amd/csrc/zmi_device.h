@@ -165,19 +165,37 @@ static __device__ __forceinline__ unsigned zmi_wave_incl_scan(unsigned v) {
     return v;
 }
 #endif
+// wave-wide sum / maximum, the same value in every lane (all 64 lanes must call).  On the device: the DPP prefix steps of the
+// scan above and one scalar lane read -- seven instructions; the butterfly of six __shfl_xor it replaces (round 4) is six
+// ds_bpermute round trips through the LDS crossbar with their address arithmetic and waits.
+#ifdef ZMI_EMU
 static __device__ __forceinline__ unsigned zmi_wave_sum(unsigned v) {
-#pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
     return v;
 }
 static __device__ __forceinline__ unsigned zmi_wave_max(unsigned v) {
-#pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         unsigned t = __shfl_xor(v, d);
         v = t > v ? t : v;
     }
     return v;
 }
+#else
+static __device__ __forceinline__ unsigned zmi_wave_sum(unsigned v) {
+    return (unsigned)__builtin_amdgcn_readlane((int)zmi_wave_incl_scan(v), 63);
+}
+static __device__ __forceinline__ unsigned zmi_wave_max(unsigned v) {
+    // (lanes without a source read 0: the identity of an unsigned maximum)
+    unsigned t;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false); v = t > v ? t : v;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false); v = t > v ? t : v;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false); v = t > v ? t : v;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false); v = t > v ? t : v;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false); v = t > v ? t : v;
+    t = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false); v = t > v ? t : v;
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+#endif
 
 // unaligned little-endian 32-bit read from a byte array that lives in LDS or global memory:
 // two aligned dword reads + v_alignbyte.  `base` must be 4-byte aligned.
