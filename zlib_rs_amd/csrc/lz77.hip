@@ -475,15 +475,19 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                 l = l > maxlen ? maxlen : l;
                 // (a candidate that differs inside its first 16 bytes cannot beat a best match of 16+: nothing to do)
                 const bool better = l > blen;
+                // the walk ends at a match of stoplen or more that is also the best so far: one compare against the larger bound
+                const uint32_t bar = blen + 1u > stoplen ? blen + 1u : stoplen;
+                const uint32_t dist = p - cand;
                 blen = better ? l : blen;
-                bdist = better ? p - cand : bdist;
+                bdist = better ? dist : bdist;
                 // deep walks: a good match halves the remaining budget (goodlen = 259 for the short budgets: never)
                 if (deep) chain >>= (uint32_t)(better & (l >= goodlen));
                 cand -= dn;
                 chain -= 1u;   // may wrap below zero after the halving: compared as signed
-                // (bitwise, not short-circuit: four compares and three ORs; as `||` the compiler built a branch per term)
-                // (p - cand > lim: the raw link led out of the window, in front of the shard, or nowhere)
-                const bool stop = (better & (l >= stoplen)) | (dn == 0u) | ((int32_t)chain <= 0) | (p - cand > lim);
+                // ... and at the end of the chain (dn = 0: dn - 1 wraps to the largest value) or where the raw link leads out of the
+                // window, in front of the shard or nowhere (dist + dn > lim; dist <= lim holds on entry and after every step): one
+                // compare for both.  (Bitwise, not short-circuit: as `||` the compiler built a branch per term.)
+                const bool stop = (l >= bar) | (dn - 1u >= lim - dist) | ((int32_t)chain <= 0);
                 if (stop) break;
             }
         }
