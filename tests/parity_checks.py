@@ -138,6 +138,42 @@ def large_stream_checks(inflate_fn, o, deflate_fn=None, size=1 << 17):
     return n
 
 
+def long_match_checks(deflate_fn, o, scale=1):
+    """The match search's second half at the short budgets (lz77.hip, round 4): a walk stops at the first candidate equal in 16
+    bytes, and the real length is found afterwards by ONE lane per run of neighbouring positions with the same distance -- the
+    others take the leader's length minus their offset.  Inputs whose compressed size hangs on exactly that: runs (distance 1,
+    capped at 258), records repeated at distances above and below 258, matches of 16..40 bytes placed across the 64-position
+    claims, a match that ends with the shard.  Every stream must round-trip and stay within a few percent of zlib level 6 on the
+    same bytes -- a quarter at level 1 -- (followers that kept 16 instead of their real length would double these sizes).  deflate_fn(blobs, level) ->
+    list of zlib streams."""
+    rnd = lambda seed, n: o.prng_bytes(seed, n, 1)
+    blobs = [bytes(70000 * scale),
+             rnd(1, 300) * (100 * scale),
+             rnd(2, 40) * (400 * scale),
+             rnd(3, 17) * (500 * scale),
+             o.gen_shard(3, (1 << 15) * scale),
+             o.gen_shard(4, (1 << 15) * scale)]
+    # matches of 16..40 bytes at every alignment against the 64-position claims, the rest incompressible
+    parts, seed = [], 10
+    for k in range(16, 41):
+        x = rnd(seed, k); seed += 1
+        parts += [rnd(seed, 50 + k), x, rnd(seed + 1, 61 + 3 * k), x]; seed += 2
+    blobs.append(b"".join(parts) * scale)
+    # a long match that ends exactly where the shard ends, and one cut short by it
+    body = rnd(90, 5000)
+    blobs.append(body + rnd(91, 777) + body)
+    blobs.append(body + rnd(92, 333) + body[:1234])
+    n = 0
+    for level in (1, 4, 6, 7):
+        outs = deflate_fn(blobs, level)
+        for b, c in zip(blobs, outs):
+            assert zlib.decompress(c) == b, (level, len(b))
+            ref = len(zlib.compress(b, 6))
+            assert len(c) <= ref * (1.25 if level < 4 else 1.12) + 96, (level, len(b), len(c), ref)
+            n += 1
+    return n
+
+
 def fixed_code_checks(inflate_fn, o, size=1 << 16):
     """Streams of FIXED-Huffman blocks (BTYPE 01: Z_FIXED, and what the reference's level 1 emits, deflate/algorithm/quick.rs:12-158)
     through the batch kernel's fast pass, whose lanes find their starts by walking every bit phase (inflate.hip inf_fixed_tracks):

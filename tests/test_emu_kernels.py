@@ -38,6 +38,15 @@ def test_deflate_kernels_roundtrip(eng, o):
             assert rc == 1 and back == b, msg
 
 
+def test_long_matches_are_extended_by_one_lane_per_run(eng, o):
+    """lz77.hip, short budgets: stop at 16 equal bytes, the leader of a run of equal distances extends, the others inherit"""
+    def deflate(blobs, level):
+        outs, st = eng.deflate(blobs, level=level, wrap=1)
+        assert all(s == 0 for s in st)
+        return outs
+    assert parity_checks.long_match_checks(deflate, o) == 36
+
+
 def test_deflate_multi_piece_streams(eng, o, monkeypatch):
     monkeypatch.setenv("ZMI_BLOCK_SPAN", "2048")
     d = o.gen_shard(1, 1 << 14)

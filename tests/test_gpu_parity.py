@@ -427,6 +427,14 @@ def test_pack_slab_and_global_stitch_on_gpu(engine):
     assert gzip.decompress(blob) == want
 
 
+def test_long_matches_are_extended_by_one_lane_per_run_on_gpu(engine):
+    """lz77.hip, short budgets: a walk stops at 16 equal bytes; one lane per run of equal distances finds the real length"""
+    import oracle_lib
+    import parity_checks
+    deflate = lambda blobs, level: _deflate(engine, blobs, level=level, wrap=1)
+    assert parity_checks.long_match_checks(deflate, oracle_lib.load(rebuild=False), scale=8) == 36
+
+
 def test_inflate_large_streams_fast_pass_on_gpu(engine):
     import oracle_lib
     import parity_checks
