@@ -76,7 +76,9 @@ static_assert(1023u + RES_NEAR + RES_SPAN + 258u + RES_BLK <= RES_RING && RES_RI
 // the compressed bytes of one fast pass (inf_fast_pass): 64 sub-sequences of 60 bytes
 #define INF_SUB_BITS 480u   // 15 dwords: an ODD stride between the lanes' read positions (the walks stay within a dword or two of lock step,
                             // so with 14 the three input reads of every token step were 4-way bank conflicts for the whole pass)
+#ifndef INF_WARM_BITS
 #define INF_WARM_BITS 192u
+#endif
 #define INF_FAST_BYTES 4096u     // 16 (alignment) + 64 * 60 + 6 (a token may end 48 bits behind the last boundary) + read slack
 struct InfShared {
     uint32_t ltab[INF_LSIZE];
