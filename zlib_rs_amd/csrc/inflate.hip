@@ -1652,12 +1652,41 @@ static __device__ __forceinline__ void res_writeback(const uint8_t* ring, uint8_
 // done; `need` is that count, found by ranking the source end in the chunk's bitmap.  Short, non-overlapping
 // holes that are ready are filled together (lane-per-hole, 16 bytes per step); self-overlapping ones are
 // filled by the whole wave when they are the first unfinished hole.  Text-like data finishes a batch in 3-5 steps.
-// the first `left` (<= 16) bytes of w[] -> ring[ip...] (byte stores: neighbouring holes may share a word)
+// the first `left` (<= 16) bytes of w[] -> ring[ip...].  Neighbouring holes may share a dword, so only the hole's own bytes may be
+// written: each of the (up to five) aligned dwords the bytes fall into gets ONE masked store, ds_mskor_b32 (LDS[a] = (LDS[a] & ~mask) |
+// value, atomic against the other lanes' masked stores to the same dword), where sixteen predicated byte stores stood -- 10 of the
+// kernel's 32 ms per 16 Ki streams, measured by doubling them (round 4).  With 23 streams per CU the kernel runs at the LDS pipe's
+// throughput: what counts is the number of LDS operations (unaligned wide stores, which gfx950 takes, were slower than the bytes).
+static __device__ __forceinline__ void res_mskor(uint8_t* p4, uint32_t mask, uint32_t val) {
+#ifdef ZMI_EMU
+    uint32_t* q = (uint32_t*)p4;
+    *q = (*q & ~mask) | val;
+#else
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)p4;
+    asm volatile("ds_mskor_b32 %0, %1, %2" : : "v"(a), "v"(mask), "v"(val) : "memory");
+#endif
+}
 static __device__ __forceinline__ void res_put16(uint8_t* ring, uint32_t ip, const uint32_t* w, uint32_t left) {
-    if (ip + 16u <= RES_RING) {
+    if (ip + 20u <= RES_RING) {
+        const uint32_t sh = ip & 3u, back = (4u - sh) & 3u;
+        uint8_t* const p4 = ring + (ip & ~3u);
+        // the 16 bytes shifted to the ring's dword grid: e[k] = bytes 4k - sh .. 4k - sh + 3 of w
+        uint32_t e[5];
+        e[0] = w[0] << (8u * sh);
+        e[1] = sh ? __builtin_amdgcn_alignbyte(w[1], w[0], back) : w[1];
+        e[2] = sh ? __builtin_amdgcn_alignbyte(w[2], w[1], back) : w[2];
+        e[3] = sh ? __builtin_amdgcn_alignbyte(w[3], w[2], back) : w[3];
+        e[4] = sh ? w[3] >> (8u * back) : 0u;
+        const uint32_t end = sh + left;   // bytes [sh, end) of the 20
 #pragma unroll
-        for (uint32_t j = 0; j < 16u; ++j)
-            if (j < left) ring[ip + j] = (uint8_t)(w[j >> 2] >> (8u * (j & 3u)));
+        for (uint32_t k = 0; k < 5u; ++k) {
+            const uint32_t lo = sh > 4u * k ? sh - 4u * k : 0u;                 // first byte of dword k that is the hole's
+            const uint32_t hi = end > 4u * k ? (end - 4u * k < 4u ? end - 4u * k : 4u) : 0u;   // one past the last
+            if (hi > lo) {
+                const uint32_t m = (0xFFFFFFFFu >> (32u - 8u * hi)) & (0xFFFFFFFFu << (8u * lo));
+                res_mskor(p4 + 4u * k, m, e[k] & m);
+            }
+        }
     } else {
 #pragma unroll
         for (uint32_t j = 0; j < 16u; ++j)
