@@ -431,7 +431,10 @@ def test_long_matches_are_extended_by_one_lane_per_run_on_gpu(engine):
     """lz77.hip, short budgets: a walk stops at 16 equal bytes; one lane per run of equal distances finds the real length"""
     import oracle_lib
     import parity_checks
-    deflate = lambda blobs, level: _deflate(engine, blobs, level=level, wrap=1)
+    def deflate(blobs, level):
+        outs, st = _deflate(engine, blobs, level=level, wrap=1)
+        assert all(int(x) == 0 for x in st)
+        return outs
     assert parity_checks.long_match_checks(deflate, oracle_lib.load(rebuild=False), scale=8) == 36
 
 
