@@ -1818,12 +1818,22 @@ __global__ void __launch_bounds__(64) zmi_inflate_resolve_kernel(uint8_t* out, c
                         const uintptr_t P = (uintptr_t)(dst + s0 + base);
                         const uint32_t* q = (const uint32_t*)(P & ~(uintptr_t)3);
                         const uint32_t sh = (uint32_t)(P & 3u), span = sh + (left < RES_SHORT ? left : RES_SHORT);
-                        // only words that hold source bytes are touched (the last one may end the allocation)
-                        const uint32_t q0 = res_ld_final(q);
-                        const uint32_t q1 = span > 4u ? res_ld_final(q + 1) : 0u;
-                        const uint32_t q2 = span > 8u ? res_ld_final(q + 2) : 0u;
-                        const uint32_t q3 = span > 12u ? res_ld_final(q + 3) : 0u;
-                        const uint32_t q4 = span > 16u ? res_ld_final(q + 4) : 0u;
+                        // the 20 bytes from the dword the source starts in: always inside this stream's output below the hole (a far
+                        // source ends more than RES_NEAR - 258 bytes in front of it).  Two loads, 16 + 4 bytes, past the CU's L1
+                        // (sc0 sc1: this wave may have written these lines back earlier) -- five dword atomics cost 3.7 of the
+                        // kernel's 28.5 ms (measured by doubling them)
+                        uint32_t q0, q1, q2, q3, q4;
+                        (void)span;
+#ifdef ZMI_EMU
+                        q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3]; q4 = q[4];
+#else
+                        {
+                            uint4 v4;
+                            asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dword %1, %2, off offset:16 sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                                         : "=&v"(v4), "=&v"(q4) : "v"(q) : "memory");
+                            q0 = v4.x; q1 = v4.y; q2 = v4.z; q3 = v4.w;
+                        }
+#endif
                         w[0] = __builtin_amdgcn_alignbyte(q1, q0, sh);
                         w[1] = __builtin_amdgcn_alignbyte(q2, q1, sh);
                         w[2] = __builtin_amdgcn_alignbyte(q3, q2, sh);
