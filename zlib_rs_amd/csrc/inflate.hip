@@ -493,10 +493,16 @@ static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, co
         const bool is_len = (e & (INF_OP_BASE << 8)) != 0u, is_eob = (e & (INF_OP_EOB << 8)) != 0u;
         bool err = (e & (INF_OP_BAD << 8)) != 0u;                               // "invalid literal/length code"
         uint32_t dist = 0, adv = used;
+        // ONE second table read serves both kinds of lane: the distance code behind a length, the next literal behind a literal (the
+        // distance table stands behind the literal / length table in LDS, so it is one gather with a per-lane index; both start at
+        // the bit behind the token's `used` bits).  As two reads behind two wave-uniform branches they were two LDS round trips in
+        // every iteration that has both kinds of lane -- most iterations of anything but pure literals.
+        const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, pos & 31u);
+        const uint32_t rest = __builtin_amdgcn_alignbit(hi, lo, used);
+        static_assert(offsetof(InfShared, dtab) == offsetof(InfShared, ltab) + 4u * INF_LSIZE, "dtab directly behind ltab");
+        const uint32_t x = S->ltab[is_len ? INF_LSIZE + (rest & ((1u << INF_DROOT) - 1u)) : (rest & ((1u << INF_LROOT) - 1u))];
         if (__ballot(is_len)) {
-            const uint32_t hi = __builtin_amdgcn_alignbit(d2, d1, pos & 31u);
-            const uint32_t rest = __builtin_amdgcn_alignbit(hi, lo, used);
-            uint32_t d = S->dtab[rest & ((1u << INF_DROOT) - 1u)];
+            uint32_t d = x;
             const bool dlink = is_len && (d & (INF_OP_LINK << 8)) != 0u;
             if (__ballot(dlink)) {
                 const uint32_t d2x = S->dtab[dlink ? (d >> 16) + __builtin_amdgcn_ubfe(rest, INF_DROOT, (d >> 8) & 0x0Fu) : 0u];
@@ -510,27 +516,25 @@ static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, co
         }
         const bool live = go && !err;                  // the token counts
         const bool mat = live && is_len, lit = live && !is_len && !is_eob;
-        // A literal takes the literal behind it along when that one is a first-level entry too and still starts inside the lane's
+        // A literal takes the literals behind it along while they are first-level entries too and still start inside the lane's
         // sub-sequence (a token that starts behind the boundary belongs to the next lane: the exits must not depend on this):
-        // one more table read and ~10 instructions per iteration against a whole iteration per pair -- literal-dense streams
-        // (half of the benchmark mix's decode time) need a third fewer iterations (round 4).
+        // one more table read and ~10 instructions each against a whole iteration -- literal-dense streams (half of the
+        // benchmark mix's decode time) need a third fewer iterations (round 4).  Up to four, out of the 64-bit window (the codes
+        // of first-level entries are <= 9 bits).
         uint32_t lit2 = 0, n_lit = 1u;
         if (__ballot(lit)) {
-            const uint32_t e2 = S->ltab[(lo >> bits) & ((1u << INF_LROOT) - 1u)];   // (a code is <= 15 bits: 17+ bits are left in lo)
-            const bool two = lit && (e2 & 0xFF00u) == 0u && pos + bits < boundary;  // op byte 0: a plain literal (holes are INF_OP_BAD)
-            lit2 = two ? (e2 >> 16) << 8 : 0u;
-            adv += two ? (e2 & 0xFFu) : 0u;
+            const bool two = lit && (x & 0xFF00u) == 0u && pos + bits < boundary;   // op byte 0: a plain literal (holes are INF_OP_BAD)
+            lit2 = two ? (x >> 16) << 8 : 0u;
+            adv += two ? (x & 0xFFu) : 0u;
             n_lit = two ? 2u : 1u;
-            // ... a third and a fourth one out of the 64-bit window (the codes of first-level entries are <= 9 bits)
             if (__ballot(two)) {
-                const uint32_t hi2 = __builtin_amdgcn_alignbit(d2, d1, pos & 31u);
-                const uint32_t e3 = S->ltab[__builtin_amdgcn_alignbit(hi2, lo, adv) & ((1u << INF_LROOT) - 1u)];   // (adv <= 24)
+                const uint32_t e3 = S->ltab[__builtin_amdgcn_alignbit(hi, lo, adv) & ((1u << INF_LROOT) - 1u)];   // (adv <= 24)
                 const bool three = two && (e3 & 0xFF00u) == 0u && pos + adv < boundary;
                 lit2 |= three ? (e3 >> 16) << 16 : 0u;
                 adv += three ? (e3 & 0xFFu) : 0u;
                 n_lit = three ? 3u : n_lit;
                 if (__ballot(three)) {
-                    const uint32_t e4 = S->ltab[__builtin_amdgcn_alignbit(hi2, lo, adv & 31u) & ((1u << INF_LROOT) - 1u)];
+                    const uint32_t e4 = S->ltab[__builtin_amdgcn_alignbit(hi, lo, adv & 31u) & ((1u << INF_LROOT) - 1u)];
                     const bool four = three && adv < 32u && (e4 & 0xFF00u) == 0u && pos + adv < boundary;
                     lit2 |= four ? (e4 >> 16) << 24 : 0u;
                     adv += four ? (e4 & 0xFFu) : 0u;
