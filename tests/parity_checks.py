@@ -224,6 +224,55 @@ def fixed_code_checks(inflate_fn, o, size=1 << 16):
     return len(streams) + len(bad)
 
 
+def literal_group_checks(inflate_fn, o, size=1 << 16):
+    """The lane walk of the decode kernel takes up to four literals per iteration (inflate.hip inf_lane_decode, round 4): a literal
+    is followed along while the next code is a first-level table entry that still starts inside the lane's sub-sequence.  Streams
+    that are nothing but literals (Z_HUFFMAN_ONLY) and streams with literals of every code length -- a skewed alphabet gives
+    codes from 1-2 bits up to 13-15, i.e. second-level entries in the middle of literal runs -- with dynamic codes and small
+    blocks, in one launch of more than 16 streams and one by one; corrupt / truncated variants and short capacities must give
+    the oracle's code and prefix for the exact stream."""
+    skew = bytearray()
+    x = 12345
+    for i in range(size):   # geometric alphabet: byte k with probability ~2^-(k/6)
+        x = (x * 1103515245 + 12345) & 0x7FFFFFFF
+        k, r = 0, x
+        while (r & 1) and k < 250:
+            r >>= 1
+            k += 6
+        skew.append((k + (x >> 20) % 6) & 0xFF)
+    blobs = [o.gen_shard(c, size + 777 * c) for c in (0, 4, 5, 6, 7)] + [bytes(skew), o.prng_bytes(5, size, 1), bytes(range(256)) * (size // 256)]
+    streams, want = [], []
+    for strat in (zlib.Z_HUFFMAN_ONLY, zlib.Z_DEFAULT_STRATEGY, zlib.Z_RLE):
+        for b in blobs:
+            co = zlib.compressobj(6, zlib.DEFLATED, 15, 1, strat)   # memLevel 1: a block every ~500 symbols
+            streams.append(co.compress(b) + co.flush()); want.append(b)
+            co = zlib.compressobj(6, zlib.DEFLATED, 15, 9, strat)
+            streams.append(co.compress(b) + co.flush()); want.append(b)
+    outs, st = inflate_fn(streams, [len(w) for w in want], 1)
+    assert [int(v) for v in st] == [0] * len(streams), list(st)
+    assert outs == want
+    for s_, w in list(zip(streams, want))[:6]:          # the 16-wave kernel (launches of a few streams)
+        o1, s1 = inflate_fn([s_], [len(w)], 1)
+        assert int(s1[0]) == 0 and o1[0] == w
+    good, d = streams[11], want[11]                     # the skewed alphabet, large blocks, literals only
+    bad, caps = [], []
+    for at in (3, 200, len(good) // 3, len(good) // 2, len(good) - 9, len(good) - 2):
+        for mask in (0x01, 0x40):
+            b = bytearray(good); b[at] ^= mask
+            bad.append(bytes(b)); caps.append(len(d))
+    for cut in (5, 3000, 4200, 9000, len(good) - 4, len(good) - 1):
+        bad.append(good[:cut]); caps.append(len(d))
+    for cap in (len(d) - 1, len(d) - 2, len(d) - 3, len(d) // 2, 4097, 1):
+        bad.append(good); caps.append(cap)
+    outs, st = inflate_fn(bad, caps, 1)
+    for i, (s_, c) in enumerate(zip(bad, caps)):
+        rc, w, msg = _want(o, s_, c, 1)
+        assert int(st[i]) == rc, (i, int(st[i]), rc, msg)
+        if rc == 0:
+            assert outs[i] == w
+    return len(streams) + len(bad)
+
+
 def jump_resolve_checks(e, o, big=False):
     """the resolve pass for few streams (csrc/resolve_jump.hip: pointer jumping over all output bytes) against the serial
     one-wave-per-stream pass, on the same compressed streams: runs that feed on themselves (dist < len), a 300 KB run of

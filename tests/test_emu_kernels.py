@@ -398,6 +398,11 @@ def test_fixed_code_streams_through_the_fast_pass(eng, o):
     assert parity_checks.fixed_code_checks(eng.inflate, o) > 40
 
 
+def test_literal_groups_in_the_lane_walk(eng, o):
+    """up to four literals per iteration of the decode kernel's lane walk: literal-only and skewed-alphabet streams, corrupt variants"""
+    assert parity_checks.literal_group_checks(eng.inflate, o, size=1 << 14) > 60
+
+
 def test_truncated_stored_blocks_match_the_oracle():
     e = zmi_ctypes.Engine(zmi_ctypes.load_emu())
     assert parity_checks.truncated_stored_checks(lambda streams, caps, wrap: e.inflate(streams, caps, wrap=wrap), oracle_lib.load()) == 8

@@ -460,6 +460,13 @@ def test_fixed_code_streams_through_the_fast_pass_on_gpu(engine):
     assert parity_checks.fixed_code_checks(_inflate_fn(engine), oracle_lib.load(rebuild=False), size=1 << 19) > 40
 
 
+def test_literal_groups_in_the_lane_walk_on_gpu(engine):
+    """up to four literals per iteration of the decode kernel's lane walk (literal-only and skewed-alphabet streams, corrupt variants)"""
+    import oracle_lib
+    import parity_checks
+    assert parity_checks.literal_group_checks(_inflate_fn(engine), oracle_lib.load(rebuild=False), size=1 << 19) > 60
+
+
 def test_split_inflate_equals_serial_inflate_on_gpu():
     """one stream decoded as segments cut at its flush points, on the whole chip (zmi_inflate_split): the results of the
     serial zmi_inflate_resume for true markers, false ones, history, corruption, short room"""
