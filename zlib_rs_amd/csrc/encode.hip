@@ -656,39 +656,38 @@ static __device__ __noinline__ EncWriter enc_flush_block(EncShared* S, EncWriter
             uint32_t i = base + lane;
             const uint32_t tk = tk_next;
             tk_next = (i + 64u < ntok) ? tok[i + 64u] : 0u;
-            // a group of literals only (the common case on literal-dense data, a third of the groups of text): codes of <= 15 bits
-            if (__ballot(i < ntok && ((tk >> 8) & 0x1FFu) != 0u) == 0ull) {
-                const uint32_t c = i < ntok ? S->lcode[tk & 0xFFu] : (i == ntok ? S->lcode[256] : 0u);
-                enc_emit_group16(S, W, c & 0xFFFFu, c >> 16);
+            // a group of literals only (the common case on literal-dense data, a third of the groups of text): codes of <= 15 bits.
+            // (The end-of-block symbol rides as the literal 256 of the virtual token behind the last one; table reads are done by
+            // every lane -- a guarded read is a divergent branch -- and the symbol mapping is branch-free: the nest of
+            // literal / match / end-of-block / short-length cases was seven exec-mask regions per group.)
+            const uint32_t len = (tk >> 8) & 0x1FFu;
+            const bool on = i <= ntok, mt = i < ntok && len != 0u;
+            const uint32_t sym = i < ntok ? (tk & 0xFFu) : 256u;
+            if (__ballot(mt) == 0ull) {
+                const uint32_t c = S->lcode[sym];
+                enc_emit_group16(S, W, c & 0xFFFFu, on ? c >> 16 : 0u);
                 continue;
             }
-            uint64_t bits = 0;
-            uint32_t nb = 0;
-            if (i < ntok) {
-                uint32_t len = (tk >> 8) & 0x1FFu;
-                if (len == 0u) {
-                    uint32_t c = S->lcode[tk & 0xFFu];
-                    bits = c & 0xFFFFu;
-                    nb = c >> 16;
-                } else {
-                    uint32_t li, leb, lev, di, deb, dev;
-                    enc_len_sym(len, li, leb, lev);
-                    enc_dist_sym((tk >> 17) + 1u, di, deb, dev);
-                    uint32_t lc = S->lcode[257u + li];
-                    uint32_t dc = S->dcode[di];
-                    bits = lc & 0xFFFFu;
-                    nb = lc >> 16;
-                    bits |= (uint64_t)lev << nb;
-                    nb += leb;
-                    bits |= (uint64_t)(dc & 0xFFFFu) << nb;
-                    nb += dc >> 16;
-                    bits |= (uint64_t)dev << nb;
-                    nb += deb;
-                }
-            } else if (i == ntok) {
-                uint32_t c = S->lcode[256];
-                bits = c & 0xFFFFu;
-                nb = c >> 16;
+            // length 3..258 -> code index, extra bits (as enc_len_sym, without its branches)
+            const uint32_t l = (mt ? len : 3u) - 3u;
+            const uint32_t k = 31u - (uint32_t)__clz(l | 4u);
+            const bool top = l == 255u;
+            const uint32_t leb = top ? 0u : k - 2u;
+            const uint32_t li = top ? 28u : (l < 4u ? l : 4u * (k - 1u) + ((l >> (k - 2u)) & 3u));
+            const uint32_t lev = l & ((1u << leb) - 1u);
+            const uint32_t lc = S->lcode[mt ? 257u + li : sym];
+            uint64_t bits = lc & 0xFFFFu;
+            uint32_t nb = on ? lc >> 16 : 0u;
+            if (mt) {
+                uint32_t di, deb, dev;
+                enc_dist_sym((tk >> 17) + 1u, di, deb, dev);
+                const uint32_t dc = S->dcode[di];
+                bits |= (uint64_t)lev << nb;
+                nb += leb;
+                bits |= (uint64_t)(dc & 0xFFFFu) << nb;
+                nb += dc >> 16;
+                bits |= (uint64_t)dev << nb;
+                nb += deb;
             }
             enc_emit_group(S, W, bits, nb);
         }
