@@ -325,6 +325,15 @@ def test_host_batch_pipeline_chunks(monkeypatch):
                 got, gst = eng.inflate(one, caps, wrap=1)
                 assert got == shards and gst == rst
             monkeypatch.delenv("ZMI_HOST_CHUNK", raising=False)
+        # how a chunk leaves the device follows what the chunks before it decoded: the whole region in one copy when most of the room
+        # was used, range by range (decoded bytes only) when the streams were given far more room than they needed -- both ways, in
+        # turns, on one context
+        monkeypatch.setenv("ZMI_HOST_CHUNK", "30000")
+        for caps in ([len(x) + 3 for x in shards], [4 * len(x) + 64 for x in shards], [4 * len(x) + 64 for x in shards],
+                     [len(x) + 1 for x in shards], [len(x) + 1 for x in shards]):
+            got, gst = eng.inflate(one, caps, wrap=1)
+            assert got == shards and gst == [0] * len(shards)
+        monkeypatch.delenv("ZMI_HOST_CHUNK", raising=False)
         # a stream that fails in the middle of a chunk keeps its own status; its neighbours are untouched
         hurt = list(one)
         hurt[5] = hurt[5][:len(hurt[5]) // 2]
