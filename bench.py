@@ -529,6 +529,10 @@ def main():
                 ibest = dt if ibest is None else min(ibest, dt)
             assert np.array_equal(h_back, h_in), "host-buffer round trip differs"
             pcie_obj["inflate_GiB_s"] = P * B / GIB / ibest
+            pcie_obj["inflate_path"] = ("zmi_inflate_batch: pageable host memory -> pinned staging -> H2D -> kernels -> the chunk's output region to "
+                                        "pinned host memory (one DMA copy enqueued ahead when the chunks before it filled their capacity -- the "
+                                        "second of the two timed calls --, decoded bytes range by range through the pack kernel otherwise) -> "
+                                        "scattered to the caller's regions; best of two calls")
             pcie_obj["round_trip"] = "bit-exact"
             del h_in, h_out, h_back
     del back
