@@ -443,7 +443,9 @@ static __device__ __forceinline__ void inf_emit(uint8_t* dst, uint32_t* bm32, bo
 //             with the reference's codes and byte counts.
 //   3. write: the lanes of the prefix decode once more and store literals / back-reference records where they belong.
 // Nothing is committed unless it is certain; whenever the pass cannot commit a single lane the caller runs one token
-// round instead.  Needs ~4 KiB of input behind the current position (ends of streams go through the token rounds).
+// round instead.  Takes 4 KiB of input behind the current position; near the end of a stream the single-wave kernel stages what
+// is left (zeros behind it) and shortens the sub-sequences so that all 64 lie inside the input (down to 96 bits a lane: the last
+// ~900 bytes of a stream go through the token rounds).
 struct InfLane {
     uint32_t exit;    // bit position (relative to fb) behind the last token decoded
     uint32_t nout;    // output bytes of those tokens
@@ -746,11 +748,28 @@ static __device__ __forceinline__ uint32_t inf_fixed_sync(const uint8_t* fb, uin
     return known;
 }
 
+// the staged input of a pass near the end of the stream: the `lim` (< INF_FAST_BYTES) bytes that exist, zeros behind them.  Out of
+// line and rolled: inlined into the pass, its guarded loads took the decode kernel from 74 to 140 VGPRs (3 waves per SIMD instead of
+// 6: 43 -> 50 ms per 16 Ki streams); it runs once or twice per stream.
+static __device__ __noinline__ void inf_stage_tail(const uint8_t* line, uint32_t lim) {
+    uint8_t* fb = g_inf_lds.fb;
+    const uint32_t lane = zmi_lane();
+#pragma unroll 1
+    for (uint32_t o = 4u * lane; o < INF_FAST_BYTES; o += 256u) {
+        uint32_t v = 0u;
+        if (o + 4u <= lim) v = *(const uint32_t*)(line + o);   // (`line` is 16-byte aligned)
+        else
+            for (uint32_t j = 0; j < 4u; ++j)
+                if (o + j < lim) v |= (uint32_t)line[o + j] << (8u * j);
+        *(uint32_t*)(fb + o) = v;
+    }
+}
+
 // One fast pass from bit P of the stream.  Returns the number of lanes committed (0: nothing done); *bits_used / *out_made
 // / *hit_eob describe what was committed.  All lanes call.
 static __device__ __forceinline__ uint32_t inf_fast_pass(InfShared* S, const uint8_t* src, uint64_t P, uint8_t* dst,
                                                       uint32_t* bm32, uint32_t opos, uint32_t cap, uint32_t hist, uint32_t sub,
-                                                      uint32_t* bits_used, uint32_t* out_made, uint32_t* hit_eob, bool fixed_code) {
+                                                      uint32_t* bits_used, uint32_t* out_made, uint32_t* hit_eob, bool fixed_code, uint32_t n_in) {
     // sub: bits per lane, 96 .. INF_SUB_BITS (wave-uniform; see the caller for how it is chosen)
     const uint32_t lane = zmi_lane();
     // stage the input: from the 16-byte line holding bit P, 4 KiB, four coalesced loads
@@ -758,8 +777,12 @@ static __device__ __forceinline__ uint32_t inf_fast_pass(InfShared* S, const uin
     const uint32_t mis = (uint32_t)((uintptr_t)(src + ib) & 15u);
     const uint8_t* line = src + ib - mis;
     zmi_wave_order();
+    const uint32_t lim = n_in - (ib - mis);   // bytes of the stream from `line` on; what lies behind them is staged as zeros (a pass
+                                              // near the end of the stream: its lanes' sub-sequences end in front of that point)
+    if (lim >= INF_FAST_BYTES) {
 #pragma unroll
-    for (uint32_t k = 0; k < INF_FAST_BYTES / 1024u; ++k) *(uint4*)(S->fb + 16u * (lane + 64u * k)) = *(const uint4*)(line + 16u * (lane + 64u * k));
+        for (uint32_t k = 0; k < INF_FAST_BYTES / 1024u; ++k) *(uint4*)(S->fb + 16u * (lane + 64u * k)) = *(const uint4*)(line + 16u * (lane + 64u * k));
+    } else inf_stage_tail(line, lim);
     zmi_wave_order();
     const uint32_t p_rel = (mis << 3) | ((uint32_t)P & 7u);
     const uint32_t boundary = p_rel + (lane + 1u) * sub;
@@ -1319,7 +1342,9 @@ __global__ void __launch_bounds__(64 * NW) zmi_inflate_kernel(const uint8_t* __r
                     // commits a lane or two per pass at the price of 64: after such a pass the token rounds take over for a
                     // while, twice as long every time it happens again)
                     if (fskip != 0u) --fskip;
-                    else if (Pend - P >= 8ull * (INF_FAST_BYTES + 32u)) {
+                    // (the single-wave kernel also takes the last kilobytes of a stream through a pass, with shorter sub-sequences: the
+                    // token rounds are ~25x the instructions per token, and the last 4 KiB of every 440 KB stream were 8 % of its decode)
+                    else if (Pend - P >= 8ull * (INF_FAST_BYTES + 32u) || (NW == 1u && Pend - P >= 64u * 96u + 128u)) {
                         // Bits per lane.  A pass ends at the end of the block, and the lanes behind that point have worked
                         // for nothing: streams of small blocks (drifting data: 4 KiB a block) spent every second pass
                         // on a block's last few hundred bytes at the price of 3.75 KiB.  The block before is the estimate
@@ -1330,6 +1355,14 @@ __global__ void __launch_bounds__(64 * NW) zmi_inflate_kernel(const uint8_t* __r
                             const uint32_t rest = done < (uint64_t)last_blk_bits ? last_blk_bits - (uint32_t)done : 0u;
                             if (rest == 0u) sub = 288u;   // longer than the block before: feel the way forward
                             else if (rest < 56u * INF_SUB_BITS) { sub = (rest + (rest >> 3) + 63u) >> 6; sub = (((sub + 31u) >> 5) | 1u) << 5; sub = sub < 96u ? 96u : (sub > INF_SUB_BITS ? INF_SUB_BITS : sub); }   // (whole dwords, an odd number of them)
+                        }
+                        if (NW == 1u && Pend - P < 8ull * (INF_FAST_BYTES + 32u)) {
+                            // near the end of the stream: all 64 sub-sequences (and the 64 bits a lane reads past its own) inside the input
+                            uint32_t room = ((uint32_t)(Pend - P) - 128u) >> 6;
+                            room &= ~31u;                                   // whole dwords,
+                            if ((room & 32u) == 0u) room -= 32u;            // an odd number of them (>= 96 - 32: the entry condition)
+                            if (room < sub) sub = room;
+                            if (sub < 64u) sub = 64u;
                         }
                         uint32_t fbits = 0, fout = 0, feob = 0;
                         uint32_t lanes;
@@ -1362,7 +1395,7 @@ __global__ void __launch_bounds__(64 * NW) zmi_inflate_kernel(const uint8_t* __r
                             lanes = zmi_uniform(g_inf_mw.res_lanes);
                             if (lanes != 0u) { fbits = zmi_uniform(g_inf_mw.res_bits); fout = zmi_uniform(g_inf_mw.res_out); feob = zmi_uniform(g_inf_mw.res_eob); }
                         } else
-                        lanes = zmi_uniform(inf_fast_pass(S, B.src, P, dst, bm32, opos, cap, hist, sub, &fbits, &fout, &feob, fixed_ready != 0u));
+                        lanes = zmi_uniform(inf_fast_pass(S, B.src, P, dst, bm32, opos, cap, hist, sub, &fbits, &fout, &feob, fixed_ready != 0u, B.n));
                         B.cbase = -(int32_t)(2u * INF_CHUNK);   // the pass staged its input over the token rounds' chunk
                         if (lanes < 8u && sub >= 288u) { fskip_len = fskip_len == 0u ? 4u : (fskip_len < 64u ? fskip_len * 2u : 64u); fskip = fskip_len; }
                         else if (lanes >= 32u) fskip_len = 0u;
