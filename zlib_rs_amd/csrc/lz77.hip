@@ -22,7 +22,10 @@
 //   * The other waves are SEARCHERS.  A searcher claims 64 consecutive positions (one per lane) from a shared
 //     LDS counter and walks the chains as a tight per-lane loop.  Every chain step issues ONE round of LDS reads
 //     (prev link of the candidate + its first 16 window bytes as five aligned dwords), so it costs one LDS
-//     latency; only a candidate equal in all 16 bytes enters the divergent extension loop (16 bytes per round).
+//     latency.  A candidate equal in all 16 bytes is extended 16 bytes per round: at the deep levels (8, 9) inside the walk,
+//     which goes on behind it; at the short budgets (levels 1-7) such a candidate ENDS the walk and is extended after it by
+//     the wave together -- one comparing lane per run of neighbouring positions with the same distance, the others take the
+//     leader's length minus their offset (round 4).
 //     A claim is a bounded amount of work (<= max_chain steps), so a slow wave delays the ring by far less than
 //     its slack; claims are dynamic, so no wave waits for another (the first version had a barrier per 1 KiB
 //     tile and spent 61 % of its wave-cycles waiting).
@@ -31,10 +34,11 @@
 //   * output: one u32 per position  lit | len<<8 | (dist-1)<<17  (len = 0: no match >= 4).
 //     The parse (greedy/lazy selection) happens in encode.hip, which sees the best match of every
 //     position, not just the visited ones.
-// Bound: instruction issue, not HBM and not LDS latency (6.9 VALU + SALU + LDS wave-instructions per
-// input byte at ~3.0 cycles each per SIMD, which is what the mix of 2- and 4-cycle instructions costs by the measured table
-// in profiles/r03_issue_probe.txt; two claims per wave in one loop -- more loads in flight -- made it slower).  HBM traffic
-// is 1 B read + 4 B scratch written per input byte (measured: exactly that, profiles/r03_traffic.json).
+// Bound: the LDS pipe first (gathers at random addresses: a gathered dword per chain step costs what a dozen VALU instructions
+// cost; the producers' pace alone is 85 of the kernel's 115 ms at level 6), instruction issue second -- not HBM and not LDS
+// latency (DESIGN.md sections 3.0 / 3.0a, profiles/r04_deflate_experiments.txt; two claims per wave in one loop -- more loads
+// in flight -- made it slower).  HBM traffic is 1 B read + 4 B scratch written per input byte (measured: exactly that,
+// profiles/r04_traffic.json).
 #include "zmi_device.h"
 #include "zmi_kernels.h"
 
