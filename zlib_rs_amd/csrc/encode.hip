@@ -26,7 +26,8 @@
 //     open block or starts a new one (enc_split_pays).
 //   * per block: lane-parallel rank sort of the symbol frequencies (scalar lane reads), two-queue Huffman merge on
 //     wave-uniform state (leaf queue in registers, node queue a FIFO in LDS scratch), depths by parallel relaxation, Kraft-exact length limiting,
-//     canonical codes by ballot ranks, RFC 1951 header planned from registers and emitted through the bit packer.
+//     canonical codes by ballot ranks, the RFC 1951 header's run-length coding for all runs at once (ballots, a closed-form symbol
+//     count per run, a prefix sum) and emitted through the bit packer.
 //   * bit packing: a wave prefix-sum over the code lengths gives every token its output bit
 //     position; codes are OR-ed into an LDS staging window with ds_or and whole dwords are stored
 //     coalesced.  No serial bit writer on the token path.
