@@ -6,6 +6,10 @@ import pytest
 # the libraries read their ZMI_* tuning / test overrides only in a process that has ZMI_TUNING set (checked once, at the
 # first call): the tests use them (segment sizes, queue limits, chunk sizes), a product process never calls getenv()
 os.environ.setdefault("ZMI_TUNING", "1")
+# launches of up to 512 streams take the multi-wave decode kernel in the product; the parity tests are mostly launches of a few
+# dozen streams and must reach the one-wave-per-stream kernel -- the one the benchmark times -- so "more than 16 streams" selects
+# it here, as it did until round 4 (tests of the multi-wave kernel on larger launches: test_multi_wave_decode_up_to_512_streams)
+os.environ.setdefault("ZMI_INF_MW_MAX", "16")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -402,6 +402,20 @@ def test_inflate_large_streams_fast_pass(eng, o):
     assert parity_checks.large_stream_checks(eng.inflate, o, lambda blobs, lvl, wrap: eng.deflate(blobs, level=lvl, wrap=wrap)) > 60
 
 
+def test_multi_wave_decode_up_to_512_streams(eng, o, monkeypatch):
+    """the product gives every stream of a launch of up to 512 streams a workgroup of 16 waves (round 4; the other tests force the
+    one-wave kernel on such launches with ZMI_INF_MW_MAX=16): the same checks through the multi-wave kernel"""
+    monkeypatch.setenv("ZMI_INF_MW_MAX", "512")
+    assert parity_checks.literal_group_checks(eng.inflate, o, size=1 << 13) > 60
+    assert parity_checks.fixed_code_checks(eng.inflate, o, size=1 << 13) > 40
+    assert parity_checks.golden_bitstreams_exact(eng.inflate, o) >= 20
+    blobs = [o.gen_shard(i % 8, 3000 + 997 * i) for i in range(40)]
+    comp, st = eng.deflate(blobs, level=6, wrap=1)
+    assert st == [0] * 40
+    back, st = eng.inflate(comp, [len(b) for b in blobs], wrap=1)
+    assert st == [0] * 40 and back == blobs
+
+
 def test_fixed_code_streams_through_the_fast_pass(eng, o):
     """BTYPE 01 blocks: the fast pass finds its lanes' starts by walking every bit phase (no self-synchronisation to live on)"""
     assert parity_checks.fixed_code_checks(eng.inflate, o) > 40

@@ -470,6 +470,22 @@ def test_literal_groups_in_the_lane_walk_on_gpu(engine):
     assert parity_checks.literal_group_checks(_inflate_fn(engine), oracle_lib.load(rebuild=False), size=1 << 19) > 60
 
 
+def test_multi_wave_decode_up_to_512_streams_on_gpu(engine, monkeypatch):
+    """launches of up to 512 streams take the multi-wave kernel in the product (the other tests force the one-wave kernel there)"""
+    import oracle_lib
+    import parity_checks
+    o = oracle_lib.load(rebuild=False)
+    monkeypatch.setenv("ZMI_INF_MW_MAX", "512")
+    assert parity_checks.literal_group_checks(_inflate_fn(engine), o, size=1 << 18) > 60
+    assert parity_checks.fixed_code_checks(_inflate_fn(engine), o, size=1 << 18) > 40
+    assert parity_checks.golden_bitstreams_exact(_inflate_fn(engine), o) >= 20
+    blobs = [o.gen_shard(i % 8, 300000 + 9973 * i) for i in range(300)]
+    comp, st = _deflate(engine, blobs, level=6, wrap=1)
+    assert all(int(x) == 0 for x in st)
+    back, st = _inflate(engine, comp, [len(b) for b in blobs], wrap=1)
+    assert all(int(x) == 0 for x in st) and back == blobs
+
+
 def test_split_inflate_equals_serial_inflate_on_gpu():
     """one stream decoded as segments cut at its flush points, on the whole chip (zmi_inflate_split): the results of the
     serial zmi_inflate_resume for true markers, false ones, history, corruption, short room"""

@@ -1977,6 +1977,10 @@ __global__ void __launch_bounds__(256) zmi_inflate_verify_kernel(const uint8_t* 
     if (detail) detail[s] = det;
 }
 
+// launches of up to this many streams take the multi-wave kernel (tests force the single-wave kernel on small launches with
+// ZMI_INF_MW_MAX under ZMI_TUNING: zmi_api.hip)
+static uint32_t g_inf_mw_max = 512u;
+extern "C" void zmi_launch_inflate_mw_max(uint32_t n) { g_inf_mw_max = n; }
 extern "C" int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n_streams,
                                   uint32_t wrap, uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                                   uint32_t* d_out_len, uint32_t* d_in_used, uint32_t* d_check, int32_t* d_status,
@@ -1986,9 +1990,11 @@ extern "C" int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off,
     ZMI_LAUNCH(zmi_inflate_order_kernel, dim3(1), dim3(1024), 0, stream, d_in_len, n_streams, d_order);
     ZMI_LAUNCH(zmi_inflate_plan_kernel, dim3(1), dim3(1024), 0, stream, d_out_cap, n_streams, bitmap_words, d_bm_off);
     ZMI_LAUNCH(zmi_inflate_clear_kernel, dim3(n_streams), dim3(256), 0, stream, d_out_cap, (const uint64_t*)d_bm_off, d_bitmap);
-    // a launch of a few streams gives every stream a workgroup of INF_MW waves (inf_pass_mw); thousands of streams fill the
+    // a launch of up to a few hundred streams gives every stream a workgroup of INF_MW waves (inf_pass_mw): such a launch takes as
+    // long as its slowest stream, and a stream alone on a CU is latency-bound (32 ... 512 streams of 1 MiB, every data class: decode
+    // 17.7 ... 18.1 -> 13.7 ... 13.9 ms; at 1024 streams one wave each is ahead, 18.2 against 19.3 ms); thousands of streams fill the
     // chip with one wave each
-    const bool mw = n_streams <= 16u;
+    const bool mw = n_streams <= g_inf_mw_max;
 #define INF_GO(R, W, IB, RS) ZMI_LAUNCH((zmi_inflate_kernel<R, W>), dim3(n_streams), dim3(64u * W), 0, stream, d_in, d_in_off, d_in_len, wrap, d_out, \
                                 d_out_off, d_out_cap, d_out_len, d_in_used, d_check, d_status, d_bitmap, (const uint64_t*)d_bm_off, d_out_hist, IB, RS,  \
                                 (const uint32_t*)d_order)

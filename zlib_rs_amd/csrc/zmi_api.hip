@@ -595,6 +595,7 @@ static int zmi_inflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     rc = zmi_reserve(c->inf_bm, (size_t)(out_limit / 8u) + (size_t)n * 16u);
     if (rc) return rc;
     const uint64_t bm_words = ((out_limit / 8u) + (uint64_t)n * 16u) / 8u;
+    if (const char* mv = zmi_tune("ZMI_INF_MW_MAX")) zmi_launch_inflate_mw_max((uint32_t)atoi(mv));   // (tests: 16 = the single-wave kernel on small launches)
     {
         zmi_scope_timer tm(c, ZMI_K_INFLATE, stream);
         int lrc = zmi_launch_inflate((const uint8_t*)d_in, d_in_off, d_in_len, n, (uint32_t)wrap, (uint8_t*)d_out, d_out_off, d_out_cap,
