@@ -192,7 +192,10 @@ int zmi_pack_slab_dev(zmi_ctx* ctx, const void* d_slots, uint64_t slot_stride, c
  * Shard g of a job lives on rank g % world (round-robin); every rank compresses its shards with zmi_deflate_batch_dev (no
  * collective in the compression) and packs them into one dense slab (zmi_pack_slab_dev).  "Append the pieces in order" --
  * the loop of the reference's parallel-deflate recipe, zlib-rs/src/deflate.rs:4145-4221 -- then is:
- *   zmi_exchange_sizes        all-gather of the u32 size tables: d_table[r * n_local + j] = size of shard j * world + r
+ *   zmi_exchange_sizes        all-gather of the u32 size tables: d_table[r * n_local + j] = size of shard j * world + r.
+ *                             Every rank passes the SAME n_local: a shard count that does not divide by the world size is
+ *                             padded with zero sizes on the short ranks (checked: ZMI_E_ARG on every rank otherwise; the
+ *                             call waits for `stream` when world > 1)
  *   zmi_stitch_plan_dev       from the table alone: d_goff[r * n_local + j] = byte offset of that shard in the stitched
  *                             output, d_soff[r * (n_local + 1) + j] = its offset inside rank r's slab (last entry of a row =
  *                             the slab's size), d_totals[r] = slab size of rank r, d_totals[world] = size of the output;
@@ -201,7 +204,9 @@ int zmi_pack_slab_dev(zmi_ctx* ctx, const void* d_slots, uint64_t slot_stride, c
  *                             ncclSend to and an ncclRecv from every peer -- xGMI is a full mesh, so the 7 transfers of a
  *                             round run side by side, one link each; there is no all-gather-v in RCCL and a ring is never
  *                             used.  root < 0: every rank receives every slab (d_recv[p] = room for slab_bytes[p] bytes;
- *                             the own entry and NULL entries are skipped); root >= 0: only that rank receives
+ *                             the own entry is skipped); root >= 0: only that rank receives, the others may pass NULL.
+ *                             A receiving rank MUST give room for every peer whose slab is not empty -- every such peer
+ *                             sends, and a send without its receive would hang the group: a NULL entry is ZMI_E_ARG
  *   zmi_exchange_slabs_round  one round with bounded memory: peer p's bytes [lo, lo + chunk_bytes) arrive at the start of
  *                             d_stage[p]; the caller consumes them and reuses the staging for the next round
  *   zmi_copy_ranges_dev       (above) scatters a slab or a round of it into the ordered output: d_src_off = the peer's row

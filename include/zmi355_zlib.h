@@ -42,8 +42,9 @@
  * byte boundary, a bit count that is not a multiple of 8 is followed by an empty stored block (3 bits + padding +
  * 00 00 FF FF), which keeps the stream valid.  inflatePrime is accepted while no undecoded input is buffered (right
  * after init / reset or at a block boundary: the documented uses).  inflateSync, inflateSyncPoint, inflateMark,
- * inflateValidate, inflateUndermine, inflateBack* follow the reference; inflateCodesUsed reports 0 (the decode tables
- * live on the device).
+ * inflateValidate, inflateUndermine, inflateBack* follow the reference; inflateCodesUsed reports the entries of the device's
+ * decode tables for the most recent dynamic block (roots 9 / 8 with exact-fit sub-tables, so 768...1252 where the reference's
+ * roots 10 / 9 give other figures for the same quantity; 0 before the first dynamic block, (ulong)-1 without a stream).
  * The gz* file API (csrc/gz_api.hip) is host code around these entry points.
  */
 #ifndef ZMI355_ZLIB_H

@@ -6,10 +6,10 @@ import pytest
 # the libraries read their ZMI_* tuning / test overrides only in a process that has ZMI_TUNING set (checked once, at the
 # first call): the tests use them (segment sizes, queue limits, chunk sizes), a product process never calls getenv()
 os.environ.setdefault("ZMI_TUNING", "1")
-# launches of up to 512 streams take the multi-wave decode kernel in the product; the parity tests are mostly launches of a few
-# dozen streams and must reach the one-wave-per-stream kernel -- the one the benchmark times -- so "more than 16 streams" selects
-# it here, as it did until round 4 (tests of the multi-wave kernel on larger launches: test_multi_wave_decode_up_to_512_streams)
-os.environ.setdefault("ZMI_INF_MW_MAX", "16")
+# Decode-kernel selection: the product gives every stream of a launch of up to 512 streams a 16-wave workgroup
+# (zmi_inflate_kernel<*, 16>) and one wave per stream above that (the kernel the benchmark times).  The parity launches are a few
+# dozen streams, so every test that decodes runs TWICE (fixture `inf_selection`): "product" = the library's own selection, nothing
+# overridden; "onewave" = ZMI_INF_MW_MAX=16, which sends the same launches of 17+ streams through the one-wave kernel.
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -26,6 +26,16 @@ def pytest_collection_modifyitems(config, items):
         for item in items:
             if item.get_closest_marker("timeout") is None:
                 item.add_marker(pytest.mark.timeout(600))
+
+
+@pytest.fixture(params=["product", "onewave"])
+def inf_selection(request, monkeypatch):
+    """every inflate family under both decode kernels; the override is read per call (zmi_api.hip)"""
+    if request.param == "onewave":
+        monkeypatch.setenv("ZMI_INF_MW_MAX", "16")
+    else:
+        monkeypatch.delenv("ZMI_INF_MW_MAX", raising=False)
+    return request.param
 
 
 @pytest.fixture(scope="session")

@@ -63,10 +63,25 @@ static int do_recv(mock_op* o) {
     return 6;
 }
 
+/* a send is complete when its receiver has taken it (the file is gone): a send nobody receives blocks its group, as on RCCL,
+ * and fails the test after the time-out instead of passing silently */
+static int wait_taken(mock_op* o, unsigned long long seq) {
+    char fin[700];
+    snprintf(fin, sizeof fin, "%s/m_%d_%d_%llu", o->c->dir, o->c->rank, o->peer, seq);
+    struct timespec ts = {0, 2000000};
+    for (int spin = 0; spin < 30000; ++spin) {   /* 60 s */
+        if (access(fin, F_OK) != 0) return 0;
+        nanosleep(&ts, NULL);
+    }
+    return 7;
+}
+
 static int run_ops(void) {
     int rc = 0;
-    for (int i = 0; i < g_nops && !rc; ++i) if (g_ops[i].kind == OP_SEND) rc = do_send(&g_ops[i]);
+    unsigned long long seq[4096];
+    for (int i = 0; i < g_nops && !rc; ++i) if (g_ops[i].kind == OP_SEND) { seq[i] = g_ops[i].c->sent[g_ops[i].peer]; rc = do_send(&g_ops[i]); }
     for (int i = 0; i < g_nops && !rc; ++i) if (g_ops[i].kind == OP_RECV) rc = do_recv(&g_ops[i]);
+    for (int i = 0; i < g_nops && !rc; ++i) if (g_ops[i].kind == OP_SEND) rc = wait_taken(&g_ops[i], seq[i]);
     g_nops = 0;
     return rc;
 }
@@ -100,7 +115,7 @@ int ncclCommCount(ncclComm_t c, int* n) { *n = c->world; return 0; }
 int ncclCommUserRank(ncclComm_t c, int* r) { *r = c->rank; return 0; }
 const char* ncclGetErrorString(int r) {
     switch (r) { case 0: return "ok"; case 2: return "mock: file error"; case 4: return "mock: invalid argument";
-                 case 5: return "mock: send / receive size mismatch"; case 6: return "mock: receive timed out"; default: return "mock: error"; }
+                 case 5: return "mock: send / receive size mismatch"; case 6: return "mock: receive timed out"; case 7: return "mock: a send was never received"; default: return "mock: error"; }
 }
 int ncclGroupStart(void) { g_depth++; return 0; }
 int ncclGroupEnd(void) {

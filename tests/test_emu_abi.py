@@ -2,11 +2,14 @@
 import ctypes as C
 import os
 
+import pytest
+
 import oracle_lib
 import zlib_abi_harness as H
 import zmi_ctypes
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_zlib_abi_on_emulator(monkeypatch):
     monkeypatch.setenv("ZMI_ABI_SEGMENT", "4096")  # several chained segments even for small inputs
     zmi_ctypes.load_emu()
@@ -35,6 +38,7 @@ def test_window_carry_over_between_segments(monkeypatch):
     assert sizes["1"] < whole * 1.03, (sizes, whole)       # with the window carried the split is nearly free
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_preset_dictionary_and_history_across_calls(monkeypatch):
     import zlib
     monkeypatch.setenv("ZMI_ABI_SEGMENT", "8192")
@@ -52,6 +56,7 @@ def test_preset_dictionary_and_history_across_calls(monkeypatch):
     assert len(chunked) < len(one) * 1.06, (len(chunked), len(one))   # ten flushes: markers + block headers only
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_gzip_header_copy_and_dictionary_queries(monkeypatch):
     monkeypatch.setenv("ZMI_ABI_SEGMENT", "8192")
     zmi_ctypes.load_emu()
@@ -59,12 +64,14 @@ def test_gzip_header_copy_and_dictionary_queries(monkeypatch):
     H.header_copy_checks(lib, oracle_lib.load().gen_shard(2, 40000))
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_hands_out_output_progressively():
     zmi_ctypes.load_emu()
     lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
     H.progressive_inflate_checks(lib, oracle_lib.load().gen_shard(0, 60000))
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_streaming_entry_points():
     """packet-wise and byte-wise inflate on the resumable device decode, inflateSync / Prime / Mark / Validate /
     SyncPoint, inflateBack, deflatePrime / deflateUsed"""
@@ -74,6 +81,7 @@ def test_streaming_entry_points():
     H.streaming_checks(lib, o.gen_shard(0, 40000) + o.gen_shard(3, 30000), syslib=C.CDLL("libz.so.1"))
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_block_and_trees_stops():
     """inflate(Z_BLOCK) / inflate(Z_TREES): every call's return code, input left, output and data_type equal the system
     zlib's (the reference's own tests: test-libz-rs-sys/src/inflate.rs:640-676, :2036-2078)"""
@@ -83,6 +91,7 @@ def test_inflate_block_and_trees_stops():
     assert H.block_stop_checks(lib, C.CDLL("libz.so.1"), o.gen_shard(0, 40000) + o.gen_shard(3, 30000)) > 50
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_gz_file_api(tmp_path):
     """gzopen ... gzclose against Python's gzip module and the system's libz (libz-rs-sys/src/gz.rs)"""
     zmi_ctypes.load_emu()
@@ -90,6 +99,7 @@ def test_gz_file_api(tmp_path):
     H.gz_checks(lib, tmp_path, oracle_lib.load().gen_shard(1, 60000), syslib=C.CDLL("libz.so.1"))
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_reference_inflate_vectors_through_the_stream_abi():
     """the golden bitstreams / fixtures of the reference's tests through inflate(), whole and in steps"""
     import json
@@ -99,6 +109,7 @@ def test_reference_inflate_vectors_through_the_stream_abi():
     assert H.golden_inflate_checks(lib, vectors) > 50
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_attempt_limits(monkeypatch):
     """the bounds inside inflate(): one device decode sees a limited slice of the buffered input, and decoding pauses
     while the caller has not fetched what is queued -- shrunk through the environment so that a small stream gets there"""
@@ -116,6 +127,7 @@ def test_inflate_attempt_limits(monkeypatch):
         assert rc == H.Z_STREAM_END and out == data and unused in (0, 4), (take, queue, rc, len(out), unused)
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_random_streaming_roundtrips():
     """randomised pieces / rooms / flush arguments through inflate() against streams of the system's zlib"""
     zmi_ctypes.load_emu()
@@ -125,6 +137,7 @@ def test_random_streaming_roundtrips():
         H.random_streaming_roundtrips(lib, o, 6, seed)
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_streams_with_flush_points_are_decoded_as_segments():
     """inflate() of streams with sync / full flush points: the segment-parallel decode gives the serial decode's results.
     (A process of its own: the library reads its tuning variables once.)"""
@@ -145,6 +158,7 @@ def test_streams_with_flush_points_are_decoded_as_segments():
     assert used and max(used) >= 4, used   # the parallel path ran
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_streams_without_flush_points_are_decoded_as_blocks():
     """inflate() and uncompress() of ordinary streams (no flush points): the device finds the dynamic block headers and decodes the
     blocks side by side (zmi_inflate_blocks); results and error codes are those of the serial path.  (A process of its own: the
@@ -214,6 +228,7 @@ def test_random_deflate_streams(monkeypatch):
         assert zlib.decompressobj(wbits).decompress(comp) == data, (r, n, wbits)
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_config_matrix_roundtrips(monkeypatch):
     """end_to_end.rs's property over level x windowBits x memLevel x strategy; small windows must bound the distances"""
     monkeypatch.setenv("ZMI_ABI_SEGMENT", "16384")
@@ -229,12 +244,14 @@ def test_misc_entry_points():
     H.misc_symbol_checks(lib, oracle_lib.load())
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_streams_on_concurrent_threads():
     zmi_ctypes.load_emu()
     lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
     H.threaded_roundtrips(lib, oracle_lib.load(), threads=4, rounds=3)
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_input_handback_after_a_paused_decode(monkeypatch, tmp_path):
     monkeypatch.setenv("ZMI_ABI_QUEUE", "4096")
     zmi_ctypes.load_emu()

@@ -82,6 +82,7 @@ def test_deflate_strategies(eng, o):
             assert strategy_token_rules(outs[0][2:-4], strat) == d
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_kernel_matches_oracle(eng, o):
     blobs = [b"", b"a", b"hello world", bytes(1000), b"abc" * 3000, o.gen_shard(0, 1 << 13), o.gen_shard(6, 1 << 13)]
     for wrap, wb in ((1, 15), (2, 31), (0, -15)):
@@ -99,17 +100,20 @@ def test_inflate_kernel_matches_oracle(eng, o):
     assert all(s == 0 for s in st) and outs == blobs + [blobs[5]]
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_kernel_golden_bitstreams(eng, o):
     import parity_checks
     assert parity_checks.golden_bitstreams_exact(eng.inflate, o) >= 20
     assert parity_checks.golden_files_exact(eng.inflate, o) >= 10
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_kernel_corrupt_streams_report_the_oracles_code(eng, o):
     import parity_checks
     parity_checks.corrupt_streams_exact(eng.inflate, o, o.gen_shard(2, 1 << 13))
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_kernel_errors(eng, o):
     d = o.gen_shard(2, 1 << 13)
     good = zlib.compress(d, 6)
@@ -120,6 +124,7 @@ def test_inflate_kernel_errors(eng, o):
     assert st[1] in (-3, -5) and st[2] == -3 and st[3] == -5 and st[4] == -5 and st[5] == -3
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_many_small_blocks(eng, o):
     """block headers, empty stored blocks and the 1 KiB input chunk boundary meet in every alignment"""
     d = o.gen_shard(0, 12000) + o.gen_shard(6, 9000)
@@ -132,6 +137,7 @@ def test_inflate_many_small_blocks(eng, o):
             assert st == [0] and outs[0] == d
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_long_distances_and_runs(eng, o):
     r = o.prng_bytes(11, 32768, 1)
     blobs = [r + r + r[:700],                       # distance 32768, maximal lengths
@@ -182,6 +188,7 @@ def resolve_window_edge_streams(o):
     return cases
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_resolve_window_edge(eng, o):
     cases = resolve_window_edge_streams(o)
     for s, want in cases:
@@ -229,6 +236,7 @@ def resolve_near_far_streams(o):
     return cases
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_resolve_near_far_boundary(eng, o):
     cases = resolve_near_far_streams(o)
     for s, want in cases:
@@ -245,6 +253,7 @@ def test_inflate_resolve_near_far_boundary(eng, o):
     assert st == [0] * len(cases) and outs == [w for _, w in cases]
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_unaligned_layout_and_scratch_limit(eng, o):
     blobs = [o.gen_shard(1, 5000), o.gen_shard(4, 3001), b"q" * 777 + o.gen_shard(6, 2000), o.gen_shard(2, 4097)]
     streams = [zlib.compress(b, 6) for b in blobs]
@@ -287,6 +296,7 @@ def test_adaptive_block_splitting(eng, o, monkeypatch):
     assert len(outs[0]) <= len(noise) + len(noise) // 8 + 64
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_resumable_inflate_from_block_checkpoints():
     """zmi_inflate_resume (include/zmi355.h): cut streams, restart at the reported block boundary with the output in
     front of it as history -- the device half of the streaming inflate (zlib-rs/src/inflate.rs:288-320)"""
@@ -298,6 +308,7 @@ def test_resumable_inflate_from_block_checkpoints():
         eng.close()
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_host_batch_pipeline_chunks(monkeypatch):
     """zmi_deflate_batch cuts a host batch into chunks that cycle through two device slots (copy-in / kernels /
     copy-out on three streams): same bytes as the one-chunk path, every shard in its own slot of the output"""
@@ -396,16 +407,17 @@ def test_pack_slab_kernel(eng, o):
     assert slab == b"".join(few) and off == [0, 70001, 70001 + 65536]
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_large_streams_fast_pass(eng, o):
     """the lane-serial fast pass of the decode kernel (inflate.hip inf_fast_pass) only runs on streams with >= 4 KiB left"""
     import parity_checks
     assert parity_checks.large_stream_checks(eng.inflate, o, lambda blobs, lvl, wrap: eng.deflate(blobs, level=lvl, wrap=wrap)) > 60
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_multi_wave_decode_up_to_512_streams(eng, o, monkeypatch):
-    """the product gives every stream of a launch of up to 512 streams a workgroup of 16 waves (round 4; the other tests force the
-    one-wave kernel on such launches with ZMI_INF_MW_MAX=16): the same checks through the multi-wave kernel"""
-    monkeypatch.setenv("ZMI_INF_MW_MAX", "512")
+    """the product gives every stream of a launch of up to 512 streams a workgroup of 16 waves (round 4; `inf_selection`
+    "product"; "onewave" sends the same launches through the one-wave kernel)"""
     assert parity_checks.literal_group_checks(eng.inflate, o, size=1 << 13) > 60
     assert parity_checks.fixed_code_checks(eng.inflate, o, size=1 << 13) > 40
     assert parity_checks.golden_bitstreams_exact(eng.inflate, o) >= 20
@@ -416,22 +428,26 @@ def test_multi_wave_decode_up_to_512_streams(eng, o, monkeypatch):
     assert st == [0] * 40 and back == blobs
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_fixed_code_streams_through_the_fast_pass(eng, o):
     """BTYPE 01 blocks: the fast pass finds its lanes' starts by walking every bit phase (no self-synchronisation to live on)"""
     assert parity_checks.fixed_code_checks(eng.inflate, o) > 40
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_literal_groups_in_the_lane_walk(eng, o):
     """up to four literals per iteration of the decode kernel's lane walk: literal-only and skewed-alphabet streams, corrupt variants"""
     assert parity_checks.literal_group_checks(eng.inflate, o, size=1 << 14) > 60
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_truncated_stored_blocks_match_the_oracle():
     e = zmi_ctypes.Engine(zmi_ctypes.load_emu())
     assert parity_checks.truncated_stored_checks(lambda streams, caps, wrap: e.inflate(streams, caps, wrap=wrap), oracle_lib.load()) == 8
     e.close()
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_split_inflate_equals_serial_inflate():
     """one stream decoded as segments cut at its flush points (zmi_inflate_split): the results of zmi_inflate_resume,
     whatever the proposed cuts are (true markers, data that looks like one, random offsets)"""
@@ -439,6 +455,7 @@ def test_split_inflate_equals_serial_inflate():
     assert parity_checks.split_inflate_checks(e, oracle_lib.load()) == 12
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_block_scan_inflate_equals_serial_decode(monkeypatch):
     """zmi_inflate_blocks: restart points found by the device's scan for dynamic block headers (csrc/blockscan.hip)"""
     monkeypatch.setenv("ZMI_TUNING", "1")
@@ -452,6 +469,7 @@ def test_block_scan_inflate_equals_serial_decode(monkeypatch):
     e.close()
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_jump_resolve_equals_serial_resolve():
     """few streams: back-references resolved by pointer jumping (resolve_jump.hip) -- byte for byte the serial pass's output"""
     e = zmi_ctypes.Engine(zmi_ctypes.load_emu())

@@ -123,6 +123,17 @@ def _worker(rank, world, n_total, wire, q):
         # argument errors are reported, not crashed on
         assert L.zmi_exchange_slabs(comm, _p(slab), _p(totals), ptrs, 0, -1, None) == -103
         assert L.zmi_exchange_slabs(comm, _p(slab), _p(totals), ptrs, 4096, world, None) == -103
+        # a receiving rank that leaves a peer's entry NULL is refused on the spot -- that peer would send into nothing and the
+        # group would hang on RCCL (the mock blocks on an unmatched send too); every rank does it here, so nothing is posted
+        nulls = (C.c_void_p * world)(*[None] * world)
+        assert L.zmi_exchange_slabs(comm, _p(slab), _p(totals), nulls, 4096, -1, None) == -103
+        assert L.zmi_exchange_slabs_round(comm, _p(slab), _p(totals), 0, 4096, nulls, -1, None) == -103
+        assert L.zmi_exchange_slabs(comm, _p(slab), _p(totals), None, 4096, -1, None) == -103
+        # ... but a rank that does not receive (gather-to-root) needs no room at all
+        ok(L.zmi_exchange_slabs(comm, _p(slab), _p(totals), ptrs if rank == 0 else None, 4096, 0, None), "gather to root, NULL d_recv elsewhere")
+        # the ranks must agree on n_local (short ranks pad with zero sizes): a mismatch is reported on EVERY rank, before the
+        # table's all-gather could hang on it
+        assert L.zmi_exchange_sizes(comm, _p(sizes), n_local - (1 if rank == 0 else 0), _p(table), None) == -103
         ok(L.zmi_comm_destroy(comm), "zmi_comm_destroy")
         eng.close()
         q.put((rank, "ok"))

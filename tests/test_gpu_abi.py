@@ -14,12 +14,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_zlib_abi_on_gpu():
     from zlib_rs_amd import _build
     lib = H.bind(C.CDLL(_build.ABI_LIB))
     H.run_abi_checks(lib, oracle_lib.load(rebuild=False), sizes=(0, 1, 100, 5000, 70000, 3 << 20))
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_preset_dictionary_and_window_carry_on_gpu():
     import zlib
     from zlib_rs_amd import _build
@@ -37,12 +39,14 @@ def test_preset_dictionary_and_window_carry_on_gpu():
     assert len(chunked) < len(one) * 1.01, (len(chunked), len(one))
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_gzip_header_copy_and_dictionary_queries_on_gpu():
     from zlib_rs_amd import _build
     lib = H.bind(C.CDLL(_build.ABI_LIB))
     H.header_copy_checks(lib, oracle_lib.load(rebuild=False).gen_shard(2, 1500000))
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_hands_out_output_progressively_on_gpu():
     from zlib_rs_amd import _build
     lib = H.bind(C.CDLL(_build.ABI_LIB))
@@ -60,6 +64,7 @@ def test_c_program_links_and_roundtrips(tmp_path):
     assert "abi_smoke ok" in r.stdout
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_streaming_entry_points_on_gpu():
     """packet-wise and piece-wise inflate on the resumable device decode, inflateSync / Prime / Mark / Validate /
     SyncPoint, inflateBack, deflatePrime / deflateUsed; the system's zlib reads the primed stream too"""
@@ -69,6 +74,7 @@ def test_streaming_entry_points_on_gpu():
     H.streaming_checks(lib, o.gen_shard(0, 400000) + o.gen_shard(3, 300000), syslib=C.CDLL("libz.so.1"))
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_block_and_trees_stops_on_gpu():
     """inflate(Z_BLOCK) / inflate(Z_TREES) on the device decode's block and header stops: call by call the system zlib's
     return code, input left, output and data_type"""
@@ -78,6 +84,7 @@ def test_inflate_block_and_trees_stops_on_gpu():
     assert H.block_stop_checks(lib, C.CDLL("libz.so.1"), o.gen_shard(0, 400000) + o.gen_shard(3, 300000)) > 50
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_streaming_inflate_large_in_small_chunks_on_gpu():
     """24 MiB through inflate() in 64 KiB pieces with a 256 KiB output buffer (the zpipe.c loop): bit-exact, and the
     host state stays small -- the decode restarts at block checkpoints instead of buffering the stream"""
@@ -93,6 +100,7 @@ def test_streaming_inflate_large_in_small_chunks_on_gpu():
         assert rc == H.Z_STREAM_END and out == data and unused == 4
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_gz_file_api_on_gpu(tmp_path):
     """gzopen ... gzclose (libz-rs-sys/src/gz.rs) against Python's gzip module and the system's libz, 3 MiB members"""
     from zlib_rs_amd import _build
@@ -100,6 +108,7 @@ def test_gz_file_api_on_gpu(tmp_path):
     H.gz_checks(lib, tmp_path, oracle_lib.load(rebuild=False).gen_shard(1, 3 << 20), syslib=C.CDLL("libz.so.1"))
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_reference_inflate_vectors_through_the_stream_abi_on_gpu():
     """the golden bitstreams / fixtures of the reference's tests through inflate(), whole and in steps"""
     import json
@@ -109,6 +118,7 @@ def test_reference_inflate_vectors_through_the_stream_abi_on_gpu():
     assert H.golden_inflate_checks(lib, vectors, steps=(0, 1, 2, 3, 5, 17, 64)) > 100
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_streams_with_flush_points_are_decoded_as_segments_on_gpu():
     """inflate() of streams with sync / full flush points (marker look-alikes inside stored blocks included): the
     segment-parallel decode (zmi_inflate_split) gives the serial decode's bytes and codes; truncated and corrupted variants"""
@@ -117,6 +127,7 @@ def test_streams_with_flush_points_are_decoded_as_segments_on_gpu():
     assert H.flush_point_stream_checks(lib, oracle_lib.load(rebuild=False), seeds=range(800, 812), big=True) == 36
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_random_streaming_roundtrips_on_gpu():
     """randomised pieces / rooms / flush arguments through inflate() against streams of the system's zlib"""
     from zlib_rs_amd import _build

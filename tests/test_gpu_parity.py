@@ -83,6 +83,7 @@ def test_generator_matches_cpu_twin(engine):
         assert s == o.gen_shard(i, 1 << 16), "shard %d differs from the CPU generator" % i
 
 
+@pytest.mark.usefixtures("inf_selection")
 @pytest.mark.parametrize("level", [1, 6, 9])
 def test_deflate_roundtrip_full_size(engine, level):
     shards = _gen(engine, 16)
@@ -148,6 +149,7 @@ def test_deflate_unaligned_offsets(engine):
         assert zlib.decompress(bytes(out[i, :olen[i]])) == base[offs[i]:offs[i] + lens[i]]
 
 
+@pytest.mark.usefixtures("inf_selection")
 @pytest.mark.parametrize("wrap,level", [(1, 6), (2, 6), (0, 6), (1, 1), (1, 9), (2, 0)])
 def test_inflate_matches_cpu(engine, wrap, level):
     shards = _gen(engine, 16)
@@ -162,6 +164,7 @@ def test_inflate_matches_cpu(engine, wrap, level):
         assert o == s
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_of_gpu_deflate(engine):
     shards = _gen(engine, 16)
     for level in (1, 6, 9):
@@ -172,6 +175,7 @@ def test_inflate_of_gpu_deflate(engine):
         assert back == shards
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_errors(engine):
     s = _gen(engine, 1, 1 << 16)[0]
     good = zlib.compress(s, 6)
@@ -196,6 +200,7 @@ def test_inflate_errors(engine):
     assert st[6] == -3                  # invalid block type (BTYPE=3)
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_unaligned_layout_and_patterns(engine):
     """odd input / output offsets (the 4- and 16-byte aligned paths are not taken), guard bytes behind every
     stream's capacity, long distances, self-overlapping runs, many tiny blocks, a hole-free stretch longer than
@@ -232,6 +237,7 @@ def test_inflate_unaligned_layout_and_patterns(engine):
         assert bytes(h[off_ + c:off_ + c + 3]) == b"\xee\xee\xee"   # nothing written past the capacity
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_fuzz_roundtrip_mixed(engine):
     """ragged random batches both ways against system zlib: random sizes (0 .. 300 KiB), data classes, levels,
     strategies, wrappers and window sizes"""
@@ -275,6 +281,7 @@ def test_checksums(engine):
         assert int(c[i]) == zlib.crc32(b), i
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_resumable_inflate_from_block_checkpoints():
     """zmi_inflate_resume through the C ABI on the MI355X: cut streams restart at the reported block boundary"""
     import oracle_lib
@@ -287,6 +294,7 @@ def test_resumable_inflate_from_block_checkpoints():
         eng.close()
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_host_batch_pipeline_on_gpu(monkeypatch):
     """zmi_deflate_batch / zmi_inflate_batch with host buffers: chunks cycle through two device slots on three HIP
     streams (copy-in / kernels / copy-out overlap); same bytes as the one-chunk path, bit-exact round trip"""
@@ -320,18 +328,21 @@ def _inflate_fn(engine):
     return lambda streams, caps, wrap: _inflate(engine, streams, caps, wrap=wrap)
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_golden_inflate_bitstreams_through_the_batch_kernel(engine):
     import oracle_lib
     import parity_checks
     assert parity_checks.golden_bitstreams_exact(_inflate_fn(engine), oracle_lib.load(rebuild=False)) >= 20
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_golden_inflate_files_through_the_batch_kernel(engine):
     import oracle_lib
     import parity_checks
     assert parity_checks.golden_files_exact(_inflate_fn(engine), oracle_lib.load(rebuild=False)) >= 10
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_corrupt_streams_report_the_oracles_code(engine):
     import oracle_lib
     import parity_checks
@@ -340,6 +351,7 @@ def test_corrupt_streams_report_the_oracles_code(engine):
         assert parity_checks.corrupt_streams_exact(_inflate_fn(engine), o, _gen(engine, 8, 1 << 16)[cls]) > 30
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_resolve_window_edge_on_gpu(engine):
     """ring restart of the resolve pass at p % 1024 in 1021..1023 with distances 32766..32768"""
     import oracle_lib
@@ -350,6 +362,7 @@ def test_resolve_window_edge_on_gpu(engine):
     assert outs == [w for _, w in cases]
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_resolve_near_far_boundary_on_gpu(engine):
     """back-references around RES_NEAR (ring vs HBM source), sources that are earlier holes, mixed batches"""
     import oracle_lib
@@ -441,6 +454,7 @@ def test_long_matches_are_extended_by_one_lane_per_run_on_gpu(engine):
     assert parity_checks.long_match_checks(deflate, oracle_lib.load(rebuild=False), scale=8) == 36
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_inflate_large_streams_fast_pass_on_gpu(engine):
     import oracle_lib
     import parity_checks
@@ -450,12 +464,14 @@ def test_inflate_large_streams_fast_pass_on_gpu(engine):
     assert n > 60
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_truncated_stored_blocks_match_the_oracle_on_gpu(engine):
     import oracle_lib
     import parity_checks
     assert parity_checks.truncated_stored_checks(_inflate_fn(engine), oracle_lib.load(rebuild=False)) == 8
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_fixed_code_streams_through_the_fast_pass_on_gpu(engine):
     """BTYPE 01 blocks (Z_FIXED, the reference's level 1): every class, corrupt / truncated variants with the oracle's codes"""
     import oracle_lib
@@ -463,6 +479,7 @@ def test_fixed_code_streams_through_the_fast_pass_on_gpu(engine):
     assert parity_checks.fixed_code_checks(_inflate_fn(engine), oracle_lib.load(rebuild=False), size=1 << 19) > 40
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_literal_groups_in_the_lane_walk_on_gpu(engine):
     """up to four literals per iteration of the decode kernel's lane walk (literal-only and skewed-alphabet streams, corrupt variants)"""
     import oracle_lib
@@ -470,12 +487,12 @@ def test_literal_groups_in_the_lane_walk_on_gpu(engine):
     assert parity_checks.literal_group_checks(_inflate_fn(engine), oracle_lib.load(rebuild=False), size=1 << 19) > 60
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_multi_wave_decode_up_to_512_streams_on_gpu(engine, monkeypatch):
-    """launches of up to 512 streams take the multi-wave kernel in the product (the other tests force the one-wave kernel there)"""
+    """launches of up to 512 streams take the multi-wave kernel in the product (`inf_selection` "product"), under "onewave" the one-wave kernel"""
     import oracle_lib
     import parity_checks
     o = oracle_lib.load(rebuild=False)
-    monkeypatch.setenv("ZMI_INF_MW_MAX", "512")
     assert parity_checks.literal_group_checks(_inflate_fn(engine), o, size=1 << 18) > 60
     assert parity_checks.fixed_code_checks(_inflate_fn(engine), o, size=1 << 18) > 40
     assert parity_checks.golden_bitstreams_exact(_inflate_fn(engine), o) >= 20
@@ -486,6 +503,7 @@ def test_multi_wave_decode_up_to_512_streams_on_gpu(engine, monkeypatch):
     assert all(int(x) == 0 for x in st) and back == blobs
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_split_inflate_equals_serial_inflate_on_gpu():
     """one stream decoded as segments cut at its flush points, on the whole chip (zmi_inflate_split): the results of the
     serial zmi_inflate_resume for true markers, false ones, history, corruption, short room"""
@@ -497,6 +515,7 @@ def test_split_inflate_equals_serial_inflate_on_gpu():
     eng.close()
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_block_scan_inflate_equals_serial_inflate_on_gpu():
     """one stream WITHOUT flush points: the device finds its dynamic block headers (csrc/blockscan.hip) and decodes the blocks
     side by side (zmi_inflate_blocks) -- the results of the serial zmi_inflate_resume for streams of the system zlib and of the
@@ -509,6 +528,7 @@ def test_block_scan_inflate_equals_serial_inflate_on_gpu():
     eng.close()
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_uncompress_of_a_large_stream_takes_the_parallel_path_and_keeps_the_reference_codes():
     """uncompress() of streams of 256 KiB and more goes through zmi_inflate_blocks (tests/zlib_abi_harness.py::uncompress_large_checks)"""
     import ctypes as C
@@ -519,6 +539,7 @@ def test_uncompress_of_a_large_stream_takes_the_parallel_path_and_keeps_the_refe
     assert H.uncompress_large_checks(lib, oracle_lib.load(rebuild=False), 1 << 20) == 6
 
 
+@pytest.mark.usefixtures("inf_selection")
 def test_jump_resolve_equals_serial_resolve_on_gpu():
     """few streams: back-references resolved by pointer jumping on the whole chip (csrc/resolve_jump.hip) -- byte for byte
     the output of the one-wave-per-stream pass, incl. a 300 KB run of one byte, history and a corrupt stream"""

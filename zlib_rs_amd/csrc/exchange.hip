@@ -40,6 +40,7 @@ struct zx_api {
     int (*CommAbort)(zx_comm_t) = nullptr;
     int (*CommCount)(zx_comm_t, int*) = nullptr;
     int (*CommUserRank)(zx_comm_t, int*) = nullptr;
+    int (*CommCuDevice)(zx_comm_t, int*) = nullptr;   // optional: only zmi_comm_adopt's device check uses it
     int (*AllGather)(const void*, void*, size_t, int, zx_comm_t, hipStream_t) = nullptr;
     int (*Send)(const void*, size_t, int, int, zx_comm_t, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, zx_comm_t, hipStream_t) = nullptr;
@@ -88,6 +89,7 @@ static void zx_load() {
     ZX_SYM(GroupEnd, "ncclGroupEnd");
     ZX_SYM(GetErrorString, "ncclGetErrorString");
 #undef ZX_SYM
+    *(void**)(&g_rccl.CommCuDevice) = dlsym(g_rccl.handle, "ncclCommCuDevice");
     if (!ok) { dlclose(g_rccl.handle); g_rccl.handle = nullptr; }
 }
 static int zx_need_rccl() {
@@ -105,6 +107,7 @@ struct zmi_comm {
     zx_comm_t comm = nullptr;
     int world = 1, rank = 0, device = 0;
     bool owned = false;   // created by zmi_comm_create (destroyed with the handle) or adopted from the host
+    uint32_t* nl_dev = nullptr;   // 65 dwords: the ranks' n_local (zmi_exchange_sizes checks that they agree)
 };
 
 struct zx_dev_guard {
@@ -149,6 +152,12 @@ extern "C" int zmi_comm_adopt(zmi_comm** out, zmi_ctx* ctx, void* nccl_comm) {
     int r = g_rccl.CommCount(c->comm, &c->world);
     if (r == 0) r = g_rccl.CommUserRank(c->comm, &c->rank);
     if (r != 0) { delete c; return zx_fail(ZMI_E_RCCL, "ncclCommCount / ncclCommUserRank", g_rccl.GetErrorString(r)); }
+    // the exchange runs under a device guard for the CONTEXT's device: a communicator that lives on another GPU is an argument error
+    int cdev = c->device;
+    if (g_rccl.CommCuDevice && g_rccl.CommCuDevice(c->comm, &cdev) == 0 && cdev != c->device) {
+        delete c;
+        return zx_fail(ZMI_E_ARG, "zmi_comm_adopt: the communicator belongs to another device than the context");
+    }
     *out = c;
     return ZMI_E_OK;
 }
@@ -157,6 +166,7 @@ extern "C" int zmi_comm_destroy(zmi_comm* c) {
     if (!c) return ZMI_E_OK;
     int r = 0;
     if (c->owned && c->comm && g_rccl.handle) { zx_dev_guard g(c->device); r = g_rccl.CommDestroy(c->comm); }
+    if (c->nl_dev) { zx_dev_guard g(c->device); (void)hipFree(c->nl_dev); }
     delete c;
     return r == 0 ? ZMI_E_OK : zx_fail(ZMI_E_RCCL, "ncclCommDestroy", g_rccl.GetErrorString(r));
 }
@@ -165,6 +175,7 @@ extern "C" int zmi_comm_destroy(zmi_comm* c) {
 extern "C" int zmi_comm_abort(zmi_comm* c) {
     if (!c) return ZMI_E_OK;
     if (c->comm && g_rccl.handle) { zx_dev_guard g(c->device); (void)g_rccl.CommAbort(c->comm); }
+    if (c->nl_dev) { zx_dev_guard g(c->device); (void)hipFree(c->nl_dev); }
     delete c;
     return ZMI_E_OK;
 }
@@ -175,8 +186,25 @@ extern "C" int zmi_comm_rank(const zmi_comm* c) { return c ? c->rank : -1; }
 // d_table[r * n_local + j] = d_sizes[j] of rank r, on every rank
 extern "C" int zmi_exchange_sizes(zmi_comm* c, const uint32_t* d_sizes, uint32_t n_local, uint32_t* d_table, void* stream) {
     if (!c || !d_sizes || !d_table) return zx_fail(ZMI_E_ARG, "zmi_exchange_sizes: null argument");
-    if (n_local == 0) return ZMI_E_OK;
+    // Every rank must pass the SAME n_local (a job whose shard count does not divide by the world size pads the short ranks'
+    // tables with zero sizes): a mismatch would be an all-gather with different counts -- a hang or a garbage table.  n_local = 0
+    // on every rank is a no-op; on one rank only it is the same mismatch, so it takes part like any other value.
     zx_dev_guard g(c->device);
+    if (c->world > 1) {   // one dword per rank in front of the table's all-gather: 4 * world bytes, checked on the host
+        if (c->nl_dev == nullptr && hipMalloc((void**)&c->nl_dev, 4u * 65u) != hipSuccess) return zx_fail(ZMI_E_NOMEM, "zmi_exchange_sizes: hipMalloc");
+        uint32_t mine = n_local;
+        std::vector<uint32_t> all((size_t)c->world);
+        if (c->world > 64) return zx_fail(ZMI_E_ARG, "zmi_exchange_sizes: more than 64 ranks");
+        if (hipMemcpyAsync(c->nl_dev + 64, &mine, 4u, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
+            return zx_fail(ZMI_E_HIP, "zmi_exchange_sizes: copy of n_local");
+        ZX_NCCL(g_rccl.AllGather(c->nl_dev + 64, c->nl_dev, 1, ZX_UINT32, c->comm, (hipStream_t)stream));
+        if (hipMemcpyAsync(all.data(), c->nl_dev, 4u * (size_t)c->world, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+            hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+            return zx_fail(ZMI_E_HIP, "zmi_exchange_sizes: read-back of the ranks' n_local");
+        for (int p = 0; p < c->world; ++p)
+            if (all[(size_t)p] != n_local) return zx_fail(ZMI_E_ARG, "zmi_exchange_sizes: the ranks passed different n_local (pad with zero sizes)");
+    }
+    if (n_local == 0) return ZMI_E_OK;
     ZX_NCCL(g_rccl.AllGather(d_sizes, d_table, n_local, ZX_UINT32, c->comm, (hipStream_t)stream));
     return ZMI_E_OK;
 }
@@ -248,8 +276,11 @@ extern "C" int zmi_stitch_plan_dev(zmi_ctx* ctx, const uint32_t* d_table, uint32
 }
 
 // One round of the exchange: bytes [lo, lo + chunk_bytes) of every slab.  This rank sends that piece of its own slab to every
-// peer (root < 0) or to `root`; it receives peer p's piece into d_recv[p] + (recv_at_offset ? lo : 0) when it is a receiver and
-// d_recv[p] is not null.  All of it inside one group: the transfers of a round run concurrently, one link each.
+// peer (root < 0) or to `root`; it receives peer p's piece into d_recv[p] + (recv_at_offset ? lo : 0) when it is a receiver.
+// Sends and receives are decided by the SAME data on both sides -- the slab sizes every rank holds and the root -- never by what
+// a receiver happens to pass: a receiver has to take every peer's bytes (zx_check refuses a null entry for a peer whose slab is
+// not empty), otherwise that peer's ncclSend would have no partner and the group would hang.
+// All of it inside one group: the transfers of a round run concurrently, one link each.
 static int zx_round(zmi_comm* c, const uint8_t* d_slab, const uint64_t* slab_bytes, uint64_t lo, uint64_t chunk, void* const* d_recv,
                     bool recv_at_offset, int root, hipStream_t stream) {
     const bool receives = root < 0 || root == c->rank;
@@ -262,7 +293,7 @@ static int zx_round(zmi_comm* c, const uint8_t* d_slab, const uint64_t* slab_byt
             const uint64_t n = mine - lo < chunk ? mine - lo : chunk;
             rc = g_rccl.Send(d_slab + lo, (size_t)n, ZX_UINT8, p, c->comm, stream);
         }
-        if (rc == 0 && receives && d_recv && d_recv[p] && lo < slab_bytes[p]) {
+        if (rc == 0 && receives && lo < slab_bytes[p]) {
             const uint64_t n = slab_bytes[p] - lo < chunk ? slab_bytes[p] - lo : chunk;
             rc = g_rccl.Recv((uint8_t*)d_recv[p] + (recv_at_offset ? lo : 0), (size_t)n, ZX_UINT8, p, c->comm, stream);
         }
@@ -273,17 +304,23 @@ static int zx_round(zmi_comm* c, const uint8_t* d_slab, const uint64_t* slab_byt
     return 0;
 }
 
-static int zx_check(zmi_comm* c, const void* d_slab, const uint64_t* slab_bytes, uint64_t chunk, int root, const char* who) {
+static int zx_check(zmi_comm* c, const void* d_slab, const uint64_t* slab_bytes, uint64_t chunk, int root, void* const* d_recv,
+                    const char* who) {
     if (!c || !slab_bytes || chunk == 0) return zx_fail(ZMI_E_ARG, who, "null argument or zero chunk");
     if (root >= c->world) return zx_fail(ZMI_E_ARG, who, "root out of range");
     if (!d_slab && slab_bytes[c->rank]) return zx_fail(ZMI_E_ARG, who, "null slab");
+    if (root < 0 || root == c->rank) {   // this rank receives: every peer with bytes sends to it, so it needs room for each
+        for (int p = 0; p < c->world; ++p)
+            if (p != c->rank && slab_bytes[p] != 0 && (!d_recv || !d_recv[p]))
+                return zx_fail(ZMI_E_ARG, who, "a receiving rank must give room for every peer's slab (null d_recv entry)");
+    }
     return 0;
 }
 
 // whole slabs: d_recv[p] holds peer p's slab (slab_bytes[p] bytes) afterwards; rounds of chunk_bytes keep RCCL's staging bounded
 extern "C" int zmi_exchange_slabs(zmi_comm* c, const void* d_slab, const uint64_t* slab_bytes, void* const* d_recv,
                                   uint64_t chunk_bytes, int root, void* stream) {
-    if (int rc = zx_check(c, d_slab, slab_bytes, chunk_bytes, root, "zmi_exchange_slabs")) return rc;
+    if (int rc = zx_check(c, d_slab, slab_bytes, chunk_bytes, root, d_recv, "zmi_exchange_slabs")) return rc;
     zx_dev_guard g(c->device);
     uint64_t biggest = 0;
     for (int p = 0; p < c->world; ++p) biggest = slab_bytes[p] > biggest ? slab_bytes[p] : biggest;
@@ -296,7 +333,7 @@ extern "C" int zmi_exchange_slabs(zmi_comm* c, const void* d_slab, const uint64_
 // peer, reused by the next round once the caller has consumed it -- scattered it with zmi_copy_ranges_dev, written it out)
 extern "C" int zmi_exchange_slabs_round(zmi_comm* c, const void* d_slab, const uint64_t* slab_bytes, uint64_t lo, uint64_t chunk_bytes,
                                         void* const* d_stage, int root, void* stream) {
-    if (int rc = zx_check(c, d_slab, slab_bytes, chunk_bytes, root, "zmi_exchange_slabs_round")) return rc;
+    if (int rc = zx_check(c, d_slab, slab_bytes, chunk_bytes, root, d_stage, "zmi_exchange_slabs_round")) return rc;
     zx_dev_guard g(c->device);
     return zx_round(c, (const uint8_t*)d_slab, slab_bytes, lo, chunk_bytes, d_stage, false, root, (hipStream_t)stream);
 }

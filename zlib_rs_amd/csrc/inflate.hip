@@ -1977,15 +1977,13 @@ __global__ void __launch_bounds__(256) zmi_inflate_verify_kernel(const uint8_t* 
     if (detail) detail[s] = det;
 }
 
-// launches of up to this many streams take the multi-wave kernel (tests force the single-wave kernel on small launches with
-// ZMI_INF_MW_MAX under ZMI_TUNING: zmi_api.hip)
-static uint32_t g_inf_mw_max = 512u;
-extern "C" void zmi_launch_inflate_mw_max(uint32_t n) { g_inf_mw_max = n; }
+// mw_max: launches of up to this many streams take the multi-wave kernel (the context's value, 512 in the product; the tests run
+// every inflate family under 16 and under 512 -- ZMI_INF_MW_MAX with ZMI_TUNING, read per call in zmi_api.hip, no process state)
 extern "C" int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n_streams,
                                   uint32_t wrap, uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                                   uint32_t* d_out_len, uint32_t* d_in_used, uint32_t* d_check, int32_t* d_status,
                                   uint64_t* d_bitmap, uint64_t bitmap_words, uint64_t* d_bm_off, const uint32_t* d_out_hist,
-                                  const uint32_t* d_in_bit, uint32_t* d_resume, uint32_t* d_order, hipStream_t stream) {
+                                  const uint32_t* d_in_bit, uint32_t* d_resume, uint32_t* d_order, uint32_t mw_max, hipStream_t stream) {
     if (n_streams == 0) return 0;
     ZMI_LAUNCH(zmi_inflate_order_kernel, dim3(1), dim3(1024), 0, stream, d_in_len, n_streams, d_order);
     ZMI_LAUNCH(zmi_inflate_plan_kernel, dim3(1), dim3(1024), 0, stream, d_out_cap, n_streams, bitmap_words, d_bm_off);
@@ -1994,7 +1992,7 @@ extern "C" int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off,
     // long as its slowest stream, and a stream alone on a CU is latency-bound (32 ... 512 streams of 1 MiB, every data class: decode
     // 17.7 ... 18.1 -> 13.7 ... 13.9 ms; at 1024 streams one wave each is ahead, 18.2 against 19.3 ms); thousands of streams fill the
     // chip with one wave each
-    const bool mw = n_streams <= g_inf_mw_max;
+    const bool mw = n_streams <= mw_max;
 #define INF_GO(R, W, IB, RS) ZMI_LAUNCH((zmi_inflate_kernel<R, W>), dim3(n_streams), dim3(64u * W), 0, stream, d_in, d_in_off, d_in_len, wrap, d_out, \
                                 d_out_off, d_out_cap, d_out_len, d_in_used, d_check, d_status, d_bitmap, (const uint64_t*)d_bm_off, d_out_hist, IB, RS,  \
                                 (const uint32_t*)d_order)

@@ -97,6 +97,8 @@ struct zmi_ctx {
     std::atomic<int> hb_out_tight{-1};     // zmi_inflate_batch: did the last chunk decoded fill most of its capacity?  (-1: nothing decoded yet)
     uint32_t last_codes_used = 0;    // zmi_inflate_resume: table entries of the most recent dynamic block of the last call (inflateCodesUsed)
     uint64_t inflate_out_limit = 0;  // output bytes one inflate batch may cover; 0 = scratch_limit
+    bool inf_limit_exact = false;    // the caller of zmi_inflate_impl sized inflate_out_limit from the capacities of THIS call (host wrappers)
+    uint32_t inf_mw_max = 512u;      // inflate launches of up to this many streams give every stream a 16-wave workgroup (inflate.hip)
     hipStream_t host_stream = nullptr;  // zmi_ctx_set_stream: where the host-buffer wrappers copy and launch
     hipStream_t side = nullptr;         // deflate: the wrapper checksums run here, beside the match search (zmi_deflate_impl)
     hipEvent_t ev_fork{}, ev_join{};
@@ -595,12 +597,13 @@ static int zmi_inflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     rc = zmi_reserve(c->inf_bm, (size_t)(out_limit / 8u) + (size_t)n * 16u);
     if (rc) return rc;
     const uint64_t bm_words = ((out_limit / 8u) + (uint64_t)n * 16u) / 8u;
-    if (const char* mv = zmi_tune("ZMI_INF_MW_MAX")) zmi_launch_inflate_mw_max((uint32_t)atoi(mv));   // (tests: 16 = the single-wave kernel on small launches)
+    uint32_t mw_max = c->inf_mw_max;
+    if (const char* mv = zmi_tune("ZMI_INF_MW_MAX")) mw_max = (uint32_t)atoi(mv);   // (tests: both selections, per call)
     {
         zmi_scope_timer tm(c, ZMI_K_INFLATE, stream);
         int lrc = zmi_launch_inflate((const uint8_t*)d_in, d_in_off, d_in_len, n, (uint32_t)wrap, (uint8_t*)d_out, d_out_off, d_out_cap,
                                      d_out_len, d_used, d_check, d_status, (uint64_t*)c->inf_bm.p, bm_words, d_bm_off, d_out_hist, d_in_bit, d_resume,
-                                     d_order, stream);
+                                     d_order, mw_max, stream);
         if (lrc) return zmi_fail(ZMI_E_HIP, "inflate launch setup", (hipError_t)lrc);
     }
     // The resolve pass.  Thousands of streams: one wave per stream fills its holes in order.  A handful of streams would leave
@@ -609,7 +612,10 @@ static int zmi_inflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     // (below 256 KiB of capacity the serial pass takes less than the jump pass's two dozen launches)
     // (the pass sweeps out_limit indices whatever the streams' real capacities are -- they are device data: a limit far above what n
     // streams plausibly hold, 64 MiB each, says the caller did not size it for this call, and the serial pass is the safer choice)
-    bool jump = n <= 16u && out_limit <= (1ull << 30) && out_limit >= (256ull << 10) && out_limit <= (uint64_t)n * (64ull << 20) + (1ull << 20);
+    // (callers that sized the limit from this call's capacities -- zmi_inflate_resume, the host-buffer batch -- are exact: one stream of
+    // several hundred MiB keeps the jump pass)
+    bool jump = n <= 16u && out_limit <= (1ull << 30) && out_limit >= (256ull << 10) &&
+                (c->inf_limit_exact || out_limit <= (uint64_t)n * (64ull << 20) + (1ull << 20));
     if (!decode_only) {
     if (const char* jv = zmi_tune("ZMI_INF_JUMP")) jump = atoi(jv) != 0 && out_limit <= (1ull << 30);
     if (jump && zmi_reserve(c->inf_ptr, (size_t)bm_words * 256u + 512u) != 0) jump = false;   // (no room: the serial pass needs none)
@@ -1124,9 +1130,13 @@ static int zmi_d2h(zmi_ctx* c, void* dst, const void* src, size_t n, hipStream_t
             hipEventCreateWithFlags(&c->st_pin_ev[1], hipEventDisableTiming) != hipSuccess) bounce = false;
         else c->st_pin_ev_live = true;
     }
+    // every error return drains `hs` first: the callers have asynchronous copies into their own frames in flight on it (the
+    // `err` word of zmi_split_core), and the DMA into st_pin must not outlive the call either
     if (!bounce) {
-        ZMI_HIP(hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, hs));
-        ZMI_HIP(hipStreamSynchronize(hs));
+        hipError_t e = hipMemcpyAsync(dst, src, n, hipMemcpyDeviceToHost, hs);
+        const hipError_t es = hipStreamSynchronize(hs);
+        if (e == hipSuccess) e = es;
+        if (e != hipSuccess) return zmi_fail(ZMI_E_HIP, "zmi_d2h", e);
         return 0;
     }
     const unsigned T = zmi_host_threads() < 4u ? zmi_host_threads() : 4u;
@@ -1140,7 +1150,8 @@ static int zmi_d2h(zmi_ctx* c, void* dst, const void* src, size_t n, hipStream_t
         }
         if (k >= 1) {   // the piece before: wait for its DMA, copy it out (the DMA of piece k runs meanwhile)
             const size_t j = k - 1, len = n - j * CH < CH ? n - j * CH : CH;
-            ZMI_HIP(hipEventSynchronize(c->st_pin_ev[j & 1]));
+            const hipError_t ew = hipEventSynchronize(c->st_pin_ev[j & 1]);
+            if (ew != hipSuccess) { (void)hipStreamSynchronize(hs); return zmi_fail(ZMI_E_HIP, "zmi_d2h: hipEventSynchronize", ew); }
             std::vector<zmi_copy_job> jobs{{(uint8_t*)dst + j * CH, c->st_pin[j & 1].p, len}};
             zmi_parallel_copy(jobs, T);
         }
@@ -1439,7 +1450,8 @@ static int zmi_inflate_batch_simple(zmi_ctx* c, const uint8_t* in, const uint64_
     }
     const uint64_t saved_limit = c->inflate_out_limit;
     c->inflate_out_limit = tout + (1ull << 20);   // the capacities are known here: size the bitmap scratch exactly
-    struct restore { zmi_ctx* c; uint64_t v; ~restore() { c->inflate_out_limit = v; } } restore_limit{c, saved_limit};
+    c->inf_limit_exact = true;
+    struct restore { zmi_ctx* c; uint64_t v; ~restore() { c->inflate_out_limit = v; c->inf_limit_exact = false; } } restore_limit{c, saved_limit};
     zmi_dev_alloc A;
     uint8_t* d_in = (uint8_t*)A.get(tin + 16);
     uint8_t* d_out = (uint8_t*)A.get(tout + 16);
@@ -1716,7 +1728,8 @@ extern "C" int zmi_inflate_resume(zmi_ctx* c, const uint8_t* in, uint32_t in_len
     ZMI_HIP(hipMemcpyAsync(d, &m, sizeof(m), hipMemcpyHostToDevice, hs));
     const uint64_t saved_limit = c->inflate_out_limit;
     c->inflate_out_limit = (uint64_t)out_cap + (1ull << 16);
-    struct restore { zmi_ctx* c; uint64_t v; ~restore() { c->inflate_out_limit = v; } } restore_limit{c, saved_limit};
+    c->inf_limit_exact = true;
+    struct restore { zmi_ctx* c; uint64_t v; ~restore() { c->inflate_out_limit = v; c->inf_limit_exact = false; } } restore_limit{c, saved_limit};
     rc = zmi_inflate_resume_dev(c, c->st_in.p, (const uint64_t*)d, (const uint32_t*)(d + 16), (const uint32_t*)(d + 28), 1, c->st_out.p,
                                 (const uint64_t*)(d + 8), (const uint32_t*)(d + 20), (const uint32_t*)(d + 24), (uint32_t*)(d + 32),
                                 (int32_t*)(d + 36), (uint32_t*)(d + 40), (int32_t*)(d + 44), (uint32_t*)(d + 48), hs);

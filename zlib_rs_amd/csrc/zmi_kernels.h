@@ -80,8 +80,7 @@ int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off, const uint
                        uint32_t wrap, uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                        uint32_t* d_out_len, uint32_t* d_in_used, uint32_t* d_check, int32_t* d_status,
                        uint64_t* d_bitmap, uint64_t bitmap_words, uint64_t* d_bm_off, const uint32_t* d_out_hist,
-                       const uint32_t* d_in_bit, uint32_t* d_resume, uint32_t* d_order, hipStream_t stream);
-void zmi_launch_inflate_mw_max(uint32_t n);
+                       const uint32_t* d_in_bit, uint32_t* d_resume, uint32_t* d_order, uint32_t mw_max, hipStream_t stream);
 int zmi_launch_resolve_jump(uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_len, uint32_t n_streams,
                             const uint64_t* d_bitmap, const uint64_t* d_bm_off, int32_t* d_ptr, uint64_t n_idx, uint32_t rounds,
                             uint32_t* d_flags, hipStream_t stream);

@@ -121,8 +121,8 @@ class Engine:
         return goff, soff, [int(x) for x in host]
 
     def exchange_round(self, comm, slab, totals, lo, chunk_bytes, stage, root=-1):
-        """one bounded round of the slab exchange: stage[p] (a uint8 tensor of chunk_bytes, None for this rank / peers not
-        wanted) receives peer p's slab bytes [lo, lo + chunk_bytes)"""
+        """one bounded round of the slab exchange: stage[p] (a uint8 tensor of chunk_bytes; None for this rank, and on a rank that does
+        not receive -- root >= 0 and not this rank; a receiving rank must give room for every peer: ZMI_E_ARG otherwise) receives peer p's slab bytes [lo, lo + chunk_bytes)"""
         import ctypes as C
         world = len(stage)
         tb = (C.c_uint64 * world)(*[int(t) for t in totals[:world]])
