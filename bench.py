@@ -112,6 +112,20 @@ def oracle_members(n, shard_bytes, level, wrap, threads):
     return out.reshape(n, stride), ln, dt
 
 
+def csrc_sha16():
+    """what the kernels ARE: sha-256 over zlib_rs_amd/csrc/*.hip / *.h (names + contents), first 16 hex digits.  The counter files
+    under profiles/ record it (tools/prof_final.sh), and a file collected from other sources is not replayed (the GPU box has no
+    .git: a content hash, not a commit)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "zlib_rs_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def issue_replay():
     """roofline.issue: what these kernels are actually bound by (instruction issue, not HBM) -- per kernel
     the wave-instructions per byte by class, the SIMD cycles one of them costs and the fraction of VALU lanes that were active,
@@ -122,13 +136,16 @@ def issue_replay():
     if not files:
         return None
     j = json.load(open(files[-1]))
+    if j.get("_csrc_sha16") != csrc_sha16():
+        return {"stale": "profiles/%s was collected from other kernel sources (%s, now %s): not replayed -- rerun tools/prof_final.sh"
+                         % (os.path.basename(files[-1]), j.get("_csrc_sha16", "no hash recorded"), csrc_sha16())}
     nbytes = float(j["bytes_per_launch"])
     out = {"source": "profiles/%s (%s; replayed, not measured in this run)" % (os.path.basename(files[-1]), j.get("_collected", "?")),
            "per": "byte of raw data (deflate kernels: input, inflate kernels: output) of one 16 384 x 1 MiB launch",
            "cycles_per_instr": "SIMD cycles per wave-instruction = SQ_BUSY_CYCLES * 32 / (VALU + SALU + LDS instructions): the chip has 32 "
                                "shader engines counting busy cycles and 1024 SIMDs issuing",
            "lane_util": "SQ_THREAD_CYCLES_VALU / (64 * SQ_INSTS_VALU)", "kernels": {}}
-    for name in ("zmi_lz77_kernel_t", "zmi_encode_kernel", "zmi_inflate_kernel", "zmi_inflate_resolve_kernel"):
+    for name in ("zmi_lz77_kernel_t", "zmi_parse_kernel", "zmi_encode_kernel_t", "zmi_encode_kernel", "zmi_inflate_kernel", "zmi_inflate_resolve_kernel"):
         k = j["kernels"].get(name)
         if not k:
             continue
@@ -352,7 +369,8 @@ def main():
         # never run on multi-GPU hardware, and a hung collective must not cost the run its line.
         plan = memory_plan(torch, world, S, B, stride, args.scratch_gib, float(olen.to(torch.int64).sum().item()) / GIB + 0.1,
                            0.5 * (world - 1))
-        stitch_obj = with_deadline(lambda: stitch_leg_multi(e, dist, torch, out, olen, dev, world, rank), args.stitch_deadline)
+        stitch_obj = with_deadline(lambda: stitch_leg_multi(e, dist, torch, out, olen, dev, world, rank, step=step, step_bytes=S * B,
+                                                             step_s=elapsed / args.steps), args.stitch_deadline)
         stitch_obj["memory_plan"] = plan
         stitch_failed = bool(stitch_obj.get("failed"))
 
@@ -487,9 +505,33 @@ def main():
             ts = o.lib.zo_bench_deflate(SEED, 0, ns, B, lvl, min(cores, ns), C.byref(tot))
             gsz = int(olen[:ns].to(torch.int64).sum().item())
             levels_obj["L%d" % lvl] = {"value": SW * B / GIB / dt, "unit": "GiB/s", "ratio": SW * B / float(csz), "shards": SW,
-                                       "kernel_ms": {"lz77": lsums[1], "encode": lsums[2]},
+                                       "kernel_ms": {"lz77": lsums[1], "parse": lsums[5], "encode": lsums[2]},
                                        "oracle_ratio_same_shards": ns * B / float(tot.value), "gpu_ratio_same_shards": ns * B / float(gsz),
                                        "oracle_GiB_s": ns * B / GIB / ts, "oracle_sample": "%d shards, %d threads" % (ns, min(cores, ns)),
+                                       "check": "%d streams inflated on device, bit-exact" % vs}
+        # the levels in between (the reference's own sweep is 0 .. 9, zlib_benchmarks.json blogpost-compress): 1024 shards each, one
+        # timed launch, device round trip of every stream; no oracle figures (levels 1 / 6 / 9 have them)
+        for lvl in (2, 3, 4, 5, 7, 8):
+            wn = min(1024, SW)
+            for rep in range(2):   # (the first call warms the level's kernels up)
+                torch.cuda.synchronize()
+                timing(rep == 1)
+                ti = time.perf_counter()
+                e.deflate_batch(data, off[:wn].contiguous(), ln[:wn].contiguous(), B, level=lvl, wrap=WRAP_ZLIB, out=out2, out_len=olen, status=st)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - ti
+            lsums, lcnts = take_timing()
+            timing(False)
+            assert int((st[:wn] != 0).sum().item()) == 0
+            csz = int(olen[:wn].to(torch.int64).sum().item())
+            vs = min(wn, LS)
+            e.inflate_batch(out2, torch.arange(vs, dtype=torch.int64, device=dev) * out2.stride(0), olen[:vs].contiguous(), back,
+                            ooff[:vs].contiguous(), cap[:vs].contiguous(), wrap=WRAP_ZLIB, out_len=blen, status=bst)
+            torch.cuda.synchronize()
+            assert int((bst[:vs] != 0).sum().item()) == 0 and torch.equal(back[:vs * B], data[:vs * B]), "level %d round trip failed" % lvl
+            levels_obj["L%d" % lvl] = {"value": wn * B / GIB / dt, "unit": "GiB/s", "ratio": wn * B / float(csz), "shards": wn,
+                                       "kernel_ms": {"lz77": lsums[1], "parse": lsums[5], "encode": lsums[2]},
+                                       "note": "one launch of %d shards (a launch of 16 384 runs ~1.2x faster)" % wn,
                                        "check": "%d streams inflated on device, bit-exact" % vs}
         del out2
         # ---- PCIe inclusive: host buffers in, host buffers out (zmi_deflate_batch, pipelined copies) ----
@@ -553,9 +595,13 @@ def main():
         # (tools/prof_final.sh), recorded per launch in profiles/ and scaled to this run's launch size -- a replayed
         # figure, not measured in this run: traffic_source names the file it comes from
         traffic, traffic_source = None, None
-        for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+        for name in ("r05_traffic.json",):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if tj.get("_csrc_sha16") != csrc_sha16():
+                    traffic_source = "profiles/%s is stale (collected from kernel sources %s, now %s): not replayed" % (
+                        name, tj.get("_csrc_sha16", "without a hash"), csrc_sha16())
+                    break
                 k = tj.get("zmi_lz77_kernel") or tj.get("zmi_lz77_kernel_t")
                 traffic = (k["fetch_bytes_per_launch"] + k["write_bytes_per_launch"]) * shards_per_launch / k["shards_per_launch"]
                 traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %s; replayed, scaled to %d shards per launch)" \
@@ -581,7 +627,8 @@ def main():
                          # written per input byte) / ms_per_step / 8 TB/s, per GPU
                          "frac_step": S * B * (1.0 + 1.0 / ratio) / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS,
                          "issue": issue_replay(),
-                         "kernel_ms": {"checksum": sums[0] / max(1, cnts[0]), "lz77": lz_ms, "encode": sums[2] / max(1, cnts[2])},
+                         "kernel_ms": {"checksum": sums[0] / max(1, cnts[0]), "lz77": lz_ms, "parse": sums[5] / max(1, cnts[5]),
+                                       "encode": sums[2] / max(1, cnts[2])},
                          "launches_per_step": int(launches_per_step)},
             "roundtrip": roundtrip_obj,
         }
@@ -598,6 +645,9 @@ def main():
             line["real_data"] = real_obj
         if stitch_obj is not None:
             line["stitch"] = stitch_obj
+            ov = stitch_obj.get("overlap") if isinstance(stitch_obj, dict) else None
+            if ov and not ov.get("failed"):   # N > 1: `value` is the compression alone; this one includes the all-gather of every slab
+                line["value_with_stitch"] = ov["value_with_stitch"]
         if world == 1 and not args.no_cpu:
             cb = cpu_baseline(B, args.level)
             if cb is not None:
@@ -715,14 +765,44 @@ def stream_abi_leg(level):
     t0 = time.perf_counter()
     zlib.decompress(zc)
     tz = time.perf_counter() - t0
+    sweep = chunk_sweep_leg(ocomp, len(data), _build.ABI_LIB)
     return {"input_bytes": len(data), "path": "deflateInit2_(level, gzip) + deflate() in 4 MiB chunks + inflate() back, one thread, host buffers",
+            "chunk_sweep": sweep,
             "deflate_GiB_s": len(data) / GIB / td, "inflate_GiB_s": len(data) / GIB / ti, "ratio": len(data) / float(len(comp)),
             "inflate_of_cpu_made_stream_GiB_s": len(data) / GIB / ti2, "uncompress_of_zlib_stream_GiB_s": len(data) / GIB / tu,
             "system_zlib_inflate_single_thread_GiB_s": len(data) / GIB / tz,
             "oracle_single_thread_GiB_s": len(data) / GIB / to, "oracle_ratio": len(data) / float(len(ocomp)),
-            "note": "one stream: deflate = 16 segments of 1 MiB on the device; inflate of a stream with flush points (this library's own: "
+            "note": "one stream: deflate = segments of 64 KiB on the device, a launch per 4 MiB chunk handed in; inflate of a stream with flush points (this library's own: "
                     "a marker every 64 KiB of input) = the pieces between the markers decoded side by side and stitched (zmi_inflate_split); "
                     "a stream without them (the CPU's) = one workgroup of 16 waves, a pass covers at most one deflate block"}
+
+
+def chunk_sweep_leg(gz_stream, out_len, abi_lib):
+    """The reference's own inflate benchmark (test-libz-rs-sys/examples/blogpost-uncompress.rs:6-44; zlib_benchmarks.json: input
+    chunks 2^4 ... 2^24, the whole output buffer available, Z_NO_FLUSH): one CPU-made gzip stream through inflate() chunk by
+    chunk, by tools/chunk_sweep.c (a C loop, compiled here with gcc), once bound to libz_mi355.so and once to the system's zlib."""
+    import subprocess
+    import tempfile
+    chunks = [1 << k for k in range(4, 25, 2)]
+    with tempfile.TemporaryDirectory(prefix="zmi_sweep_") as td:
+        exe, gz = os.path.join(td, "chunk_sweep"), os.path.join(td, "in.gz")
+        subprocess.run(["gcc", "-O2", "-o", exe, os.path.join(ROOT, "tools", "chunk_sweep.c"), "-ldl"], check=True)
+        open(gz, "wb").write(gz_stream)
+        res = {}
+        for name, lib in (("zmi", abi_lib), ("system_zlib", "libz.so.1")):
+            env = dict(os.environ)
+            env["LD_LIBRARY_PATH"] = os.path.dirname(abi_lib) + ":" + env.get("LD_LIBRARY_PATH", "")
+            r = subprocess.run([exe, lib, gz, str(out_len), "31"] + [str(c) for c in chunks], capture_output=True, text=True, env=env, timeout=1200)
+            assert r.returncode == 0, r.stderr
+            res[name] = [ln.split() for ln in r.stdout.strip().splitlines()]
+    rows = {}
+    for a, b in zip(res["zmi"], res["system_zlib"]):
+        assert a[0] == b[0] and int(a[2]) == out_len == int(b[2]) and int(a[3]) == 1 and a[5] == b[5], ("chunk sweep: outputs differ", a, b)
+        rows[a[0]] = {"zmi_GiB_s": out_len / GIB / float(a[1]), "system_zlib_GiB_s": out_len / GIB / float(b[1]), "polls": int(a[4])}
+    return {"chunks": rows, "stream": "the oracle's gzip stream of the same %d bytes (no flush points)" % out_len,
+            "polls": "inflate() calls with avail_in = 0 after the last chunk until Z_STREAM_END (zlib lets an inflate() take input "
+                     "without producing its output yet; this library does while less than a launch's worth is buffered)",
+            "check": "every run: Z_STREAM_END, total_out and the FNV-1a of the output equal the system zlib's"}
 
 
 def real_data_leg(e, torch, dev, B):
@@ -813,7 +893,7 @@ def with_deadline(fn, seconds):
     return box["res"]
 
 
-def stitch_leg_multi(e, dist, torch, out, olen, dev, world, rank, chunk_bytes=1 << 29):
+def stitch_leg_multi(e, dist, torch, out, olen, dev, world, rank, chunk_bytes=1 << 29, step=None, step_bytes=0, step_s=None):
     """N > 1: size tables -> plan -> slots packed into this rank's slab -> point-to-point slab exchange in rounds of 512 MiB
     with reused staging (8 slabs of ~29 GiB do not fit beside a 64 GiB working set; a real job scatters / writes out round by
     round, here the received chunks are counted and the first round is checked against sums the owners computed).
@@ -865,8 +945,38 @@ def stitch_leg_multi(e, dist, torch, out, olen, dev, world, rank, chunk_bytes=1 
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     ex_s = float(tmax.item())
     assert got == sum(totals[:world]) - totals[rank]
+    # The north star's number -- "shard + all-gather stitch": one more compression step of this rank on its stream WHILE the complete
+    # exchange of the previous step's slabs (every slab to every rank, rounds of 512 MiB into the reused staging) runs on a side
+    # stream.  value_with_stitch = all ranks' raw bytes / the slower of the two, max over ranks.  (The kernels of a step fill the
+    # chip; RCCL's transfers are copies over xGMI with a few workgroups: DESIGN section 5 expects ~0.2 s of exchange under ~1 s of
+    # compression.)  value_with_stitch_no_overlap: the step time and the exchange time measured above, added.
+    overlap = None
+    if step is not None:
+      try:   # (its own guard: a failure here must not cost the line the exchange figures measured above)
+          side = torch.cuda.Stream(device=dev)
+          dist.barrier()
+          torch.cuda.synchronize()
+          t0 = time.perf_counter()
+          step()                                        # enqueued on the current stream, returns at once
+          with torch.cuda.stream(side):
+              lo = 0
+              while lo < biggest:
+                  e.exchange_round(comm, slab, totals, lo, chunk_bytes, stage, -1)
+                  lo += chunk_bytes
+          side.synchronize()
+          torch.cuda.synchronize()
+          both = time.perf_counter() - t0
+          dist.barrier()
+          tboth = torch.tensor([both], dtype=torch.float64, device=dev)
+          dist.all_reduce(tboth, op=dist.ReduceOp.MAX)
+          overlap = {"value_with_stitch": world * step_bytes / GIB / float(tboth.item()), "unit": "GiB/s",
+                     "step_and_exchange_s": float(tboth.item()),
+                     "value_with_stitch_no_overlap": world * step_bytes / GIB / (step_s + ex_s) if step_s else None,
+                     "note": "one compression step on the main stream while every slab of the step before goes to every rank on a side stream"}
+      except Exception as ex:  # noqa: BLE001
+        overlap = {"failed": True, "error": repr(ex)[:300]}
     e.comm_destroy(comm)
-    return {"pack_GB_s": totals[rank] / 1e9 / pack_s, "slab_bytes": totals[rank], "stitched_bytes": totals[world],
+    return {"overlap": overlap, "pack_GB_s": totals[rank] / 1e9 / pack_s, "slab_bytes": totals[rank], "stitched_bytes": totals[world],
             "exchange": "C ABI (zmi_exchange_sizes + zmi_stitch_plan_dev + zmi_exchange_slabs_round on RCCL): all-gather of the slabs by "
                         "grouped ncclSend / ncclRecv, one pair per peer per 512 MiB round, no ring, staging reused; round 0 of every "
                         "peer checked against the owner's byte sum (%d peers)" % checked,

@@ -79,7 +79,7 @@ int zmi_ctx_last_codes_used(zmi_ctx* ctx, uint32_t* entries);
 int zmi_ctx_reset_codes_used(zmi_ctx* ctx);
 
 /* per-kernel HIP-event timing for benchmarking: kernels 0 checksum, 1 lz77, 2 encode, 3 inflate (decode),
- * 4 verify, 6 inflate (resolve), 7 pack / stitch copies.  zmi_ctx_get_timing synchronises, returns the sums (ms) / launch counts since the
+ * 4 verify, 5 cost parse (deflate levels 3-9), 6 inflate (resolve), 7 pack / stitch copies.  zmi_ctx_get_timing synchronises, returns the sums (ms) / launch counts since the
  * previous call (arrays of 8) and resets them. */
 int zmi_ctx_set_timing(zmi_ctx* ctx, int on);
 int zmi_ctx_get_timing(zmi_ctx* ctx, double* ms_sums, uint32_t* counts);

@@ -377,7 +377,8 @@ def test_real_fixtures_roundtrip_and_ratio_vs_oracle(engine):
     """SURVEY 8(d) non-synthetic cross-check: lcet10.txt, paper-100k.pdf, fireworks.jpg
     (test-libz-rs-sys/src/deflate.rs:1982-2003) tiled to 1 MiB, levels 1 / 6 / 9: a conformant inflater and the GPU
     inflater give the input back bit-exactly; the GPU's ratio is reported beside the oracle's (the reference's
-    algorithm at the same level) and level 6 may not be more than 3 % worse."""
+    algorithm at the same level) and levels 6 and 9 may not be more than 1 % worse (round 5: the cost parse, csrc/parse.hip;
+    the gate was 3 % while the parse was the three-deep lazy rule)."""
     import json
     import os
     import oracle_lib
@@ -408,7 +409,8 @@ def test_real_fixtures_roundtrip_and_ratio_vs_oracle(engine):
     except OSError:
         pass
     for n, row in table.items():
-        assert row["L6"]["gpu_ratio"] >= 0.97 * row["L6"]["oracle_ratio"], (n, row)
+        assert row["L6"]["gpu_ratio"] >= 0.99 * row["L6"]["oracle_ratio"], (n, row)
+        assert row["L9"]["gpu_ratio"] >= 0.99 * row["L9"]["oracle_ratio"], (n, row)
 
 
 def test_pack_slab_and_global_stitch_on_gpu(engine):

@@ -13,6 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch  # noqa: E402
+if os.environ.get("PROBE_LIB"):   # a measurement build of the engine (build_prof/): same ABI, extra counters
+    import zlib_rs_amd._lib as _zl
+    _zl.LIB = os.path.abspath(os.environ["PROBE_LIB"])
 from zlib_rs_amd.engine import Engine, uniform_layout  # noqa: E402
 
 
@@ -42,8 +45,14 @@ def main():
             dt = time.perf_counter() - t
             sums, cnts = timing(e)
             ratio = S * B / float(olen.to(torch.int64).sum().item())
-            print("deflate S=%d L%d: %.2f GiB/s wall  ratio %.3f  ms: checksum %.2f lz77 %.2f encode %.2f" %
-                  (S, lvl, S * B / 2**30 / dt, ratio, sums[0], sums[1], sums[2]))
+            print("deflate S=%d L%d: %.2f GiB/s wall  ratio %.3f  ms: checksum %.2f lz77 %.2f parse %.2f encode %.2f" %
+                  (S, lvl, S * B / 2**30 / dt, ratio, sums[0], sums[1], sums[5], sums[2]))
+            if hasattr(e.L, "zmi_enc_prof_read"):
+                pr = (C.c_ulonglong * 8)()
+                e.L.zmi_enc_prof_read(pr)
+                tot = float(pr[0]) or 1.0
+                print("    encode wave-cycles (both passes): kernel %.3g | recurrence %.1f %% chain %.1f %% walk %.1f %% prices %.1f %% emission %.1f %%" %
+                      (tot, 100 * pr[1] / tot, 100 * pr[2] / tot, 100 * pr[3] / tot, 100 * pr[4] / tot, 100 * pr[5] / tot))
             if lvl == 6 and os.environ.get("PROBE_CLASSES"):
                 for cls in range(8):
                     idx = torch.arange(cls, S, 8, device=e.device)
@@ -52,7 +61,7 @@ def main():
                     o2, l2, s2 = e.deflate_batch(data, off[idx].contiguous(), ln[idx].contiguous(), B, level=lvl)
                     torch.cuda.synchronize()
                     sm, _ = timing(e)
-                    print("    class %d: lz77 %.2f ms encode %.2f ms for %d shards" % (cls, sm[1], sm[2], idx.numel()))
+                    print("    class %d: lz77 %.2f ms parse %.2f ms encode %.2f ms for %d shards" % (cls, sm[1], sm[5], sm[2], idx.numel()))
             if lvl == 6:
                 # per-class ratio
                 l = olen.cpu().numpy().astype("int64")

@@ -27,6 +27,10 @@ def main(src, dst, tag):
                        "(tools/prof_final.sh): deflate kernels = one launch of 16 384 x 1 MiB shards, inflate kernels = the round trip of the "
                        "same 16 384 streams (+ a 64-stream warm-up launch, 0.4 %)",
            "bytes_per_launch": 16384 << 20, "kernels": {}}
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out["_csrc_sha16"] = bench.csrc_sha16()   # (run right after the counter passes, on the same tree)
     for k, r in sorted(rows.items()):
         if "SQ_INSTS_VALU" not in r:
             continue

@@ -122,16 +122,19 @@ int parse_dp(const uint32_t* m, uint32_t p0, uint32_t p1, const uint32_t* lprice
  * byte); candidates len, len-1 .. len-(ncand-1) (>= 3); prices in 1/4 bit from the tokens emitted so far in the piece
  * (first chunk: `first` = 0 static prices, 1 = statistics over all positions' words, 2 = parse it twice).  The forward walk
  * follows the real chain across strips and chunks. */
+static const uint32_t* g_ltok = 0; static const uint32_t* g_lpos = 0; static int g_lnt = 0; static uint32_t g_lwin = 65536; static int g_quant = 4; static double g_smooth = 0.25; static int g_pmax = 15; static int g_half = 64; static int g_every = 1; static int g_stat0 = 0; static int g_minl = 3; static int g_lmax = 9999; static int g_force = 999; static int g_flat = 99; static int g_pen = 0; static int g_pen_short = 0;
 static void static_prices(int32_t* lp, int32_t* dp) {
     for (int s = 0; s < 288; ++s) lp[s] = 4 * (s < 144 ? 8 : (s < 256 ? 9 : (s < 280 ? 7 : 8)));
     for (int s = 0; s < 32; ++s) dp[s] = 4 * 5;
 }
 static void prices_q(const double* lf, const double* df, int32_t* lp, int32_t* dp) {
     double nl = 0, nd = 0;
-    for (int s = 0; s < 288; ++s) nl += lf[s] + 0.25;
-    for (int s = 0; s < 32; ++s) nd += df[s] + 0.25;
-    for (int s = 0; s < 288; ++s) { double b = log2(nl / (lf[s] + 0.25)); if (b > 15) b = 15; if (b < 1) b = 1; lp[s] = (int32_t)(b * 4 + 0.5); }
-    for (int s = 0; s < 32; ++s) { double b = log2(nd / (df[s] + 0.25)); if (b > 15) b = 15; if (b < 1) b = 1; dp[s] = (int32_t)(b * 4 + 0.5); }
+    for (int s = 0; s < 288; ++s) nl += lf[s] + g_smooth;
+    for (int s = 0; s < 32; ++s) nd += df[s] + g_smooth;
+    double lf2[288]; for (int s = 0; s < 288; ++s) lf2[s] = lf[s];
+    if (g_flat < 29) { double sum = 0; int cnt = 0; for (int s = 257 + g_flat; s < 286; ++s) { sum += lf[s]; cnt++; } for (int s = 257 + g_flat; s < 286; ++s) lf2[s] = sum / cnt; }
+    for (int s = 0; s < 288; ++s) { double b = log2(nl / (lf2[s] + g_smooth)); if (b > g_pmax) b = g_pmax; if (b < 1) b = 1; lp[s] = (int32_t)(b * 4 + 0.5); }
+    for (int s = 0; s < 32; ++s) { double b = log2(nd / (df[s] + g_smooth)); if (b > g_pmax) b = g_pmax; if (b < 1) b = 1; dp[s] = (int32_t)(b * 4 + 0.5); }
 }
 static void strip_dp(const uint32_t* m, uint32_t q0, uint32_t q1, const int32_t* lp, const int32_t* dp, int ncand, int32_t avgq, uint8_t* dec) {
     /* positions [q0, q1), q1 - q0 <= 1024 */
@@ -143,16 +146,23 @@ static void strip_dp(const uint32_t* m, uint32_t q0, uint32_t q1, const int32_t*
         int32_t best = lp[w & 0xFF] + cost[k + 1];
         int d = 0;
         const uint32_t len = (w >> 8) & 0x1FF;
+        if (len >= (uint32_t)g_force) best = 1 << 28;   /* a long match is never deferred */
         if (len >= 3) {
             const int di = dist_idx((w >> 17) + 1);
             const int32_t dc = dp[di] + 4 * dist_eb(di);
             for (int t = 0; t < ncand; ++t) {
-                if (len < 3u + (uint32_t)t) break;
+                if (len < (uint32_t)g_minl + (uint32_t)t) break;
                 const uint32_t l = len - (uint32_t)t;
                 const int li = len_idx(l);
                 const uint32_t tg = (uint32_t)k + l;
-                const int32_t ct = tg <= S ? cost[tg] : -avgq * (int32_t)(tg - S);
-                const int32_t c = lp[257 + li] + 4 * len_eb(li) + dc + ct;
+                int32_t ct;
+                if ((int)l <= g_lmax) ct = tg <= S ? cost[tg] : -avgq * (int32_t)(tg - S);
+                else {   /* outside the register window: extrapolate from the last cost inside it (or from the strip's end) */
+                    const uint32_t ref = (uint32_t)k + (uint32_t)g_lmax;
+                    const int32_t base = ref <= S ? cost[ref] : -avgq * (int32_t)(ref - S);
+                    ct = base - avgq * (int32_t)(l - (uint32_t)g_lmax);
+                }
+                const int32_t c = lp[257 + li] + 4 * len_eb(li) + dc + ct + g_pen + (l <= 6 ? g_pen_short : 0);
                 if (c < best) { best = c; d = 1 + t; }
             }
         }
@@ -160,6 +170,14 @@ static void strip_dp(const uint32_t* m, uint32_t q0, uint32_t q1, const int32_t*
         dec[q0 + k] = (uint8_t)d;
     }
 }
+void set_ext(const uint32_t* ltok, const uint32_t* lpos, int lnt, uint32_t win) { g_ltok = ltok; g_lpos = lpos; g_lnt = lnt; g_lwin = win; }
+void set_price_model(double smooth, int pmax) { g_smooth = smooth; g_pmax = pmax; }
+void set_flat(int k) { g_flat = k; }
+void set_force(int k) { g_force = k; }
+void set_lmax(int k) { g_lmax = k; }
+void set_stat0(int k, int minl) { g_stat0 = k; g_minl = minl; }
+void set_sample(int half, int every) { g_half = half; g_every = every; }
+void set_pen(int pen, int pen_short) { g_pen = pen; g_pen_short = pen_short; }
 int parse_strips(const uint32_t* m, uint32_t p0, uint32_t p1, uint32_t S, int ncand, int first, int decay, uint8_t* dec, uint32_t* tok, uint32_t* tpos, int nt) {
     double lf[288] = {0}, df[32] = {0};
     int32_t lp[288], dp[32];
@@ -171,7 +189,7 @@ int parse_strips(const uint32_t* m, uint32_t p0, uint32_t p1, uint32_t S, int nc
         int passes = 1;
         if (c0 == p0) {
             if (first == 0) static_prices(lp, dp);
-            else if (first == 1) {
+            else if (first == 1 || (first >= 3 && first != 6)) {
                 double l2[288] = {0}, d2[32] = {0};
                 for (uint32_t i = c0; i < c1; ++i) {
                     const uint32_t len = (m[i] >> 8) & 0x1FF;
@@ -179,8 +197,31 @@ int parse_strips(const uint32_t* m, uint32_t p0, uint32_t p1, uint32_t S, int nc
                     else { l2[257 + len_idx(len)] += 1.0; d2[dist_idx((m[i] >> 17) + 1)] += 1.0; }
                 }
                 prices_q(l2, d2, lp, dp);
-            } else { static_prices(lp, dp); passes = 2; }
+            } else if (first == 6) static_prices(lp, dp); else { static_prices(lp, dp); passes = 2; }
+        } else if (first == 6) { static_prices(lp, dp);
+        } else if (first >= 3) {
+            /* position statistics: every (sampled) position's literal or best match; first = 3: this chunk, all positions; 4: every
+             * 4th segment of 64; 5: cumulative over the piece so far + this chunk, every 4th segment */
+            static double l3[288], d3[32];
+            if (first != 5 || c0 == p0) { memset(l3, 0, sizeof l3); memset(d3, 0, sizeof d3); }
+            for (uint32_t i = c0; i < c1; ++i) {
+                if (first >= 4 && ((i >> 6) & 3)) continue;
+                const uint32_t len = (m[i] >> 8) & 0x1FF;
+                if (len < 3) l3[m[i] & 0xFF] += 1;
+                else { l3[257 + len_idx(len)] += 1.0; d3[dist_idx((m[i] >> 17) + 1)] += 1.0; }
+            }
+            prices_q(l3, d3, lp, dp);
         } else prices_q(lf, df, lp, dp);
+        if (g_ltok && c0 > 0) {
+            double l2[288] = {0}, d2[32] = {0};
+            const uint32_t lo = c0 > g_lwin ? c0 - g_lwin : 0;
+            for (int i = 0; i < g_lnt; ++i) {
+                if (g_lpos[i] < lo || g_lpos[i] >= c0) continue;
+                const uint32_t len = (g_ltok[i] >> 8) & 0x1FF;
+                if (!len) l2[g_ltok[i] & 0xFF]++; else { l2[257 + len_idx(len)]++; d2[dist_idx((g_ltok[i] >> 17) + 1)]++; }
+            }
+            prices_q(l2, d2, lp, dp);
+        }
         for (int pass = 0; pass < passes; ++pass) {
             for (uint32_t q0 = c0; q0 < c1; q0 += S) strip_dp(m, q0, q0 + S < c1 ? q0 + S : c1, lp, dp, ncand, avgq, dec);
             if (pass + 1 < passes) {   /* statistics of the trial parse price the real one */
@@ -208,14 +249,56 @@ int parse_strips(const uint32_t* m, uint32_t p0, uint32_t p1, uint32_t S, int nc
             if (l > 1) {
                 tok[nt++] = (w & ~(0x1FFu << 8)) | (l << 8);
                 const int li = len_idx(l), di = dist_idx((w >> 17) + 1);
-                lf[257 + li]++; df[di]++;
+                if (!g_stat0) { lf[257 + li]++; df[di]++; }
                 bits += (lp[257 + li] + dp[di]) / 4.0 + len_eb(li) + dist_eb(di);
-            } else { tok[nt++] = w & 0xFF; lf[w & 0xFF]++; bits += lp[w & 0xFF] / 4.0; }
+            } else { tok[nt++] = w & 0xFF; if (!g_stat0) lf[w & 0xFF]++; bits += lp[w & 0xFF] / 4.0; }
             i += l;
+        }
+        if (g_stat0 && ((c0 - p0) / CH) % (uint32_t)g_every == 0) {   /* the separate parse kernel's statistics: every strip walked from its own first position */
+            for (uint32_t q0 = c0; q0 < c1; q0 += S) {
+                uint32_t q = q0; uint32_t q1 = q0 + S < c1 ? q0 + S : c1;
+                if (q1 > q0 + (uint32_t)g_half) q1 = q0 + (uint32_t)g_half;
+                while (q < q1) {
+                    const uint32_t w = m[q];
+                    uint32_t l = 1;
+                    if (dec[q]) { l = ((w >> 8) & 0x1FF) - (dec[q] - 1u); if (q + l > p1) { l = p1 - q; if (l < 3) l = 1; } }
+                    if (l > 1) { lf[257 + len_idx(l)]++; df[dist_idx((w >> 17) + 1)]++; } else lf[w & 0xFF]++;
+                    q += l;
+                }
+            }
         }
         avgq = (int32_t)(4.0 * bits / (double)(c1 - c0) + 0.5);
         if (avgq < 1) avgq = 1;
         e = i;
+    }
+    return nt;
+}
+
+/* the three-deep lazy rule + a local truncation rule: a match gives up its last byte (its last two) when the match that starts
+ * there is that much better than the one behind it */
+int parse_lazy3_trunc(const uint32_t* m, uint32_t n, uint32_t max_lazy, uint32_t lazy2, uint32_t lazy3, int margin, int depth, uint32_t* tok, uint32_t* tpos) {
+    uint32_t p = 0; int nt = 0;
+#define LEN_AT(q) ((q) < n ? (m[(q)] >> 8) & 0x1FF : 0)
+    while (p < n) {
+        uint32_t l0 = LEN_AT(p), l1 = LEN_AT(p + 1), l2 = LEN_AT(p + 2), l3 = LEN_AT(p + 3);
+        int defer = (l0 < max_lazy) && ((l1 > l0) || (l2 > l0 + lazy2) || (l3 > l0 + lazy3));
+        uint32_t step = 1;
+        if (l0 >= 4 && !defer) {
+            step = l0;
+            if (l0 < 258) {
+                const uint32_t a = LEN_AT(p + l0);
+                uint32_t a_eff = a >= 4 ? a : 1;
+                for (int t = 1; t <= depth; ++t) {
+                    if (l0 < 4u + (uint32_t)t) break;
+                    const uint32_t b = LEN_AT(p + l0 - t);
+                    if (b >= 4 && b >= a_eff + (uint32_t)t + (uint32_t)margin) { step = l0 - t; a_eff = b - t; }
+                }
+            }
+        }
+        if (p + step > n) { step = n - p; if (step < 3) step = 1; }
+        tpos[nt] = p;
+        tok[nt++] = step > 1 ? ((m[p] & ~(0x1FFu << 8)) | (step << 8)) : (m[p] & 0xFF);
+        p += step;
     }
     return nt;
 }

@@ -63,17 +63,47 @@ def main():
     nt = P.parse_lazy3(m.ctypes.data, n, 32, 1, 2, tok.ctypes.data, tpos.ctypes.data)
     base = P.cost_tokens(tok.ctypes.data, nt, BLK, 640.0)
     print("%s chain %d: lazy3  tokens %7d  bytes %8.0f  ratio %.4f" % (which, chain, nt, base / 8, n / (base / 8)))
+    P.parse_lazy3_trunc.argtypes = [V, U, U, U, U, I, I, V, V]
+    if os.environ.get("LAB_TRUNC"):
+        for margin in (0, 1, 2, 3):
+            for depth in (1, 2, 3):
+                tk = np.zeros(n + 8, dtype=np.uint32); tp = np.zeros(n + 8, dtype=np.uint32)
+                ntt = P.parse_lazy3_trunc(m.ctypes.data, n, 32, 1, 2, margin, depth, tk.ctypes.data, tp.ctypes.data)
+                c = P.cost_tokens(tk.ctypes.data, ntt, BLK, 640.0)
+                print("  lazy3 + truncate margin %d depth %d: tokens %7d ratio %.4f (%+.2f %%)" % (margin, depth, ntt, n / (c / 8), 100.0 * (base / c - 1.0)))
+        return
     P.parse_strips.argtypes = [V, U, U, U, I, I, I, V, V, V, I]
     dec = np.zeros(n + 8, dtype=np.uint8)
-    for S in (32, 64, 128, 256, 1024):
+    P.set_ext.argtypes = [V, V, I, U]
+    P.set_price_model.argtypes = [C.c_double, I]
+    if os.environ.get("LAB_EXT"):
+        lt = tok[:nt].copy(); lpz = tpos[:nt].copy()
+        P.set_ext(lt.ctypes.data, lpz.ctypes.data, nt, int(os.environ["LAB_EXT"]))
+    P.set_stat0.argtypes = [I, I]
+    if os.environ.get("LAB_STAT0"): P.set_stat0(int(os.environ["LAB_STAT0"]), int(os.environ.get("LAB_MINL", "3")))
+    P.set_sample.argtypes = [I, I]
+    if os.environ.get("LAB_HALF"): P.set_sample(int(os.environ["LAB_HALF"]), int(os.environ.get("LAB_EVERY", "1")))
+    P.set_lmax.argtypes = [I]
+    if os.environ.get("LAB_LMAX"): P.set_lmax(int(os.environ["LAB_LMAX"]))
+    P.set_force.argtypes = [I]
+    if os.environ.get("LAB_FORCE"): P.set_force(int(os.environ["LAB_FORCE"]))
+    P.set_flat.argtypes = [I]
+    if os.environ.get("LAB_FLAT"): P.set_flat(int(os.environ["LAB_FLAT"]))
+    P.set_pen.argtypes = [I, I]
+    if os.environ.get("LAB_PEN"):
+        P.set_pen(int(os.environ["LAB_PEN"]), int(os.environ.get("LAB_PEN_SHORT", "0")))
+    if os.environ.get("LAB_SMOOTH"):
+        P.set_price_model(float(os.environ["LAB_SMOOTH"]), int(os.environ.get("LAB_PMAX", "15")))
+    for S in (64,):
         for ncand in (1, 2, 4):
-            for first in (0, 1, 2):
+            for first in (0, 1, 2, 3, 4, 5, 6):
                 for decay in (0, 1):
-                    if (first != 1 or decay) and not (S == 64 and ncand == 4): continue
+                    if (first not in (1, 3, 4, 5, 6) or decay) and not (S == 64 and ncand == 4): continue
                     nt2 = 0
                     tok2 = np.zeros(n + 8, dtype=np.uint32); tpos2 = np.zeros(n + 8, dtype=np.uint32)
-                    for p0 in range(0, n, 65536):
-                        nt2 = P.parse_strips(m.ctypes.data, p0, min(n, p0 + 65536), S, ncand, first, decay, dec.ctypes.data, tok2.ctypes.data, tpos2.ctypes.data, nt2)
+                    PIECE = int(os.environ.get('LAB_PIECE', '65536'))
+                    for p0 in range(0, n, PIECE):
+                        nt2 = P.parse_strips(m.ctypes.data, p0, min(n, p0 + PIECE), S, ncand, first, decay, dec.ctypes.data, tok2.ctypes.data, tpos2.ctypes.data, nt2)
                     c = P.cost_tokens(tok2.ctypes.data, nt2, BLK, 640.0)
                     print("  strips S=%4d ncand %d first %d decay %d: tokens %7d bytes %8.0f ratio %.4f (%+.2f %%)" % (S, ncand, first, decay, nt2, c / 8, n / (c / 8), 100.0 * (base / c - 1.0)))
     if os.environ.get("LAB_STRIPS_ONLY"): return

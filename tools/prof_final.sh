@@ -9,7 +9,7 @@
 cd /tmp && export TMPDIR=/tmp
 # bench.py as the rank itself (WORLD_SIZE set: no launcher in between -- rocprofv3 follows the process it starts)
 export WORLD_SIZE=1 RANK=0 LOCAL_RANK=0
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=${1:-r04}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; TAG=${1:-r05}
 cd $R
 mkdir -p $O/$TAG/trace $O/$TAG/fetch $O/$TAG/write $O/$TAG/sq
 rocprofv3 --kernel-trace --stats -d $O/$TAG/trace -o t -- python bench.py --steps 2 --warmup 1 --no-cpu --verify 0 > $O/$TAG/trace_bench.json 2> $O/$TAG/trace.log
@@ -45,6 +45,10 @@ for d in ("fetch", "write", "sq"):
 res = {k: {"fetch_bytes_per_launch": v.get("FETCH_SIZE", 0) * 1024 * 2, "write_bytes_per_launch": v.get("WRITE_SIZE", 0) * 1024,
            "shards_per_launch": 16384} for k, v in traffic.items()}
 res["_collected"] = "$TAG, " + datetime.date.today().isoformat()
+import sys
+sys.path.insert(0, "$R")
+import bench
+res["_csrc_sha16"] = bench.csrc_sha16()   # bench.py replays this file only against the kernel sources it was collected from
 json.dump(res, open("$O/$TAG/traffic.json", "w"), indent=1)
 PY
 # (the caller redirects stdout into gpurun_out/TAG/rocprofv3_summary.csv: the issue file is made from it afterwards)

@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzmi355.so")
 ABI_LIB = os.path.join(HERE, "libz_mi355.so")
-SOURCES = ["gen.hip", "checksum.hip", "lz77.hip", "encode.hip", "inflate.hip", "resolve_jump.hip", "pack.hip", "blockscan.hip", "exchange.hip", "zmi_api.hip"]
+SOURCES = ["gen.hip", "checksum.hip", "lz77.hip", "parse.hip", "encode.hip", "encode_cp.hip", "inflate.hip", "resolve_jump.hip", "pack.hip", "blockscan.hip", "exchange.hip", "zmi_api.hip"]
 ABI_SOURCES = ["zlib_abi.hip", "gz_api.hip", "host_sums.cpp"]
 
 

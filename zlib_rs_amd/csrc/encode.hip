@@ -784,6 +784,19 @@ static __device__ __forceinline__ uint32_t enc_seg_step(uint32_t& m, uint32_t nx
     return step;
 }
 
+// Levels 3-9: which positions become tokens was decided by the cost parse (csrc/parse.hip), two bits per position: 0 = literal,
+// 1 = the match at its full length, 2 = one byte shorter.  The token chain follows these steps; nothing is judged here.
+static __device__ __forceinline__ uint32_t enc_seg_step_cp(uint32_t m, uint32_t decw, uint32_t pos, uint32_t pend) {
+    const uint32_t dec = (decw >> (2u * (zmi_lane() & 15u))) & 3u;
+    const bool valid = pos < pend;
+    const uint32_t room = valid ? pend - pos : 0u;       // (the parse clipped its lengths the same way: a token ends with its piece)
+    uint32_t mlen = (m >> 8) & 0x1FFu;
+    mlen = mlen < room ? mlen : room;
+    uint32_t step = mlen + 1u - dec;
+    step = ((dec != 0u) & (step >= 3u) & (step <= mlen)) ? step : 1u;
+    return step;
+}
+
 #if defined(ZMI_EMU) || defined(ENC_NO_OCC)
 #define ENC_OCC
 #else
@@ -791,9 +804,13 @@ static __device__ __forceinline__ uint32_t enc_seg_step(uint32_t& m, uint32_t nx
 // round trips (measured: a wave per SIMD less costs ~3 %)
 #define ENC_OCC __attribute__((amdgpu_waves_per_eu(6, 8)))
 #endif
-__global__ void __launch_bounds__(64) ENC_OCC zmi_encode_kernel(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off,
+// CP: the token choice comes from the cost parse's decisions (`dec`, 2 bits per position, 16 bytes per segment of 64; levels 3-9);
+// otherwise from the lazy rule below (levels 1 and 2, Z_HUFFMAN_ONLY).
+// (A template kernel and not two kernels around one inlined body: in that form both came out at 116 VGPRs instead of 80.)
+template <bool CP>
+__global__ void __launch_bounds__(64) ENC_OCC zmi_encode_kernel_t(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off,
                                                         const uint32_t* __restrict__ len, uint32_t first_shard,
-                                                        uint32_t* match, uint64_t match_stride,
+                                                        uint32_t* match, uint64_t match_stride, const uint32_t* __restrict__ dec, uint64_t dec_stride,
                                                         const uint32_t* __restrict__ adler, const uint32_t* __restrict__ crc,
                                                         uint8_t* __restrict__ out, uint64_t out_stride, uint32_t pieces,
                                                         uint32_t region_stride, uint32_t* __restrict__ piece_len,
@@ -813,6 +830,7 @@ __global__ void __launch_bounds__(64) ENC_OCC zmi_encode_kernel(const uint8_t* _
     const uint8_t* src = data + off[s];
     const uint32_t n = len[s];
     uint32_t* tokbuf = match + (uint64_t)local * match_stride;
+    const uint32_t* decw = CP ? dec + (uint64_t)local * dec_stride : nullptr;   // dword 4 * segment + lane / 16 holds this lane's two bits
 
     // piece geometry: `pieces` equal ranges (multiple of 64 positions); ranges past the end are empty
     uint32_t psize = ((n + pieces - 1u) / pieces + 63u) & ~63u;
@@ -898,6 +916,13 @@ __global__ void __launch_bounds__(64) ENC_OCC zmi_encode_kernel(const uint8_t* _
     uint32_t m_a = (pstart + lane < pend) ? tokbuf[pstart + lane] : 0u;
     uint32_t m_b = (pstart + 64u + lane < pend) ? tokbuf[pstart + 64u + lane] : 0u;
     uint32_t m_c = (pstart + 128u + lane < pend) ? tokbuf[pstart + 128u + lane] : 0u;
+    // (the decisions of a trip's two segments, fetched a trip ahead like the match words: 4 distinct dwords per segment)
+    const uint32_t dlast = CP ? 4u * (nseg - 1u) + 3u : 0u;
+    uint32_t d_a = 0u, d_b = 0u;
+    if constexpr (CP) {
+        d_a = decw[4u * seg0 + (lane >> 4)];
+        d_b = decw[4u * (seg0 + 1u) + (lane >> 4) < dlast ? 4u * (seg0 + 1u) + (lane >> 4) : dlast];
+    }
     for (uint32_t seg = seg0; seg < nseg; seg += 2u) {
         const uint32_t posA = seg * 64u + lane, posB = posA + 64u;
         // (loads at a clamped index + a select: a guarded load is a divergent branch, six scalar instructions around one load)
@@ -905,8 +930,18 @@ __global__ void __launch_bounds__(64) ENC_OCC zmi_encode_kernel(const uint8_t* _
         const uint32_t ld_d = tokbuf[posA + 192u < plast ? posA + 192u : plast], ld_e = tokbuf[posA + 256u < plast ? posA + 256u : plast];
         const uint32_t m_d = (posA + 192u < pend) ? ld_d : 0u;
         const uint32_t m_e = (posA + 256u < pend) ? ld_e : 0u;
-        const uint32_t stepA = enc_seg_step(m_a, m_b, posA, pend, prm, far4, far5, far6);
-        const uint32_t stepB = enc_seg_step(m_b, m_c, posB, pend, prm, far4, far5, far6);
+        uint32_t stepA, stepB;
+        if constexpr (CP) {
+            const uint32_t ia = 4u * (seg + 2u) + (lane >> 4), ib = 4u * (seg + 3u) + (lane >> 4);
+            const uint32_t n_a = decw[ia < dlast ? ia : dlast], n_b = decw[ib < dlast ? ib : dlast];
+            stepA = enc_seg_step_cp(m_a, d_a, posA, pend);
+            stepB = enc_seg_step_cp(m_b, d_b, posB, pend);
+            d_a = n_a;
+            d_b = n_b;
+        } else {
+            stepA = enc_seg_step(m_a, m_b, posA, pend, prm, far4, far5, far6);
+            stepB = enc_seg_step(m_b, m_c, posB, pend, prm, far4, far5, far6);
+        }
         const uint64_t validA = __ballot(posA < pend), validB = __ballot(posB < pend);
         uint32_t JA = lane + stepA, RA = zmi_lane_bit32_here(lane), JB = lane + stepB, RB = RA;
         const bool any_match = __ballot(stepA > 1u || stepB > 1u) != 0ull;
@@ -989,7 +1024,7 @@ __global__ void __launch_bounds__(64) ENC_OCC zmi_encode_kernel(const uint8_t* _
             nH = ntok;
             bendH = bmid;
             zmi_wave_sync();
-            if (!last_seg) {
+            if (!CP && !last_seg) {
                 enc_far_limits(S, S->lfreq, S->dfreq);   // the open block's statistics price the next sub-block's short matches
                 far4 = zmi_uniform(S->misc[M_FAR4]); far5 = zmi_uniform(S->misc[M_FAR5]); far6 = zmi_uniform(S->misc[M_FAR6]);
             }
@@ -1048,6 +1083,23 @@ __global__ void __launch_bounds__(64) ENC_OCC zmi_encode_kernel(const uint8_t* _
     }
 }
 
+// The cost-parse instantiation is compiled in a translation unit of its own (encode_cp.hip includes this file with ENC_CP_UNIT):
+// the two kernels share their out-of-line helpers (enc_flush_block, enc_split_pays ...), and with both instantiations in one unit
+// the lazy kernel's register allocation changed with them (4 VGPR spills instead of 1, level 1: 78.7 -> 83.4 ms per 16 Ki shards).
+extern "C" int zmi_launch_encode_cp(const uint8_t* d_data, const uint64_t* d_off, const uint32_t* d_len, uint32_t first_shard,
+                                    uint32_t n_shards, uint32_t* d_match, uint64_t match_stride, const uint32_t* d_adler,
+                                    const uint32_t* d_crc, uint8_t* d_out, uint64_t out_stride, uint32_t pieces, uint32_t region,
+                                    uint32_t* d_piece_len, const uint32_t* d_dec, uint64_t dec_stride, zmi_enc_params prm, hipStream_t stream);
+#ifdef ENC_CP_UNIT
+extern "C" int zmi_launch_encode_cp(const uint8_t* d_data, const uint64_t* d_off, const uint32_t* d_len, uint32_t first_shard,
+                                    uint32_t n_shards, uint32_t* d_match, uint64_t match_stride, const uint32_t* d_adler,
+                                    const uint32_t* d_crc, uint8_t* d_out, uint64_t out_stride, uint32_t pieces, uint32_t region,
+                                    uint32_t* d_piece_len, const uint32_t* d_dec, uint64_t dec_stride, zmi_enc_params prm, hipStream_t stream) {
+    ZMI_LAUNCH(zmi_encode_kernel_t<true>, dim3(n_shards * pieces), dim3(64), 0, stream, d_data, d_off, d_len, first_shard, d_match,
+               match_stride, d_dec, dec_stride, d_adler, d_crc, d_out, out_stride, pieces, region, d_piece_len, prm);
+    return 0;
+}
+#else
 // Concatenate the pieces of every shard inside its output slot (piece r lives at r*region_stride and
 // only ever moves towards lower addresses), then publish length and status.  One 256-thread
 // workgroup per shard; 4 KiB blocks are loaded with aligned 16-byte reads, staged in LDS and
@@ -1098,15 +1150,20 @@ extern "C" int zmi_launch_encode(const uint8_t* d_data, const uint64_t* d_off, c
                                  uint32_t n_shards, uint32_t* d_match, uint64_t match_stride, const uint32_t* d_adler,
                                  const uint32_t* d_crc, uint8_t* d_out, uint64_t out_stride, uint32_t out_cap,
                                  uint32_t* d_out_len, int32_t* d_status, uint32_t pieces, uint32_t* d_piece_len,
-                                 zmi_enc_params prm, hipStream_t stream) {
+                                 const uint32_t* d_dec, uint64_t dec_stride, zmi_enc_params prm, hipStream_t stream) {
     if (n_shards == 0) return 0;
     if (prm.block_span < 64u) prm.block_span = 64u;
     prm.block_span &= ~63u;
     if (pieces < 1u) pieces = 1u;
     uint32_t region = (uint32_t)((out_cap / pieces) & ~15u);
-    ZMI_LAUNCH(zmi_encode_kernel, dim3(n_shards * pieces), dim3(64), 0, stream, d_data, d_off, d_len, first_shard, d_match,
-               match_stride, d_adler, d_crc, d_out, out_stride, pieces, region, d_piece_len, prm);
+    if (prm.cost_parse && d_dec)
+        zmi_launch_encode_cp(d_data, d_off, d_len, first_shard, n_shards, d_match, match_stride, d_adler, d_crc, d_out, out_stride, pieces, region,
+                             d_piece_len, d_dec, dec_stride, prm, stream);
+    else
+        ZMI_LAUNCH(zmi_encode_kernel_t<false>, dim3(n_shards * pieces), dim3(64), 0, stream, d_data, d_off, d_len, first_shard, d_match,
+                   match_stride, d_dec, dec_stride, d_adler, d_crc, d_out, out_stride, pieces, region, d_piece_len, prm);
     ZMI_LAUNCH(zmi_compact_kernel, dim3(n_shards), dim3(256), 0, stream, d_out, out_stride, first_shard, pieces, region,
                d_piece_len, d_out_len, d_status);
     return 0;
 }
+#endif

@@ -67,7 +67,7 @@ struct zmi_timer {
     hipEvent_t a, b;
     int kernel;
 };
-enum { ZMI_K_CHECKSUM = 0, ZMI_K_LZ77 = 1, ZMI_K_ENCODE = 2, ZMI_K_INFLATE = 3, ZMI_K_VERIFY = 4, ZMI_K_GEN = 5, ZMI_K_RESOLVE = 6, ZMI_K_PACK = 7 };
+enum { ZMI_K_CHECKSUM = 0, ZMI_K_LZ77 = 1, ZMI_K_ENCODE = 2, ZMI_K_INFLATE = 3, ZMI_K_VERIFY = 4, ZMI_K_PARSE = 5, ZMI_K_RESOLVE = 6, ZMI_K_PACK = 7 };
 
 #define ZMI_HB_SLOTS 3   // host-buffer pipelines: chunks in flight (staging in, on the device, staging out)
 struct zmi_ctx {
@@ -466,6 +466,8 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     ep.chain_mode = chain_mode;
     ep.last_shard = n - 1u;
     if (level == 0) ep.strategy = 100u;           // stored blocks only (deflate_stored)
+    ep.cost_parse = (level >= 3 && strategy != 2) ? 1u : 0u;
+    if (const char* cp = zmi_tune("ZMI_COST_PARSE")) ep.cost_parse = atoi(cp) ? 1u : 0u;
     if (strategy == 2) { lp.max_chain = 0; lp.max_dist = 0; }   // Z_HUFFMAN_ONLY: literals only -- with no distance allowed no
                                                                  // position gets a candidate (a zero chain budget alone still
                                                                  // examines the first one)
@@ -511,14 +513,17 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     const char* span_env = zmi_tune("ZMI_BLOCK_SPAN");
     if (span_env && atoi(span_env) >= 64) ep.block_span = (uint32_t)atoi(span_env);
 
-    // match/token scratch: one u32 per position, shards padded to a multiple of 64 positions
+    // match/token scratch: one u32 per position, shards padded to a multiple of 64 positions; with the cost parse two more bits
+    // per position behind it (its decisions, 16 bytes per 64 positions)
     const uint64_t stride = ((uint64_t)max_len + 63u) & ~63ull;
     uint64_t per_shard = (stride ? stride : 64u) * 4u;
-    uint64_t group = c->scratch_limit / per_shard;
+    const uint64_t dec_bytes = ep.cost_parse ? per_shard / 16u : 0u;
+    uint64_t group = c->scratch_limit / (per_shard + dec_bytes);
     if (group == 0) return zmi_fail(ZMI_E_NOMEM, "scratch limit too small for one shard");
     if (group > n) group = n;
-    rc = zmi_reserve(c->match, (size_t)(group * per_shard));
+    rc = zmi_reserve(c->match, (size_t)(group * (per_shard + dec_bytes)));
     if (rc) return rc;
+    uint32_t* const d_dec = ep.cost_parse ? (uint32_t*)((uint8_t*)c->match.p + group * per_shard) : nullptr;
     // the encoder runs `pieces` waves per shard (byte-aligned sub-streams, concatenated afterwards):
     // one piece per block_span of input, at most 16
     uint32_t pieces = (max_len + ep.block_span - 1u) / ep.block_span;
@@ -547,11 +552,16 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
                                       per_shard / 4u, lp, stream);
             if (lrc) return zmi_fail(ZMI_E_HIP, "lz77 launch setup", (hipError_t)lrc);
         }
+        if (ep.cost_parse) {
+            zmi_scope_timer tm(c, ZMI_K_PARSE, stream);
+            zmi_launch_parse(d_in_len, (uint32_t)first, cnt, max_len, (const uint32_t*)c->match.p, per_shard / 4u, d_dec, dec_bytes / 4u, pieces,
+                             (uint32_t)strategy, stream);
+        }
         if (forked) { ZMI_HIP(hipStreamWaitEvent(stream, c->ev_join, 0)); forked = false; }
         zmi_scope_timer tm2(c, ZMI_K_ENCODE, stream);
         zmi_launch_encode((const uint8_t*)d_in, d_in_off, d_in_len, (uint32_t)first, cnt, (uint32_t*)c->match.p,
                           per_shard / 4u, d_adler, d_crc, (uint8_t*)d_out, out_stride, (uint32_t)out_stride, d_out_len,
-                          d_status, pieces, (uint32_t*)c->pieces.p, ep, stream);
+                          d_status, pieces, (uint32_t*)c->pieces.p, d_dec, dec_bytes / 4u, ep, stream);
     }
     ZMI_HIP(hipGetLastError());
     return ZMI_E_OK;

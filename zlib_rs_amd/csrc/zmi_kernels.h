@@ -47,6 +47,8 @@ struct zmi_enc_params {
                           // segments of ONE raw deflate stream, only shard `last_shard` ends it (BFINAL);
                           // 2: as 1 but nothing ends the stream (Z_SYNC_FLUSH / Z_FULL_FLUSH output)
     uint32_t last_shard;
+    uint32_t cost_parse;  // 1: tokens are chosen by a backward cost parse over the matches (levels 3-9, csrc/parse.hip);
+                          // 0: by the lazy rule (levels 1, 2 -- greedy -- and Z_HUFFMAN_ONLY / level 0, which have no matches)
 };
 
 // per-shard result codes written by the kernels (zlib numbering, zlib-rs/src/c_api.rs:140-148)
@@ -75,7 +77,12 @@ int zmi_launch_lz77(const uint8_t* d_data, const uint64_t* d_off, const uint32_t
 int zmi_launch_encode(const uint8_t* d_data, const uint64_t* d_off, const uint32_t* d_len, uint32_t first_shard,
                       uint32_t n_shards, uint32_t* d_match, uint64_t match_stride, const uint32_t* d_adler,
                       const uint32_t* d_crc, uint8_t* d_out, uint64_t out_stride, uint32_t out_cap, uint32_t* d_out_len,
-                      int32_t* d_status, uint32_t pieces, uint32_t* d_piece_len, zmi_enc_params prm, hipStream_t stream);
+                      int32_t* d_status, uint32_t pieces, uint32_t* d_piece_len, const uint32_t* d_dec, uint64_t dec_stride,
+                      zmi_enc_params prm, hipStream_t stream);
+// the cost parse (levels 3-9, csrc/parse.hip): d_dec receives two bits per position of every shard of the group (dec_stride
+// dwords per shard, 16 bytes per segment of 64 positions): 0 literal, 1 the match, 2 the match one byte shorter
+int zmi_launch_parse(const uint32_t* d_len, uint32_t first_shard, uint32_t n_shards, uint32_t max_len, const uint32_t* d_match,
+                     uint64_t match_stride, uint32_t* d_dec, uint64_t dec_stride, uint32_t pieces, uint32_t strategy, hipStream_t stream);
 int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n_streams,
                        uint32_t wrap, uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                        uint32_t* d_out_len, uint32_t* d_in_used, uint32_t* d_check, int32_t* d_status,
