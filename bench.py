@@ -789,19 +789,36 @@ def chunk_sweep_leg(gz_stream, out_len, abi_lib):
         subprocess.run(["gcc", "-O2", "-o", exe, os.path.join(ROOT, "tools", "chunk_sweep.c"), "-ldl"], check=True)
         open(gz, "wb").write(gz_stream)
         res = {}
-        for name, lib in (("zmi", abi_lib), ("system_zlib", "libz.so.1")):
+        # eager = the library's default: every inflate() decodes what it was given (a device launch per call: the pieces below
+        # 256 bytes would take minutes and are left out); deferred = ZMI_INFLATE_DEFER=262144 (opt-in, include/zmi355_zlib.h)
+        for name, lib, defer, cs in (("system_zlib", "libz.so.1", None, chunks), ("zmi_deferred", abi_lib, "262144", chunks),
+                                     ("zmi_eager", abi_lib, None, [c for c in chunks if c >= 256])):
             env = dict(os.environ)
             env["LD_LIBRARY_PATH"] = os.path.dirname(abi_lib) + ":" + env.get("LD_LIBRARY_PATH", "")
-            r = subprocess.run([exe, lib, gz, str(out_len), "31"] + [str(c) for c in chunks], capture_output=True, text=True, env=env, timeout=1200)
+            env.pop("ZMI_INFLATE_DEFER", None)
+            if defer:
+                env["ZMI_INFLATE_DEFER"] = defer
+            r = subprocess.run([exe, lib, gz, str(out_len), "31"] + [str(c) for c in cs], capture_output=True, text=True, env=env, timeout=1800)
             assert r.returncode == 0, r.stderr
-            res[name] = [ln.split() for ln in r.stdout.strip().splitlines()]
+            res[name] = {ln.split()[0]: ln.split() for ln in r.stdout.strip().splitlines()}
     rows = {}
-    for a, b in zip(res["zmi"], res["system_zlib"]):
-        assert a[0] == b[0] and int(a[2]) == out_len == int(b[2]) and int(a[3]) == 1 and a[5] == b[5], ("chunk sweep: outputs differ", a, b)
-        rows[a[0]] = {"zmi_GiB_s": out_len / GIB / float(a[1]), "system_zlib_GiB_s": out_len / GIB / float(b[1]), "polls": int(a[4])}
+    for c in chunks:
+        b = res["system_zlib"][str(c)]
+        row = {"system_zlib_GiB_s": out_len / GIB / float(b[1])}
+        for name in ("zmi_deferred", "zmi_eager"):
+            a = res[name].get(str(c))
+            if a is None:
+                continue
+            assert int(a[2]) == out_len == int(b[2]) and int(a[3]) == 1 and a[5] == b[5], ("chunk sweep: outputs differ", name, a, b)
+            row[name + "_GiB_s"] = out_len / GIB / float(a[1])
+            if name == "zmi_deferred":
+                row["polls"] = int(a[4])
+        rows[str(c)] = row
     return {"chunks": rows, "stream": "the oracle's gzip stream of the same %d bytes (no flush points)" % out_len,
-            "polls": "inflate() calls with avail_in = 0 after the last chunk until Z_STREAM_END (zlib lets an inflate() take input "
-                     "without producing its output yet; this library does while less than a launch's worth is buffered)",
+            "modes": "zmi_eager: the default -- every inflate() call decodes what it brought (exact input accounting, the end of the "
+                     "stream is found by the call that delivers it); zmi_deferred: ZMI_INFLATE_DEFER=262144 -- input is taken and "
+                     "decoded once 256 KiB have come in (zlib's 'output latency'), `polls` = calls with avail_in = 0 after the last "
+                     "piece until Z_STREAM_END",
             "check": "every run: Z_STREAM_END, total_out and the FNV-1a of the output equal the system zlib's"}
 
 

@@ -10,13 +10,15 @@
  * Each declaration cites the reference definition it replaces (libz-rs-sys/src/lib.rs:LINE).
  *
  * Stream semantics on the GPU (documented deviations that stay inside zlib's contract):
- *   deflate()  consumes and buffers input; compressed data is produced when the caller flushes or
- *              finishes (or 64 MiB are pending).  The input is compressed in 1 MiB segments, one
- *              workgroup each, that start byte aligned (the empty stored block of Z_SYNC_FLUSH,
- *              zlib-rs/src/deflate.rs:2733-2738) and keep the window: a segment matches into the
- *              27 KiB in front of it, like a preset dictionary (deflate.rs:499-564).  Across separate
- *              deflate() calls the last 32 KiB of input stay the window; only Z_FULL_FLUSH forgets them
- *              (deflate.rs:2739-2752).
+ *   deflate()  consumes and buffers input; compressed data is produced when the caller flushes or finishes, and under
+ *              Z_NO_FLUSH whenever 4 MiB have come in (the reference emits whenever its pending buffer fills,
+ *              deflate.rs:2805-2826): a caller sees output as it goes and a stream holds a few MiB, not its input.
+ *              The input is compressed in 64 KiB segments side by side -- one match-search workgroup and one
+ *              encoder wave each, so a 4 MiB call is 64 workgroups on the chip -- that start byte aligned (the
+ *              empty stored block of Z_SYNC_FLUSH, zlib-rs/src/deflate.rs:2733-2738) and keep the window: a
+ *              segment matches into the 27 KiB in front of it, like a preset dictionary (deflate.rs:499-564).
+ *              Across separate deflate() calls the last 32 KiB of input stay the window; only Z_FULL_FLUSH
+ *              forgets them (deflate.rs:2739-2752).
  *   inflate()  decodes as far as the input it is given allows, so the output of a flushed packet is there when the call
  *              returns.  The caller's input is taken a piece at a time and only while the decoder can use it; what a pause
  *              (much output queued, Z_NEED_DICT) leaves unread is handed back.  The device decodes from a checkpoint -- the
@@ -31,6 +33,13 @@
  *              spot are delivered before Z_DATA_ERROR, as the reference does; header, trailer and deflate-data errors
  *              carry the reference's messages ("invalid stored block lengths", "invalid distance too far back", ...:
  *              the decode kernel reports the cause, inflate.rs State::bad).
+ *              ZMI_INFLATE_DEFER=BYTES in the environment (read once, default off) lets inflate(Z_NO_FLUSH) take small
+ *              pieces WITHOUT a device decode per call -- zlib's "output latency": the input is decoded once BYTES have come
+ *              in, or when a call flushes, brings no input, brings less than the call before, or asks for a block stop.  A
+ *              device decode costs a launch (~170 us) whatever it is given; a caller feeding 16-byte pieces needs this, a
+ *              caller feeding 64 KiB and more does not.  Its price: Z_STREAM_END may come from a later call than the one
+ *              that delivered the last byte (ask again with avail_in = 0), and bytes behind the end of the stream that
+ *              arrived in earlier calls cannot be handed back -- readers of concatenated streams leave it off.
  *   windowBits 9..14 bound the back-references (2^windowBits - 262, deflate.rs:1423-1425); deflateBound is the
  *              reference's bound() (deflate.rs:3193-3287: wrapper, gzip header fields, DICTID, small windows);
  *              the first deflate() call writes the wrapper's header even without input (deflate.rs:2543-2627).

@@ -259,3 +259,88 @@ def test_input_handback_after_a_paused_decode(monkeypatch, tmp_path):
     H.handback_checks(lib, oracle_lib.load(), tmp_path)
     monkeypatch.setenv("ZMI_ABI_ABSORB", "1000")     # the caller's input is taken in small pieces
     H.handback_checks(lib, oracle_lib.load(), tmp_path, size=60000)
+
+
+def test_deflate_emits_as_input_arrives(monkeypatch):
+    """deflate(Z_NO_FLUSH) hands out compressed data once a few segments' worth of input has come in (the reference: whenever its
+    pending buffer fills, zlib-rs/src/deflate.rs:2805-2826) -- a zpipe.c-style caller sees output before Z_FINISH and the stream
+    does not hold its whole input; the pieces form one valid stream"""
+    import zlib
+    monkeypatch.setenv("ZMI_ABI_SEGMENT", "4096")
+    monkeypatch.setenv("ZMI_ABI_EMIT", "20000")
+    zmi_ctypes.load_emu()
+    lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+    data = oracle_lib.load().gen_shard(0, 90000)
+    strm = H.ZStream()
+    assert lib.deflateInit2_(C.byref(strm), 6, 8, 15, 8, 0, lib.zlibVersion(), C.sizeof(H.ZStream)) == H.Z_OK
+    src = C.create_string_buffer(data, len(data))
+    obuf = C.create_string_buffer(1 << 17)
+    out = bytearray()
+    seen_before_finish = 0
+    for pos in range(0, len(data), 3000):
+        strm.next_in, strm.avail_in = C.addressof(src) + pos, min(3000, len(data) - pos)
+        strm.next_out, strm.avail_out = C.addressof(obuf), len(obuf)
+        assert lib.deflate(C.byref(strm), H.Z_NO_FLUSH) == H.Z_OK and strm.avail_in == 0
+        got = len(obuf) - strm.avail_out
+        out += obuf.raw[:got]
+        seen_before_finish += got
+    assert seen_before_finish > 20000 // 4, "no output before Z_FINISH: deflate() is buffering the whole input again"
+    rc = H.Z_OK
+    while rc != H.Z_STREAM_END:
+        strm.next_out, strm.avail_out = C.addressof(obuf), len(obuf)
+        rc = lib.deflate(C.byref(strm), H.Z_FINISH)
+        assert rc in (H.Z_OK, H.Z_STREAM_END)
+        out += obuf.raw[:len(obuf) - strm.avail_out]
+    assert lib.deflateEnd(C.byref(strm)) == H.Z_OK
+    assert zlib.decompress(bytes(out)) == data
+
+
+def test_inflate_input_deferral_is_opt_in_and_exact_at_the_end():
+    """ZMI_INFLATE_DEFER (off by default): inflate(Z_NO_FLUSH) takes small pieces without a device decode per call; the output is
+    complete once the caller asks again with avail_in = 0 (or flushes), a shorter last piece ends the deferral by itself, and the
+    number of device decodes drops from one per call to one per threshold.  In its own process: the setting is read once."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes as C, os, sys, zlib
+sys.path.insert(0, %r)
+import oracle_lib, zmi_ctypes
+import zlib_abi_harness as H
+zmi_ctypes.load_emu(rebuild=False)
+lib = H.bind(C.CDLL(os.path.join(zmi_ctypes.ROOT, "tests", "emu", "libzmi355_emu.so")))
+o = oracle_lib.load(rebuild=False)
+data = o.gen_shard(0, 60000)
+for wbits, tail in ((15, b""), (31, b""), (15, b"x" * 7)):
+    co = zlib.compressobj(6, zlib.DEFLATED, wbits)
+    comp = co.compress(data) + co.flush()
+    for chunk in (16, 100, 1000):
+        strm = H.ZStream()
+        assert lib.inflateInit2_(C.byref(strm), wbits, lib.zlibVersion(), C.sizeof(H.ZStream)) == 0
+        feed = comp + (tail if chunk == 16 else b"")
+        src = C.create_string_buffer(feed, len(feed))
+        dst = C.create_string_buffer(len(data) + 64)
+        strm.next_out, strm.avail_out = C.addressof(dst), len(dst)
+        rc, calls_with_output = 0, 0
+        for pos in range(0, len(feed), chunk):
+            before = strm.avail_out
+            strm.next_in, strm.avail_in = C.addressof(src) + pos, min(chunk, len(feed) - pos)
+            rc = lib.inflate(C.byref(strm), 0)
+            assert rc in (0, 1), rc
+            calls_with_output += before != strm.avail_out
+            if rc == 1:
+                break
+        polls = 0
+        while rc == 0 and polls < 10:
+            strm.avail_in = 0
+            rc = lib.inflate(C.byref(strm), 0)
+            polls += 1
+        assert rc == 1 and dst.raw[:len(data)] == data and strm.total_out == len(data), (wbits, chunk, rc, polls)
+        ncalls = (len(feed) + chunk - 1) // chunk
+        assert calls_with_output <= ncalls // 4 + 4, ("a decode per call?", calls_with_output, ncalls)
+        lib.inflateEnd(C.byref(strm))
+print("deferral ok")
+''' % os.path.join(zmi_ctypes.ROOT, "tests")
+    env = dict(os.environ)
+    env["ZMI_INFLATE_DEFER"] = "8192"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "deferral ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -271,12 +271,28 @@ const char* abi_tune(const char* name) {
     static const bool enabled = getenv("ZMI_TUNING") != nullptr;
     return enabled ? getenv(name) : nullptr;
 }
-size_t segment_bytes() {  // 1 MiB segments; ZMI_ABI_SEGMENT (bytes, multiple of 64) overrides for tests
+// 64 KiB segments (one match-search workgroup and one encoder wave each): a 4 MiB deflate() call is 64 workgroups on the 256 CUs
+// -- with the 1 MiB segments of rounds 1-4 it was 4, and the single-stream path ran at 1 % of the batch rate.  A segment sees the
+// 27 KiB in front of it (window carry-over), the encoder cut its pieces -- with the same marker behind each -- every 64 KiB
+// already, so the stream a caller gets is the same one; ZMI_ABI_SEGMENT (bytes, multiple of 64) overrides for tests
+size_t segment_bytes() {
     static size_t v = 0;
     if (!v) {
         const char* e = abi_tune("ZMI_ABI_SEGMENT");
         long n = e ? atol(e) : 0;
-        v = (n >= 64 && n <= (1 << 28)) ? ((size_t)n & ~(size_t)63) : ((size_t)1 << 20);
+        v = (n >= 64 && n <= (1 << 28)) ? ((size_t)n & ~(size_t)63) : ((size_t)64 << 10);
+    }
+    return v;
+}
+// deflate(Z_NO_FLUSH) compresses what is buffered once this much has come in (the reference emits whenever its pending buffer
+// fills, zlib-rs/src/deflate.rs:2805-2826 flush_pending): a zpipe.c-style caller sees output as it goes and the stream holds a
+// few MiB, not its whole input.  ZMI_ABI_EMIT (bytes) overrides for tests.
+size_t emit_bytes() {
+    static size_t v = 0;
+    if (!v) {
+        const char* e = abi_tune("ZMI_ABI_EMIT");
+        long long n = e ? atoll(e) : 0;
+        v = n >= 64 ? (size_t)n : ((size_t)4 << 20);
     }
     return v;
 }
@@ -481,6 +497,7 @@ struct InflateState {
     Bytes in;       // input from the checkpoint on; the next block starts at bit `sbit` of in[0]
     uint32_t sbit = 0;
     size_t tried = (size_t)-1;     // in.size() at the last decode attempt
+    uInt prev_in0 = 0;             // avail_in of the previous inflate() call (ZMI_INFLATE_DEFER: a shorter piece ends the deferral)
     size_t stop = 0;               // how far into `in` the decoder got (inflateSync searches from there)
     Bytes hist;     // the up to 32 KiB of output in front of the checkpoint; starts as the preset dictionary
     size_t pend = 0;               // decoded bytes behind the checkpoint that are already queued
@@ -721,6 +738,19 @@ size_t abi_limit(const char* name, size_t dflt) {
     return v > 0 ? (size_t)v : dflt;
 }
 size_t queue_limit() { return abi_limit("ZMI_ABI_QUEUE", (size_t)32 << 20); }
+// ZMI_INFLATE_DEFER=BYTES (a product setting, read once; default 0 = off): inflate(Z_NO_FLUSH) may take its input and decode
+// LATER, once BYTES have come in since the last decode -- what zlib calls output latency ("may introduce some output latency
+// (reading input without producing any output) except when forced to flush").  A device decode costs a launch and a round trip
+// (~170 us) whatever it is given, and restarts at the last block boundary: a caller feeding 16-byte pieces pays that a thousand
+// times per block.  Off by default, because it is not free of consequences: the end of the stream may be found in a LATER call
+// than the one that delivered its last byte (the caller asks again with avail_in = 0, or flushes), and input behind the end of
+// the stream that arrived in earlier calls cannot be handed back (avail_in is exact only for the call that finds the end) --
+// a reader of concatenated streams in small pieces must leave it off.  A call decodes at once when it flushes, brings no input,
+// brings LESS than the call before (the last piece of a file), asks for a block stop, or the threshold is reached.
+size_t defer_bytes() {
+    static const size_t v = [] { const char* e = getenv("ZMI_INFLATE_DEFER"); const long long n = e ? atoll(e) : 0; return n > 0 ? (size_t)n : (size_t)0; }();
+    return v;
+}
 size_t take_limit() { return abi_limit("ZMI_ABI_TAKE", (size_t)256 << 20); }
 
 // Flush points in what is buffered: a stream written with Z_SYNC_FLUSH / Z_FULL_FLUSH points (pigz, a logger, this library's
@@ -1054,7 +1084,7 @@ int deflate(z_streamp strm, int flush) {
     if (!s->finished) {
         if (flush == Z_FINISH) rc = compress_buffered(s, true);
         else if (flush != Z_NO_FLUSH) { if (!s->in.empty() || s->last_flush != flush || in0) rc = compress_buffered(s, false, flush == Z_FULL_FLUSH); }
-        else if (s->in.size() >= (64u << 20)) rc = compress_buffered(s, false);
+        else if (s->in.size() >= emit_bytes()) rc = compress_buffered(s, false);
         if (rc != Z_OK) { strm->msg = zError(rc); return rc; }
     }
     s->last_flush = flush;
@@ -1349,10 +1379,14 @@ int inflate(z_streamp strm, int flush) {
     // the next call copies again) stays bounded, however much the caller offers
     const size_t kAbsorb = abi_limit("ZMI_ABI_ABSORB", (size_t)16 << 20);
     bool stopped_now = false;
+    const size_t kDefer = defer_bytes();
+    const bool may_defer = kDefer != 0 && flush == Z_NO_FLUSH && stop_mode == 0 && in0 != 0 && in0 >= s->prev_in0;
+    bool deferred = false;
+    s->prev_in0 = in0;
     for (;;) {
         if (s->stop_state) { inflate_drain(strm, s); break; }   // a pending stop: only the queue is handed out
         const bool paused = s->mode == IM_BLOCKS && s->out.size() - s->out_pos > queue_limit();
-        const bool wants_input = s->mode != IM_BLOCKS || s->in.empty() || s->tried == s->in.size();
+        const bool wants_input = s->mode != IM_BLOCKS || s->in.empty() || s->tried == s->in.size() || may_defer;
         if (s->mode != IM_DONE && s->mode != IM_BAD && strm->avail_in && !paused && wants_input) {
             const uInt n = strm->avail_in < kAbsorb ? strm->avail_in : (uInt)kAbsorb;
             s->in.insert(s->in.end(), strm->next_in, strm->next_in + n);
@@ -1361,6 +1395,11 @@ int inflate(z_streamp strm, int flush) {
             s->in_sync = false;
         }
         const int was = s->mode;
+        if (may_defer && s->mode == IM_BLOCKS && s->in.size() - (s->tried == (size_t)-1 || s->tried > s->in.size() ? 0 : s->tried) < kDefer &&
+            s->out_pos >= s->out.size()) {
+            deferred = true;   // taken, not decoded yet (ZMI_INFLATE_DEFER)
+            break;
+        }
         const int rc = inflate_run(strm, s, stop_mode);
         if (rc == Z_NEED_DICT) { hand_back(0); return Z_NEED_DICT; }
         if (rc != Z_OK) { strm->msg = zError(rc); return rc; }
@@ -1386,7 +1425,7 @@ int inflate(z_streamp strm, int flush) {
     (void)stopped_now;
     // paused (output queued beyond the limit, or the caller's buffer is full) with input the decoder has not reached:
     // `stop` is how far it read (its bit reader runs a few bytes ahead, hence the margin)
-    if (!s->stop_state && s->mode == IM_BLOCKS && s->tried != s->in.size()) hand_back(s->stop > 64 ? s->stop - 64 : 0);
+    if (!deferred && !s->stop_state && s->mode == IM_BLOCKS && s->tried != s->in.size()) hand_back(s->stop > 64 ? s->stop - 64 : 0);
     const bool drained = s->out_pos >= s->out.size();
     // data_type as the reference reports it (inflate.rs:1856-1873): unused bits of the last byte, +64 in the last
     // block, +128 right behind a block (or a wrapper header), +256 behind a block header
