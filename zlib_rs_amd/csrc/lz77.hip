@@ -566,7 +566,7 @@ extern "C" int zmi_launch_lz77(const uint8_t* d_data, const uint64_t* d_off, con
 #else
     const uint32_t LZ_DYN = 0u;
 #endif
-    const bool deep = prm.max_chain > 8u;
+    const bool deep = prm.deep_from != 0u && prm.max_chain >= prm.deep_from;
 #define LZ_GO(H, D) ZMI_LAUNCH((zmi_lz77_kernel_t<H, D>), dim3(n_shards), dim3(1024), LZ_DYN, stream, d_data, d_off, d_len, first_shard, \
                                d_match, match_stride, prm)
     if (prm.hash6) { if (deep) LZ_GO(true, true); else LZ_GO(true, false); }

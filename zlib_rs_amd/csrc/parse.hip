@@ -32,7 +32,7 @@
 #define PAR_NL 288u
 #define PAR_ND 32u
 #define PAR_BIAS 2048
-#define PAR_SPAN 64u      // chunks per wave
+#define PAR_SPAN 64u      // chunks per wave in a batch of thousands of shards (256 KiB); a small launch takes shorter spans (zmi_launch_parse)
 
 struct ParShared {
     uint32_t lfreq[PAR_NL];   // literal / length symbols of the tokens chosen so far (this wave's span)
@@ -125,7 +125,8 @@ static __device__ __forceinline__ ParA par_stage_a(const ParShared* S, const uin
 
 __global__ void __launch_bounds__(64) zmi_parse_kernel(const uint32_t* __restrict__ len, uint32_t first_shard, uint32_t n_shards,
                                                        const uint32_t* __restrict__ match, uint64_t match_stride,
-                                                       uint32_t* __restrict__ dec, uint64_t dec_stride, uint32_t pieces, uint32_t strategy) {
+                                                       uint32_t* __restrict__ dec, uint64_t dec_stride, uint32_t pieces, uint32_t strategy,
+                                                       uint32_t span_chunks) {
     __shared__ ParShared Sh;
     ParShared* S = &Sh;
     const uint32_t lane = zmi_lane();
@@ -133,7 +134,7 @@ __global__ void __launch_bounds__(64) zmi_parse_kernel(const uint32_t* __restric
     const uint32_t span = blockIdx.x / n_shards;
     const uint32_t n = len[first_shard + local];
     const uint32_t nchunks = (n + 4095u) >> 12;
-    if (span * PAR_SPAN >= nchunks) return;
+    if (span * span_chunks >= nchunks) return;
     const uint32_t* words = match + (uint64_t)local * match_stride;
     uint32_t* dout = dec + (uint64_t)local * dec_stride;
     // the encoder's pieces: a token ends with its piece
@@ -146,8 +147,8 @@ __global__ void __launch_bounds__(64) zmi_parse_kernel(const uint32_t* __restric
     zmi_wave_sync();
     uint32_t ntok = 0u;       // tokens counted so far
     uint32_t aq = 12u;        // running average cost of a byte, quarter bits (3 bits per byte before anything is known)
-    const uint32_t c_end = (span + 1u) * PAR_SPAN < nchunks ? (span + 1u) * PAR_SPAN : nchunks;
-    for (uint32_t ch = span * PAR_SPAN; ch < c_end; ++ch) {
+    const uint32_t c_end = (span + 1u) * span_chunks < nchunks ? (span + 1u) * span_chunks : nchunks;
+    for (uint32_t ch = span * span_chunks; ch < c_end; ++ch) {
         par_prices(S, strategy != 4u && ntok >= 256u);
         const uint32_t sb = (ch << 12) + 64u * lane;     // this lane's strip
         uint32_t pe = (sb / psize + 1u) * psize;         // the end of the piece the strip lies in (psize is a multiple of 64)
@@ -239,7 +240,7 @@ __global__ void __launch_bounds__(64) zmi_parse_kernel(const uint32_t* __restric
         // 64 positions: `nxt` is where the next token starts; no pointer chase, the words are read again in ascending order)
         // (every second chunk: the prices of chunks 2 i + 1 and 2 i + 2 come from the counts up to chunk 2 i -- half the scans for
         // -0.04 ... -0.14 % of ratio, tools/parse_lab.py LAB_EVERY)
-        if (ch + 1u < c_end && ((ch - span * PAR_SPAN) & 1u) == 0u) {
+        if (ch + 1u < c_end && ((ch - span * span_chunks) & 1u) == 0u) {
             uint32_t nxt = 0u, cnt = 0u;
 #pragma unroll 1
             for (uint32_t b = 0; b < 4u; ++b) {
@@ -273,8 +274,13 @@ extern "C" int zmi_launch_parse(const uint32_t* d_len, uint32_t first_shard, uin
                                 hipStream_t stream) {
     if (n_shards == 0 || max_len == 0) return 0;
     const uint32_t nchunks = (max_len + 4095u) >> 12;
-    const uint32_t spans = (nchunks + PAR_SPAN - 1u) / PAR_SPAN;
+    // a wave's span: 64 chunks in a batch (its prices adapt over 256 KiB); a launch of a few shards -- the segments of one deflate()
+    // call -- takes spans down to 4 chunks so that the chip sees a thousand waves or so (a 4 MiB call: 275 -> 70 us; the first
+    // chunk of every span is priced with the static code)
+    uint32_t span_chunks = PAR_SPAN;
+    while (span_chunks > 4u && (uint64_t)n_shards * ((nchunks + span_chunks - 1u) / span_chunks) < 1024u) span_chunks >>= 1;
+    const uint32_t spans = (nchunks + span_chunks - 1u) / span_chunks;
     ZMI_LAUNCH(zmi_parse_kernel, dim3(n_shards * spans), dim3(64), 0, stream, d_len, first_shard, n_shards, d_match, match_stride, d_dec,
-               dec_stride, pieces < 1u ? 1u : pieces, strategy);
+               dec_stride, pieces < 1u ? 1u : pieces, strategy, span_chunks);
     return 0;
 }

@@ -287,14 +287,10 @@ size_t segment_bytes() {
 // deflate(Z_NO_FLUSH) compresses what is buffered once this much has come in (the reference emits whenever its pending buffer
 // fills, zlib-rs/src/deflate.rs:2805-2826 flush_pending): a zpipe.c-style caller sees output as it goes and the stream holds a
 // few MiB, not its whole input.  ZMI_ABI_EMIT (bytes) overrides for tests.
-size_t emit_bytes() {
-    static size_t v = 0;
-    if (!v) {
-        const char* e = abi_tune("ZMI_ABI_EMIT");
-        long long n = e ? atoll(e) : 0;
-        v = n >= 64 ? (size_t)n : ((size_t)4 << 20);
-    }
-    return v;
+size_t emit_bytes() {   // (not cached: abi_tune is a null pointer in a product process, and the tests change the value between streams)
+    const char* e = abi_tune("ZMI_ABI_EMIT");
+    const long long n = e ? atoll(e) : 0;
+    return n >= 64 ? (size_t)n : ((size_t)4 << 20);
 }
 
 // compress `n` host bytes as consecutive raw-deflate segments; appends the bytes to `out`.  `hist` (hist_len

@@ -271,17 +271,22 @@ struct zmi_level_cfg {
 // reference's level 6: 2.91), benchmark shards 2.247 -> see DESIGN.md section 9.
 static const zmi_level_cfg kLevels[10] = {
     {0, 0, 0, 0, 4096},          // 0: stored
-    {2, 16, 8, 0, 8192},         // 1
-    {3, 32, 8, 0, 8192},         // 2
+    {2, 16, 8, 0, 8192},         // 1  (greedy, lazy path of the encoder)
+    {3, 32, 8, 0, 8192},         // 2  (greedy)
+    // 3 ... 9: the token choice is the cost parse's (csrc/parse.hip) -- `lazy` is not used there, what separates the levels is the
+    // search: budget, and the length at which a walk is content (good)
     {3, 32, 8, 4, 4096},         // 3
     {3, 64, 16, 8, 4096},        // 4
-    {3, 128, 16, 16, 4096},      // 5
+    {3, 128, 16, 16, 4096},      // 5  (= 4 in effect: both stop at 16 equal bytes)
     {4, 128, 16, 32, 4096},      // 6  (good 32 -> 16 in round 4: lz77 138.7 -> 130.1 ms, ratio 2.2550 -> 2.2532, lcet10.txt -0.04 %)
     {6, 128, 16, 32, 4096},      // 7
-    {14, 258, 64, 128, 2048},    // 8
-    // 9: the ratio curve is flat beyond ~24 candidates (lcet10.txt 2.8776 at 24, 2.8802 at 128; benchmark shards 2.2726 /
-    // 2.2807, the reference's level 9: 2.2735) while every candidate costs the same: round 1's 128 ran at 5.6 GiB/s
-    {22, 258, 128, 258, 2048},
+    // 8, 9 (round 5): budgets 10 and 16 on the SHORT-budget kernel (the walk ends at the first candidate equal in 16 bytes, the wave
+    // extends it afterwards) instead of 14 and 22 on the deep one, whose in-loop extension makes a candidate cost 22 ms against 7
+    // (per 16 Ki shards).  Measured with the cost parse, 8192 shards (profiles/r05_level9_budget_sweep.txt): deep 22 = 2.325 at
+    // 24.8 GiB/s, deep 12 = 2.319 at 35.4, short 16 = 2.319 at 39.5, short 10 = 2.314 at 49.2 (round 4's level 9, lazy parse, deep
+    // 22: 2.315 at 26.0).  The deep instantiation stays reachable for experiments (ZMI_DEEP_FROM under ZMI_TUNING).
+    {10, 258, 16, 128, 2048},    // 8
+    {16, 258, 16, 258, 2048},    // 9
 };
 
 extern "C" int zmi_checksum_batch_dev(zmi_ctx* c, const void* d_data, const uint64_t* d_off, const uint32_t* d_len,
@@ -487,10 +492,12 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     // waves outrun one producer: budget 5 measured 227 ms with two, 273 ms with one), 3 at level 1, whose searchers do so
     // little per position that even two producers set the pace (97.1 -> 95.2 ms per 16 Ki shards; at level 3 a third
     // producer already costs more as a missing searcher than it brings: 114.2 -> 120.5 ms)
-    lp.producers = L.chain > 8u ? 1u : (level == 1 ? 3u : 2u);
+    lp.producers = L.chain > 8u ? 1u : (level == 1 ? 3u : 2u);   // (budgets 10 / 16: one producer measured 1-2 % ahead of two)
     if (const char* pv = zmi_tune("ZMI_PRODUCERS")) lp.producers = (uint32_t)atoi(pv);
     lp.dbg = 0u;
     if (const char* dv = zmi_tune("ZMI_LZ_DBG")) lp.dbg = (uint32_t)atoi(dv);
+    lp.deep_from = 0xFFFFFFFFu;   // (no level uses the deep instantiation any more: see kLevels)
+    if (const char* dv = zmi_tune("ZMI_DEEP_FROM")) lp.deep_from = (uint32_t)atoi(dv);
     lp.barren_chain = 1u;
     if (const char* bv = zmi_tune("ZMI_BARREN_CHAIN")) lp.barren_chain = (uint32_t)atoi(bv);
     // short far matches are judged by the encoder, block by block, from the codes it just used (enc_far_limits); the
@@ -510,6 +517,10 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     if (const char* ms = zmi_tune("ZMI_MIN_SUB_SPAN")) ep.min_sub_span = (uint32_t)atoi(ms);
     if (const char* hb = zmi_tune("ZMI_SPLIT_HDR")) ep.split_hdr_bits = (uint32_t)atoi(hb);
     if (const char* bt = zmi_tune("ZMI_BLOCK_TOKENS")) ep.block_tokens = (uint32_t)atoi(bt) >= 64u ? (uint32_t)atoi(bt) : 64u;
+    // a launch of a few shards -- the 64 KiB segments of one deflate() call, a compress2() -- would be a few dozen encoder waves of
+    // 0.7 ... 1.8 ms each on 256 CUs (profiles/r05_stream_deflate_trace.txt): pieces of 16 KiB there, four waves per segment
+    // (a marker and a fresh block per 16 KiB: ~1 % of ratio, only where the chip would otherwise stand empty)
+    if ((uint64_t)n * ((max_len + 65535u) / 65536u) < 512u) ep.block_span = 16384u;
     const char* span_env = zmi_tune("ZMI_BLOCK_SPAN");
     if (span_env && atoi(span_env) >= 64) ep.block_span = (uint32_t)atoi(span_env);
 
