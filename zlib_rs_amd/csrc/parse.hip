@@ -97,30 +97,35 @@ struct ParA {
     uint32_t plit, pd, len;
     uint32_t pl2, cw[2];
 };
-// CLIP: the strip comes within a token's reach (258) of the end of its piece, or holds positions behind the shard's end -- one chunk
-// in sixteen of a 1 MiB shard; everywhere else the five instructions of the two checks are not there
-template <bool CLIP>
-static __device__ __forceinline__ ParA par_stage_a(const ParShared* S, const uint16_t* row, uint32_t w, uint32_t k, uint32_t sb, uint32_t pe) {
+// (The piece-end rule -- a token ends with its piece, positions behind the shard's end are nothing -- is applied to the WORDS when a
+// batch is loaded, and only in a batch that comes within a token's reach of such an end: par_clip_batch.  Stage A itself has no
+// check left: five instructions per position less in fifteen chunks of sixteen.)
+static __device__ __forceinline__ ParA par_stage_a(const ParShared* S, const uint16_t* row, uint32_t w, uint32_t k) {
     ParA a;
-    uint32_t len = (w >> 8) & 0x1FFu;
-    const uint32_t pl = S->psym[w & 0xFFu];
-    if (CLIP) {
-        const uint32_t pos = sb + k;                      // (k wraps for the two positions "in front of" a strip: nothing valid there)
-        const bool valid = pos < pe;
-        const uint32_t room = valid ? pe - pos : 0u;      // a token may not cross the end of its piece (encode.hip starts a fresh parse there)
-        len = len < room ? len : room;
-        a.plit = valid ? pl : 0u;
-    } else a.plit = pl;
+    const uint32_t len = (w >> 8) & 0x1FFu;
+    a.plit = S->psym[w & 0xFFu];
     a.len = len;
     a.pd = S->pdist[par_dist_idx((w >> 17) + 1u)];
     a.pl2 = S->plen2[(len >= 4u ? len : 4u) - 3u];
 #pragma unroll
     for (uint32_t c = 0; c < 2u; ++c) {
         const uint32_t l = len >= 4u + c ? len - c : 4u;
-        const uint32_t tg = k + l;
+        const uint32_t tg = (k + l) & 0x3FFu;                // (k wraps for the two positions "in front of" a strip: any cell will do)
         a.cw[c] = row[tg < 63u ? tg : 63u];
     }
     return a;
+}
+// words of positions first ... first + 15 of a strip whose piece ends at pe: lengths clipped to the room left, positions at or
+// behind pe become literals of symbol 0 (their cost is a constant per position: it shifts every cost in front of them alike)
+static __device__ __forceinline__ void par_clip_batch(uint32_t (&w)[16], uint32_t first, uint32_t pe) {
+#pragma unroll
+    for (uint32_t q = 0; q < 16u; ++q) {
+        const uint32_t pos = first + q;
+        const uint32_t room = pos < pe ? pe - pos : 0u;
+        const uint32_t len = (w[q] >> 8) & 0x1FFu;
+        const uint32_t l = len < room ? len : room;
+        w[q] = pos < pe ? ((w[q] & ~(0x1FFu << 8)) | (l << 8)) : 0u;
+    }
 }
 
 __global__ void __launch_bounds__(64) zmi_parse_kernel(const uint32_t* __restrict__ len, uint32_t first_shard, uint32_t n_shards,
@@ -164,29 +169,34 @@ __global__ void __launch_bounds__(64) zmi_parse_kernel(const uint32_t* __restric
                 dst[4u * q] = v.x; dst[4u * q + 1u] = v.y; dst[4u * q + 2u] = v.z; dst[4u * q + 3u] = v.w;
             }
         };
+        const bool near_end = __ballot(pe < sb + 64u + 258u) != 0ull;   // (wave-uniform: some strip of the chunk is within reach of an end)
         load16(wa, sb + 48u);
         load16(wb, sb + 32u);
+        if (near_end) { par_clip_batch(wa, sb + 48u, pe); par_clip_batch(wb, sb + 32u, pe); }
         int32_t cnext = 0;                                // cost of position k + 1, relative to the end of the strip
         uint32_t d0 = 0u, d1 = 0u, d2 = 0u, d3 = 0u;      // the strip's decisions, 16 positions per register
         uint16_t* const row = S->cost + PAR_PITCH * lane;
         auto strip = [&](auto clip_tag) {
-            constexpr bool CLIP = decltype(clip_tag)::value;
-            ParA s0 = par_stage_a<CLIP>(S, row, wa[15], 63u, sb, pe);   // (targets behind the strip: no cell is read before its store)
-            ParA s1 = par_stage_a<CLIP>(S, row, wa[14], 62u, sb, pe);
+            ParA s0 = par_stage_a(S, row, wa[15], 63u);   // (targets behind the strip: no cell is read before its store)
+            ParA s1 = par_stage_a(S, row, wa[14], 62u);
             // (the batch loop stays rolled and every position's code stays together: unrolled and left to the scheduler, the strip's
             // 64 positions were one region of 332 VGPRs)
 #pragma unroll 1
             for (int b = 3; b >= 0; --b) {
-                if (b >= 2) load16(wc, sb + 16u * (uint32_t)(b - 2));
+                if (b >= 2) {
+                    load16(wc, sb + 16u * (uint32_t)(b - 2));
+                    if (near_end) par_clip_batch(wc, sb + 16u * (uint32_t)(b - 2), pe);
+                }
                 uint32_t dcur = 0u;
 #pragma unroll
                 for (int t = 15; t >= 0; --t) {
                     const uint32_t k = 16u * (uint32_t)b + (uint32_t)t;
                     // stage A of position k - 2 (the last two steps of a strip: positions in front of it, harmless and unused)
-                    const ParA s2 = par_stage_a<CLIP>(S, row, t >= 2 ? wa[t >= 2 ? t - 2 : 0] : wb[t + 14], k - 2u, sb, pe);
-                    // stage B of position k
-                    int32_t best = (int32_t)s0.plit + cnext;
-                    uint32_t code = 0u;
+                    const ParA s2 = par_stage_a(S, row, t >= 2 ? wa[t >= 2 ? t - 2 : 0] : wb[t + 14], k - 2u);
+                    // stage B of position k: the three alternatives as (biased cost << 2 | code), one three-way minimum (costs are biased
+                    // by PAR_BIAS in the cells, so everything is unsigned; an alternative that does not exist is all ones)
+                    const uint32_t st_next = (uint32_t)(cnext + PAR_BIAS);
+                    uint32_t alt[2];
 #pragma unroll
                     for (uint32_t c = 0; c < 2u; ++c) {
                         const bool ok = s0.len >= 4u + c;
@@ -194,21 +204,23 @@ __global__ void __launch_bounds__(64) zmi_parse_kernel(const uint32_t* __restric
                         const uint32_t tg = k + l;
                         const bool inside = tg < 64u;
                         const uint32_t over = __umul24(tg & 0x1FFu, aq) - 64u * aq;   // (tg - 64) * aq, full-rate; only used behind the strip
-                        int32_t behind = -(int32_t)(over < (uint32_t)PAR_BIAS ? over : (uint32_t)PAR_BIAS);
+                        uint32_t behind = (uint32_t)PAR_BIAS - (over < (uint32_t)PAR_BIAS ? over : (uint32_t)PAR_BIAS);
 #ifndef ZMI_EMU
-                        asm volatile("" : "+v"(behind));   // (computed for every lane and selected: left alone the compiler branches around these four instructions)
+                        asm volatile("" : "+v"(behind));   // (computed for every lane and selected: left alone the compiler branches around these instructions)
 #endif
-                        const int32_t cc = inside ? (int32_t)s0.cw[c] - PAR_BIAS : behind;
-                        const int32_t tot = (int32_t)(c ? s0.pl2 >> 16 : s0.pl2 & 0xFFFFu) + (int32_t)s0.pd + cc;
-                        const bool better = ok & (tot < best);
-                        best = better ? tot : best;
-                        code = better ? c + 1u : code;
+                        const uint32_t cc = inside ? s0.cw[c] : behind;
+                        const uint32_t tot = (c ? s0.pl2 >> 16 : s0.pl2 & 0xFFFFu) + s0.pd + cc;
+                        alt[c] = ok ? ((tot << 2) | (c + 1u)) : 0xFFFFFFFFu;
                     }
-                    int32_t st = best + PAR_BIAS;
-                    st = st < 0 ? 0 : (st > 16383 ? 16383 : st);
+                    uint32_t m = (s0.plit + st_next) << 2;
+                    m = m < alt[0] ? m : alt[0];
+                    m = m < alt[1] ? m : alt[1];
+                    const uint32_t code = m & 3u;
+                    uint32_t st = m >> 2;
+                    st = st > 16383u ? 16383u : st;
                     row[k] = (uint16_t)st;
                     zmi_wave_order();   // (the gathers of the stage A below this point may read this cell: the store stays in front of them)
-                    cnext = st - PAR_BIAS;
+                    cnext = (int32_t)st - PAR_BIAS;
                     dcur |= code << (2u * (uint32_t)t);
                     s0 = s1;
                     s1 = s2;
@@ -219,8 +231,6 @@ __global__ void __launch_bounds__(64) zmi_parse_kernel(const uint32_t* __restric
                 for (uint32_t q = 0; q < 16u; ++q) { wa[q] = wb[q]; wb[q] = wc[q]; }
             }
         };
-        // (a second instantiation without the piece-end checks for the fifteen chunks in sixteen that need none: five instructions per
-        // position less, but 207 VGPRs instead of 160 for the kernel -- a wave per SIMD; not taken)
         strip(ParTag<true>{});
         // the decisions leave: 16 bytes per strip, 1 KiB per chunk, in position order (segment g of the shard: bytes 16 g ...)
         if ((uint64_t)(sb >> 4) + 4u <= dec_stride) {
@@ -271,14 +281,14 @@ __global__ void __launch_bounds__(64) zmi_parse_kernel(const uint32_t* __restric
 
 extern "C" int zmi_launch_parse(const uint32_t* d_len, uint32_t first_shard, uint32_t n_shards, uint32_t max_len, const uint32_t* d_match,
                                 uint64_t match_stride, uint32_t* d_dec, uint64_t dec_stride, uint32_t pieces, uint32_t strategy,
-                                hipStream_t stream) {
+                                uint32_t span_chunks, hipStream_t stream) {
     if (n_shards == 0 || max_len == 0) return 0;
     const uint32_t nchunks = (max_len + 4095u) >> 12;
-    // a wave's span: 64 chunks in a batch (its prices adapt over 256 KiB); a launch of a few shards -- the segments of one deflate()
-    // call -- takes spans down to 4 chunks so that the chip sees a thousand waves or so (a 4 MiB call: 275 -> 70 us; the first
-    // chunk of every span is priced with the static code)
-    uint32_t span_chunks = PAR_SPAN;
-    while (span_chunks > 4u && (uint64_t)n_shards * ((nchunks + span_chunks - 1u) / span_chunks) < 1024u) span_chunks >>= 1;
+    // a wave's span: 64 chunks in a batch (its prices adapt over 256 KiB); the segments of one deflate() call take 4 so that the
+    // chip sees a few hundred waves (a 4 MiB call: 275 -> 70 us; the first chunk of every span is priced with the static code).
+    // The caller decides (zmi_api.hip): what a shard compresses to must not depend on how many shards its launch holds.
+    if (span_chunks < 1u) span_chunks = 1u;
+    if (span_chunks > PAR_SPAN) span_chunks = PAR_SPAN;
     const uint32_t spans = (nchunks + span_chunks - 1u) / span_chunks;
     ZMI_LAUNCH(zmi_parse_kernel, dim3(n_shards * spans), dim3(64), 0, stream, d_len, first_shard, n_shards, d_match, match_stride, d_dec,
                dec_stride, pieces < 1u ? 1u : pieces, strategy, span_chunks);

@@ -520,7 +520,10 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     // a launch of a few shards -- the 64 KiB segments of one deflate() call, a compress2() -- would be a few dozen encoder waves of
     // 0.7 ... 1.8 ms each on 256 CUs (profiles/r05_stream_deflate_trace.txt): pieces of 16 KiB there, four waves per segment
     // (a marker and a fresh block per 16 KiB: ~1 % of ratio, only where the chip would otherwise stand empty)
-    if ((uint64_t)n * ((max_len + 65535u) / 65536u) < 512u) ep.block_span = 16384u;
+    // (only for the segments of ONE stream -- chain mode: what a batch of independent shards compresses to does not depend on how
+    // many of them a launch holds, tests/test_gpu_parity.py::test_host_batch_pipeline_on_gpu)
+    const bool small_launch = chain_mode != 0u && (uint64_t)n * ((max_len + 65535u) / 65536u) < 512u;
+    if (small_launch) ep.block_span = 16384u;
     const char* span_env = zmi_tune("ZMI_BLOCK_SPAN");
     if (span_env && atoi(span_env) >= 64) ep.block_span = (uint32_t)atoi(span_env);
 
@@ -566,7 +569,7 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
         if (ep.cost_parse) {
             zmi_scope_timer tm(c, ZMI_K_PARSE, stream);
             zmi_launch_parse(d_in_len, (uint32_t)first, cnt, max_len, (const uint32_t*)c->match.p, per_shard / 4u, d_dec, dec_bytes / 4u, pieces,
-                             (uint32_t)strategy, stream);
+                             (uint32_t)strategy, small_launch ? 4u : 64u, stream);
         }
         if (forked) { ZMI_HIP(hipStreamWaitEvent(stream, c->ev_join, 0)); forked = false; }
         zmi_scope_timer tm2(c, ZMI_K_ENCODE, stream);

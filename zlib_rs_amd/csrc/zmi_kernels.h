@@ -85,7 +85,8 @@ int zmi_launch_encode(const uint8_t* d_data, const uint64_t* d_off, const uint32
 // the cost parse (levels 3-9, csrc/parse.hip): d_dec receives two bits per position of every shard of the group (dec_stride
 // dwords per shard, 16 bytes per segment of 64 positions): 0 literal, 1 the match, 2 the match one byte shorter
 int zmi_launch_parse(const uint32_t* d_len, uint32_t first_shard, uint32_t n_shards, uint32_t max_len, const uint32_t* d_match,
-                     uint64_t match_stride, uint32_t* d_dec, uint64_t dec_stride, uint32_t pieces, uint32_t strategy, hipStream_t stream);
+                     uint64_t match_stride, uint32_t* d_dec, uint64_t dec_stride, uint32_t pieces, uint32_t strategy, uint32_t span_chunks,
+                     hipStream_t stream);
 int zmi_launch_inflate(const uint8_t* d_in, const uint64_t* d_in_off, const uint32_t* d_in_len, uint32_t n_streams,
                        uint32_t wrap, uint8_t* d_out, const uint64_t* d_out_off, const uint32_t* d_out_cap,
                        uint32_t* d_out_len, uint32_t* d_in_used, uint32_t* d_check, int32_t* d_status,
