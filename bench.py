@@ -790,8 +790,8 @@ def chunk_sweep_leg(gz_stream, out_len, abi_lib):
         open(gz, "wb").write(gz_stream)
         res = {}
         # eager = the library's default: every inflate() decodes what it was given (a device launch per call: the pieces below
-        # 256 bytes would take minutes and are left out); deferred = ZMI_INFLATE_DEFER=262144 (opt-in, include/zmi355_zlib.h)
-        for name, lib, defer, cs in (("system_zlib", "libz.so.1", None, chunks), ("zmi_deferred", abi_lib, "262144", chunks),
+        # 256 bytes would take minutes and are left out); deferred = ZMI_INFLATE_DEFER=1048576 (opt-in, include/zmi355_zlib.h)
+        for name, lib, defer, cs in (("system_zlib", "libz.so.1", None, chunks), ("zmi_deferred", abi_lib, "1048576", chunks),
                                      ("zmi_eager", abi_lib, None, [c for c in chunks if c >= 256])):
             env = dict(os.environ)
             env["LD_LIBRARY_PATH"] = os.path.dirname(abi_lib) + ":" + env.get("LD_LIBRARY_PATH", "")
@@ -816,8 +816,8 @@ def chunk_sweep_leg(gz_stream, out_len, abi_lib):
         rows[str(c)] = row
     return {"chunks": rows, "stream": "the oracle's gzip stream of the same %d bytes (no flush points)" % out_len,
             "modes": "zmi_eager: the default -- every inflate() call decodes what it brought (exact input accounting, the end of the "
-                     "stream is found by the call that delivers it); zmi_deferred: ZMI_INFLATE_DEFER=262144 -- input is taken and "
-                     "decoded once 256 KiB have come in (zlib's 'output latency'), `polls` = calls with avail_in = 0 after the last "
+                     "stream is found by the call that delivers it); zmi_deferred: ZMI_INFLATE_DEFER=1048576 -- input is taken and "
+                     "decoded once 1 MiB has come in (zlib's 'output latency'), `polls` = calls with avail_in = 0 after the last "
                      "piece until Z_STREAM_END",
             "check": "every run: Z_STREAM_END, total_out and the FNV-1a of the output equal the system zlib's"}
 

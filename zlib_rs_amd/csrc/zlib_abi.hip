@@ -647,7 +647,13 @@ void put_header(DeflateState* s) {
     s->header_done = true;
 }
 // full_flush: the caller asked for Z_FULL_FLUSH -- the data after it must not refer to anything before it
-int compress_buffered(DeflateState* s, bool finish, bool full_flush = false) {
+// (data, n): what to compress -- the stream's buffer (the default), or the caller's own buffer when a call brings a whole launch's
+// worth and nothing is buffered in front of it: the bytes then go from the caller's memory to the device without a stop in the
+// stream's buffer (a 4 MiB deflate() call: 0.3 of its 1.3 ms).  The call stays synchronous: the caller's buffer is read only while
+// deflate() runs (zlib-rs/src/deflate.rs:1697-1698 copies its input for the same reason).
+int compress_buffered(DeflateState* s, bool finish, bool full_flush = false, const uint8_t* data = nullptr, size_t n = 0) {
+    const bool direct = data != nullptr;
+    if (!direct) { data = s->in.data(); n = s->in.size(); }
     if (!s->header_done) put_header(s);
     if (s->prime_bits) {
         // deflatePrime left a partial byte.  Every segment of this engine starts on a byte boundary, so an empty
@@ -659,28 +665,31 @@ int compress_buffered(DeflateState* s, bool finish, bool full_flush = false) {
         s->prime_bits = 0;
         s->prime_val = 0;
     }
-    s->total_len += s->in.size();
+    s->total_len += n;
     uint32_t part = 0;   // checksum of this call's input, computed on the GPU next to the compression
     size_t last_at = 0;
-    int rc = gpu_deflate_segments(s->in.data(), s->in.size(), s->hist.data(), s->hist.size(), s->level, s->strategy, finish, s->pending,
+    int rc = gpu_deflate_segments(data, n, s->hist.data(), s->hist.size(), s->level, s->strategy, finish, s->pending,
                                   s->wrap, &part, &last_at, s->wbits);
     if (rc == Z_OK) {
         s->last_seg.assign(s->pending.begin() + last_at, s->pending.end());
         s->last_seg_final = finish;
         s->used_bits = -1;
     }
-    if (rc == Z_OK && s->wrap == 1) s->adler = host_adler_combine(s->adler, part, s->in.size());
-    if (rc == Z_OK && s->wrap == 2) s->crc = gf2_mul(gf2_xpow8(s->in.size()), s->crc) ^ part;
+    if (rc == Z_OK && s->wrap == 1) s->adler = host_adler_combine(s->adler, part, n);
+    if (rc == Z_OK && s->wrap == 2) s->crc = gf2_mul(gf2_xpow8(n), s->crc) ^ part;
     // window carry-over to the next call: the last 32 KiB of what the stream has seen (deflate.rs:2739-2752: only
     // Z_FULL_FLUSH forgets it)
     // (Z_FINISH leaves the window as it is -- deflateGetDictionary after the last deflate() still shows it, as
     // libz-rs-sys-cdylib/example.c test_deflate_get_dict expects; nothing is compressed against it any more)
     if (full_flush) s->hist.clear();
     else {
-        s->hist.insert(s->hist.end(), s->in.begin(), s->in.end());
-        if (s->hist.size() > 32768u) s->hist.erase(s->hist.begin(), s->hist.end() - 32768);
+        if (n >= 32768u) s->hist.assign(data + (n - 32768u), data + n);
+        else {
+            s->hist.insert(s->hist.end(), data, data + n);
+            if (s->hist.size() > 32768u) s->hist.erase(s->hist.begin(), s->hist.end() - 32768);
+        }
     }
-    s->in.clear();
+    if (!direct) s->in.clear();
     if (rc != Z_OK) return rc;
     if (finish) {
         if (s->wrap == 1) {  // deflate.rs:2786-2788
@@ -1066,8 +1075,13 @@ int deflate(z_streamp strm, int flush) {
     if (strm->avail_out == 0) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; }
     const uInt in0 = strm->avail_in, out0 = strm->avail_out;
     if (s->finished && strm->avail_in != 0) { strm->msg = kErrMsg[7]; return Z_BUF_ERROR; }
+    // a call that brings a launch's worth (or flushes / finishes) with nothing buffered in front of it is compressed straight from
+    // the caller's buffer (compress_buffered)
+    const uint8_t* direct = nullptr;
+    size_t direct_n = 0;
     if (strm->avail_in) {
-        s->in.insert(s->in.end(), strm->next_in, strm->next_in + strm->avail_in);
+        if (s->in.empty() && !s->finished && (flush != Z_NO_FLUSH || strm->avail_in >= emit_bytes())) { direct = strm->next_in; direct_n = strm->avail_in; }
+        else s->in.insert(s->in.end(), strm->next_in, strm->next_in + strm->avail_in);
         strm->next_in += strm->avail_in;
         strm->total_in += strm->avail_in;
         strm->avail_in = 0;
@@ -1078,9 +1092,9 @@ int deflate(z_streamp strm, int flush) {
     if (!s->header_done && !s->finished) put_header(s);
     const int old_flush = s->last_flush;
     if (!s->finished) {
-        if (flush == Z_FINISH) rc = compress_buffered(s, true);
-        else if (flush != Z_NO_FLUSH) { if (!s->in.empty() || s->last_flush != flush || in0) rc = compress_buffered(s, false, flush == Z_FULL_FLUSH); }
-        else if (s->in.size() >= emit_bytes()) rc = compress_buffered(s, false);
+        if (flush == Z_FINISH) rc = compress_buffered(s, true, false, direct, direct_n);
+        else if (flush != Z_NO_FLUSH) { if (!s->in.empty() || s->last_flush != flush || in0) rc = compress_buffered(s, false, flush == Z_FULL_FLUSH, direct, direct_n); }
+        else if (direct || s->in.size() >= emit_bytes()) rc = compress_buffered(s, false, false, direct, direct_n);
         if (rc != Z_OK) { strm->msg = zError(rc); return rc; }
     }
     s->last_flush = flush;
