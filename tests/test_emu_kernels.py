@@ -475,3 +475,24 @@ def test_jump_resolve_equals_serial_resolve():
     e = zmi_ctypes.Engine(zmi_ctypes.load_emu())
     assert parity_checks.jump_resolve_checks(e, oracle_lib.load()) == 8
     e.close()
+
+
+def test_cost_parse_against_the_lazy_rule(eng, o, monkeypatch):
+    """the cost parse (csrc/parse.hip, levels 3-9) against the lazy rule on the same matches: valid streams either way, text and the
+    XML-like class smaller, nothing more than 2 % larger; odd sizes around the chunk (4096) and strip (64) borders, and a shard whose
+    pieces are no multiple of a chunk"""
+    blobs = [parity_checks.tile(dict(parity_checks.real_fixtures())["lcet10.txt"], 1 << 17), o.gen_shard(3, 1 << 17), o.gen_shard(4, 100000),
+             o.gen_shard(0, 4095), o.gen_shard(1, 4097), o.gen_shard(2, 65), o.gen_shard(6, 70001), o.gen_shard(5, 12345), b"", b"a" * 300]
+    sizes = {}
+    for cp in ("0", "1"):
+        monkeypatch.setenv("ZMI_COST_PARSE", cp)
+        for lvl in (3, 6, 9):
+            comp, st = eng.deflate(blobs, level=lvl, wrap=1)
+            assert st == [0] * len(blobs)
+            for b, c in zip(blobs, comp):
+                assert zlib.decompress(c) == b
+            sizes[cp, lvl] = [len(c) for c in comp]
+    for lvl in (3, 6, 9):
+        assert sizes["1", lvl][0] < sizes["0", lvl][0] and sizes["1", lvl][1] < sizes["0", lvl][1], (lvl, sizes)
+        for a, b in zip(sizes["1", lvl], sizes["0", lvl]):
+            assert a <= b * 1.02 + 8, (lvl, sizes)

@@ -552,3 +552,26 @@ def test_jump_resolve_equals_serial_resolve_on_gpu():
     eng = zmi_ctypes.Engine(zmi_ctypes.load_product())
     assert parity_checks.jump_resolve_checks(eng, oracle_lib.load(rebuild=False), big=True) == 8
     eng.close()
+
+
+def test_cost_parse_against_the_lazy_rule_on_gpu(engine, monkeypatch):
+    """levels 3-9 choose their tokens by price (csrc/parse.hip).  Against the lazy rule on the same matches (ZMI_COST_PARSE=0, a test
+    override): valid streams either way, real text at least 1.5 % smaller, no data class more than 1.5 % larger (record-like data
+    loses ~0.9 %: pricing from one's own statistics), the mix smaller."""
+    import oracle_lib
+    import parity_checks
+    o = oracle_lib.load(rebuild=False)
+    blobs = [parity_checks.tile(raw) for _, raw in parity_checks.real_fixtures()][:1] + [o.gen_shard(i, SHARD) for i in range(8)]
+    sizes = {}
+    for cp in ("0", "1"):
+        monkeypatch.setenv("ZMI_COST_PARSE", cp)
+        outs, st = _deflate(engine, blobs, level=6, wrap=1)
+        assert (st == 0).all()
+        for b, c in zip(blobs, outs):
+            assert zlib.decompress(c) == b
+        sizes[cp] = [len(c) for c in outs]
+    monkeypatch.delenv("ZMI_COST_PARSE")
+    assert sizes["1"][0] <= sizes["0"][0] * 0.985, ("lcet10.txt", sizes)
+    for i in range(1, 9):
+        assert sizes["1"][i] <= sizes["0"][i] * 1.015, (i, sizes)
+    assert sum(sizes["1"][1:]) < sum(sizes["0"][1:])

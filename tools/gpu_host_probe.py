@@ -22,6 +22,9 @@ def main():
     ap.add_argument("--shards", type=int, default=4096)
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--scratch-gib", type=float, default=0.0, help="the context's scratch limit (bench.py: 70)")
+    ap.add_argument("--hog-gib", type=float, default=0.0, help="device memory held beside the run (bench.py holds ~206 GiB)")
+    ap.add_argument("--empty-out", action="store_true", help="np.empty output buffers (pages never touched before the first call), as bench.py has them")
     a = ap.parse_args()
     L, path = P.load_lib()
     vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
@@ -29,6 +32,10 @@ def main():
     L.zmi_inflate_batch.argtypes = [vp, vp, vp, vp, u32, i32, vp, vp, vp, vp, vp]
     ctx = C.c_void_p()
     assert L.zmi_ctx_create(C.byref(ctx), 0) == 0
+    if a.scratch_gib > 0:
+        L.zmi_ctx_set_scratch_limit.argtypes = [vp, u64]
+        assert L.zmi_ctx_set_scratch_limit(ctx, int(a.scratch_gib * 2**30)) == 0
+    hog = [P.dmalloc(1 << 30) for _ in range(int(a.hog_gib))]
     B, S = 1 << 20, a.shards
     stride = int(L.zmi_deflate_bound(B, 1))
     d_in = P.dmalloc(S * B)
@@ -40,7 +47,7 @@ def main():
     P.hip.hipFree(d_in)
     h_off = np.arange(S, dtype=np.uint64) * B
     h_len = np.full(S, B, dtype=np.uint32)
-    h_out = np.zeros(S * stride, dtype=np.uint8)
+    h_out = np.empty(S * stride, dtype=np.uint8) if a.empty_out else np.zeros(S * stride, dtype=np.uint8)
     h_olen = np.zeros(S, dtype=np.uint32)
     h_st = np.zeros(S, dtype=np.int32)
     best = None
