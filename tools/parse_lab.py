@@ -16,7 +16,7 @@ import zmi_ctypes  # noqa: E402
 
 class LzParams(C.Structure):
     _fields_ = [(k, C.c_uint32) for k in ("max_chain", "nice_len", "good_len", "max_dist", "claim", "hash6", "producers", "dbg",
-                                           "carry", "dict_len", "barren_chain", "deep_from", "far4", "far5")]
+                                           "carry", "dict_len", "barren_chain", "far4", "far5")]
 
 
 def matches(L, data, chain=4, nice=128, good=16):
@@ -26,7 +26,7 @@ def matches(L, data, chain=4, nice=128, good=16):
     ln = np.array([n], dtype=np.uint32)
     stride = (n + 63) & ~63
     m = np.zeros(stride + 64, dtype=np.uint32)
-    prm = LzParams(chain, nice, good, 32768, 64, 1, 2 if chain <= 8 else 1, 0, 0, 0, 1, 9, 32768, 32768)
+    prm = LzParams(chain, nice, good, 32768, 64, 1, 2 if chain <= 8 else 1, 0, 0, 0, 1, 32768, 32768)
     L.zmi_launch_lz77.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint64, LzParams, C.c_void_p]
     rc = L.zmi_launch_lz77(buf.ctypes.data, off.ctypes.data, ln.ctypes.data, 0, 1, m.ctypes.data, stride, prm, None)
     assert rc == 0

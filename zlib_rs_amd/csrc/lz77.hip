@@ -22,10 +22,9 @@
 //   * The other waves are SEARCHERS.  A searcher claims 64 consecutive positions (one per lane) from a shared
 //     LDS counter and walks the chains as a tight per-lane loop.  Every chain step issues ONE round of LDS reads
 //     (prev link of the candidate + its first 16 window bytes as five aligned dwords), so it costs one LDS
-//     latency.  A candidate equal in all 16 bytes is extended 16 bytes per round: at the deep levels (8, 9) inside the walk,
-//     which goes on behind it; at the short budgets (levels 1-7) such a candidate ENDS the walk and is extended after it by
+//     latency.  A candidate equal in all 16 bytes ENDS the walk and is extended after it, 16 bytes per round, by
 //     the wave together -- one comparing lane per run of neighbouring positions with the same distance, the others take the
-//     leader's length minus their offset (round 4).
+//     leader's length minus their offset (round 4; round 5: at every level).
 //     A claim is a bounded amount of work (<= max_chain steps), so a slow wave delays the ring by far less than
 //     its slack; claims are dynamic, so no wave waits for another (the first version had a barrier per 1 KiB
 //     tile and spent 61 % of its wave-cycles waiting).
@@ -245,7 +244,7 @@ static __device__ __forceinline__ void lz_build_tile(const uint8_t* win, uint16_
     else lz_build_tile_t<H6, false>(win, prev, head, head4, c4, tile, n, max_dist, ctl, producers);
 }
 
-template <bool H6, bool DEEP>
+template <bool H6>
 __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restrict__ data, const uint64_t* __restrict__ off,
                                                         const uint32_t* __restrict__ len, uint32_t first_shard,
                                                         uint32_t* __restrict__ match, uint64_t match_stride,
@@ -398,7 +397,7 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
         const uint32_t lim = p < prm.max_dist ? p : prm.max_dist;
         uint32_t delta = prev[p & LZ_WMASK];
         delta = delta - 1u < lim ? delta : 0u;
-        uint32_t blen = 3u, bdist = 0u, tail = 0u;
+        uint32_t blen = 3u, bdist = 0u;
         // H6: the most recent 4-byte match (no chain of its own) is looked at first, outside the chain loop and with an
         // 8-byte compare only: what it is for are the 4- and 5-byte matches the 6-byte chain cannot see; a longer match
         // is in the chain as well.  (Peeling a full-size step out of the loop was slower -- lanes without a probe idle
@@ -422,21 +421,19 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
         const bool barren = H6 && __ballot(blen >= 4u) == 0ull;
         uint32_t chain = H6 ? (prm.max_chain > 1u ? prm.max_chain - 1u : prm.max_chain) : prm.max_chain;
         if (H6 && barren && chain > prm.barren_chain) chain = prm.barren_chain;
-        // a match this long ends the walk: nice_len, the end of the input -- and, for the short budgets, good_len
-        // (the reference quarters the remaining chain there, longest_match.rs:60-66: of a budget of 3 nothing is left)
-        constexpr bool deep = DEEP;   // prm.max_chain > 8 (the launcher picks the instantiation): the short budgets never halve
-                                      // their chain, and the three instructions of that bookkeeping leave their loop
+        // a match this long ends the walk: nice_len, the end of the input, good_len (the reference quarters the remaining chain
+        // there, longest_match.rs:60-66: of these budgets nothing is left) -- and at most 16: the walk ends at the first candidate
+        // equal in all 16 bytes it looks at, how long that match really is the wave finds out afterwards (below).
+        // (Until round 5 a second instantiation for the budgets above 8 went on behind such a match and extended it inside the loop:
+        // 22 ms per candidate against 7, and with the cost parse no level's choice -- profiles/r05_level9_budget_sweep.txt.)
         uint32_t stoplen = prm.nice_len < maxlen ? prm.nice_len : maxlen;
-        if (!deep && prm.good_len < stoplen) stoplen = prm.good_len;
-        if (!deep && stoplen > 16u) stoplen = 16u;   // (the launcher keeps good_len <= 16 for the short budgets anyway)
-        const uint32_t goodlen = deep ? prm.good_len : 259u;
+        if (prm.good_len < stoplen) stoplen = prm.good_len;
+        if (stoplen > 16u) stoplen = 16u;
         if (maxlen >= 4u && delta != 0u && chain != 0u && prm.max_chain != 0u) {
             uint32_t cand = p - delta;
-            // The loop body is straight-line for the common case: a candidate is decided by its first 16 bytes (five aligned
-            // dwords, one LDS round trip together with the prev link).  Everything that concerns matches of 16+ bytes -- the
-            // check of the 4 bytes ending at the best length, the divergent extension loop, the new tail -- sits behind ONE
-            // branch that the wave rarely takes (an 8-byte threshold made 2/3 of the steps on text execute it for some lane;
-            // as three separate conditions it cost every step a dozen mask instructions).
+            // The loop body is straight-line: a candidate is decided by its first 16 bytes (five aligned dwords, one LDS round trip
+            // together with the prev link); a candidate equal in all 16 ends the walk (stoplen <= 16), so nothing in here concerns
+            // matches of 16+ bytes.
             for (;;) {
                 const uint32_t r = cand & LZ_WMASK;
                 const uint32_t* w = (const uint32_t*)(win + (r & ~3u));
@@ -453,29 +450,7 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                 m3 = m3 < c2 ? m3 : c2;
                 m3 = m3 < c3 ? m3 : c3;
                 uint32_t l = m3 >> 3;        // 0..15, or 0x1FFFFFFF when all 16 bytes are equal
-                if (deep && m3 >= 128u) {
-                    // rare: all 16 bytes equal.  With a best match of 16+ already, the 4 bytes ending at the best length
-                    // decide first whether this candidate can be longer at all.
-                    l = 16u;
-                    if (blen >= 16u && lz_ring32(win, cand + blen - 3u) != tail) l = 0u;
-                    else if (maxlen > 16u) {
-                        // extend 16 bytes per round
-                        for (;;) {
-                            uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
-                            lz_ring128(win, p + l, a0, a1, a2, a3);
-                            lz_ring128(win, cand + l, b0, b1, b2, b3);
-                            uint32_t m = lz_match8(a0 ^ b0, a1 ^ b1);
-                            if (m == 8u) m += lz_match8(a2 ^ b2, a3 ^ b3);
-                            l += m;
-                            if (m < 16u || l >= maxlen) break;
-                        }
-                    }
-                    const uint32_t lc = l > maxlen ? maxlen : l;
-                    if (lc > blen && lc >= 16u) tail = lz_ring32(win, p + lc - 3u);
-                }
-                // (the short budgets stop at the first candidate equal in 16 bytes -- stoplen <= 16 -- and find out how long it really
-                // is after the walk, see below: their loop has no branch at all)
-                if (!deep) l = l > 16u ? 16u : l;
+                l = l > 16u ? 16u : l;
                 l = l > maxlen ? maxlen : l;
                 // (a candidate that differs inside its first 16 bytes cannot beat a best match of 16+: nothing to do)
                 const bool better = l > blen;
@@ -484,10 +459,8 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                 const uint32_t dist = p - cand;
                 blen = better ? l : blen;
                 bdist = better ? dist : bdist;
-                // deep walks: a good match halves the remaining budget (goodlen = 259 for the short budgets: never)
-                if (deep) chain >>= (uint32_t)(better & (l >= goodlen));
                 cand -= dn;
-                chain -= 1u;   // may wrap below zero after the halving: compared as signed
+                chain -= 1u;
                 // ... and at the end of the chain (dn = 0: dn - 1 wraps to the largest value) or where the raw link leads out of the
                 // window, in front of the shard or nowhere (dist + dn > lim; dist <= lim holds on entry and after every step): one
                 // compare for both.  (Bitwise, not short-circuit: as `||` the compiler built a branch per term.)
@@ -495,8 +468,8 @@ __global__ void __launch_bounds__(1024) zmi_lz77_kernel_t(const uint8_t* __restr
                 if (stop) break;
             }
         }
-        if (!deep) {
-            // The short budgets' walk ended at the first candidate equal in 16 bytes; its real length is found here, the wave
+        {
+            // The walk ended at the first candidate equal in 16 bytes; its real length is found here, the wave
             // together: NEIGHBOURING positions mostly hold the same match one byte further on -- the same distance, one byte
             // shorter -- so of a run of lanes with one distance only the lowest (the leader) compares bytes, and lane leader + k
             // takes the leader's length - k (exact: both stop at the same mismatching byte).  A leader that ran into its cap
@@ -566,11 +539,9 @@ extern "C" int zmi_launch_lz77(const uint8_t* d_data, const uint64_t* d_off, con
 #else
     const uint32_t LZ_DYN = 0u;
 #endif
-    const bool deep = prm.deep_from != 0u && prm.max_chain >= prm.deep_from;
-#define LZ_GO(H, D) ZMI_LAUNCH((zmi_lz77_kernel_t<H, D>), dim3(n_shards), dim3(1024), LZ_DYN, stream, d_data, d_off, d_len, first_shard, \
-                               d_match, match_stride, prm)
-    if (prm.hash6) { if (deep) LZ_GO(true, true); else LZ_GO(true, false); }
-    else { if (deep) LZ_GO(false, true); else LZ_GO(false, false); }
+#define LZ_GO(H) ZMI_LAUNCH((zmi_lz77_kernel_t<H>), dim3(n_shards), dim3(1024), LZ_DYN, stream, d_data, d_off, d_len, first_shard, \
+                            d_match, match_stride, prm)
+    if (prm.hash6) LZ_GO(true); else LZ_GO(false);
 #undef LZ_GO
     return 0;
 }

@@ -284,7 +284,7 @@ static const zmi_level_cfg kLevels[10] = {
     // extends it afterwards) instead of 14 and 22 on the deep one, whose in-loop extension makes a candidate cost 22 ms against 7
     // (per 16 Ki shards).  Measured with the cost parse, 8192 shards (profiles/r05_level9_budget_sweep.txt): deep 22 = 2.325 at
     // 24.8 GiB/s, deep 12 = 2.319 at 35.4, short 16 = 2.319 at 39.5, short 10 = 2.314 at 49.2 (round 4's level 9, lazy parse, deep
-    // 22: 2.315 at 26.0).  The deep instantiation stays reachable for experiments (ZMI_DEEP_FROM under ZMI_TUNING).
+    // 22: 2.315 at 26.0).  The deep instantiation is gone from lz77.hip.
     {10, 258, 16, 128, 2048},    // 8
     {16, 258, 16, 258, 2048},    // 9
 };
@@ -496,8 +496,6 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     if (const char* pv = zmi_tune("ZMI_PRODUCERS")) lp.producers = (uint32_t)atoi(pv);
     lp.dbg = 0u;
     if (const char* dv = zmi_tune("ZMI_LZ_DBG")) lp.dbg = (uint32_t)atoi(dv);
-    lp.deep_from = 0xFFFFFFFFu;   // (no level uses the deep instantiation any more: see kLevels)
-    if (const char* dv = zmi_tune("ZMI_DEEP_FROM")) lp.deep_from = (uint32_t)atoi(dv);
     lp.barren_chain = 1u;
     if (const char* bv = zmi_tune("ZMI_BARREN_CHAIN")) lp.barren_chain = (uint32_t)atoi(bv);
     // short far matches are judged by the encoder, block by block, from the codes it just used (enc_far_limits); the

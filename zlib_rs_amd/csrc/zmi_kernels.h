@@ -25,9 +25,6 @@ struct zmi_lz_params {
     uint32_t barren_chain; // chain links walked in a claim whose 64 probes all missed (an incompressible stretch: whatever the 6-byte
                            // chain holds there is mostly a hash collision).  1: with 0 the benchmark mix keeps its ratio but paper-100k.pdf loses 0.2 %
                            // for 0.5 % of the kernel's time (round 4)
-    uint32_t deep_from;  // budgets of this many candidates and more take the deep instantiation of the kernel (the walk goes on behind a
-                         // match of 16+ bytes and extends it inside the loop); below it the walk ends at the first candidate equal in
-                         // 16 bytes and the wave extends it afterwards (lz77.hip)
     uint32_t far4, far5; // a 4- (5-) byte match further back than this costs more bits than its literals: dropped
                          // (classic zlib's TOO_FAR idea; the reference itself only drops matches <= 5 under
                          // Z_FILTERED, zlib-rs/src/deflate/algorithm/slow.rs:69-74)
