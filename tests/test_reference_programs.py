@@ -55,4 +55,5 @@ def test_reference_example_c_and_zpipe_c_on_the_emulator(tmp_path):
 def test_reference_example_c_and_zpipe_c_on_gpu(tmp_path):
     import oracle_lib
     o = oracle_lib.load(rebuild=False)
-    _run_programs("zmi", tmp_path, o.gen_shard(0, 3 << 20) + o.gen_shard(5, 1 << 20))
+    # 11 MiB through zpipe.c's 16 KiB deflate(Z_NO_FLUSH) calls: the stream emits twice on the way (every 4 MiB) and once at Z_FINISH
+    _run_programs("zmi", tmp_path, o.gen_shard(0, 3 << 20) + o.gen_shard(5, 1 << 20) + o.gen_shard(3, 4 << 20) + o.gen_shard(6, 3 << 20))
