@@ -1,6 +1,7 @@
 """CPU tests of the HIP kernels themselves, compiled by g++ against the SIMT emulator
 (tests/emu/, -DZMI_EMU).  Small inputs only (the emulator runs ~1 us per fiber switch); the same
 kernels are tested at full size on the MI355X by test_gpu_parity.py."""
+import ctypes as C
 import json
 import os
 import zlib
@@ -496,3 +497,24 @@ def test_cost_parse_against_the_lazy_rule(eng, o, monkeypatch):
         assert sizes["1", lvl][0] < sizes["0", lvl][0] and sizes["1", lvl][1] < sizes["0", lvl][1], (lvl, sizes)
         for a, b in zip(sizes["1", lvl], sizes["0", lvl]):
             assert a <= b * 1.02 + 8, (lvl, sizes)
+
+
+def test_cost_parse_distance_slot_covers_every_distance(eng):
+    """parse.hip prices a distance through par_dq(): exponent and top mantissa bit of float(2 (dist - 1) + 1).  Every distance 1 ... 32768,
+    under every value of the length bits next to it in the match word, must land in the slot of its RFC 1951 distance code."""
+    lib = eng.lib
+    for f in (lib.zmi_emu_par_dq, lib.zmi_emu_par_slot_of_code, lib.zmi_emu_par_dist_code):
+        f.restype = C.c_uint32
+        f.argtypes = [C.c_uint32]
+    base = [1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577]
+    def code(dist):
+        c = 0
+        while c + 1 < 30 and base[c + 1] <= dist:
+            c += 1
+        return c
+    for dist in range(1, 32769):
+        want = code(dist)
+        assert lib.zmi_emu_par_dist_code(dist) == want
+        for length in (0, 3, 255, 258, 511):
+            word = 0x41 | (length << 8) | ((dist - 1) << 17)
+            assert lib.zmi_emu_par_dq(word) == lib.zmi_emu_par_slot_of_code(want), (dist, length)

@@ -982,7 +982,9 @@ __global__ void __launch_bounds__(64) ENC_OCC zmi_encode_kernel_t(const uint8_t*
                     uint32_t tk = step > 1u ? ((mw & ~(0x1FFu << 8)) | (step << 8)) : (mw & 0xFFu);
                     tokbuf[tok0 + ntok + zmi_mbcnt(mask)] = tk;
                     // (one count for every token, a second one for the matches: as if / else the literal and the length count were
-                    // two divergent regions)
+                    // two divergent regions.  Counting in a pass of its own over the stored tokens -- 64 lanes, 64 tokens, symbols
+                    // worked out once for the emission too -- took these sixty instructions out of the walk and was 5 % SLOWER:
+                    // they ride in the shadow of the walk's shuffles, profiles/r05_parse_tables.txt)
                     const bool mt = step > 1u;
                     atomicAdd(&S->lfreq2[mt ? 257u + enc_len_idx(step) : (mw & 0xFFu)], 1u);
                     if (mt) atomicAdd(&S->dfreq2[enc_dist_idx((mw >> 17) + 1u)], 1u);

@@ -36,8 +36,11 @@
 // Bound: the LDS pipe first (gathers at random addresses: a gathered dword per chain step costs what a dozen VALU instructions
 // cost; the producers' pace alone is 85 of the kernel's 115 ms at level 6), instruction issue second -- not HBM and not LDS
 // latency (DESIGN.md sections 3.0 / 3.0a, profiles/r04_deflate_experiments.txt; two claims per wave in one loop -- more loads
-// in flight -- made it slower).  HBM traffic is 1 B read + 4 B scratch written per input byte (measured: exactly that,
-// profiles/r04_traffic.json).
+// in flight -- made it slower).  Round 5 counters: VALU instructions take 83 % of all SIMD cycles (3.4 per byte: ~50 per 64 positions
+// in the producers, ~50 claim set-up and probe, 34 per chain step at 1.9 steps per position); fetching a candidate's five dwords
+// only after ONE byte of it agreed (67 % of the candidates of text fail that) was slower at budgets 2 and 4 and faster at 16 --
+// a second dependent round trip costs more than the dwords saved (profiles/r05_parse_tables.txt).  HBM traffic is 1 B read +
+// 4 B scratch written per input byte (measured: exactly that, profiles/r05_traffic.json).
 #include "zmi_device.h"
 #include "zmi_kernels.h"
 

@@ -319,6 +319,12 @@ __global__ void __launch_bounds__(64) zmi_parse_kernel(const uint32_t* __restric
     }
 }
 
+#ifdef ZMI_EMU
+// test hook (CPU build only): the slot par_dq() gives the distance in a match word, and the slot its distance code's price is kept in
+extern "C" uint32_t zmi_emu_par_dq(uint32_t word) { return par_dq(word); }
+extern "C" uint32_t zmi_emu_par_slot_of_code(uint32_t code) { return code ? code : 30u; }
+extern "C" uint32_t zmi_emu_par_dist_code(uint32_t dist) { return par_dist_idx(dist); }
+#endif
 extern "C" int zmi_launch_parse(const uint32_t* d_len, uint32_t first_shard, uint32_t n_shards, uint32_t max_len, const uint32_t* d_match,
                                 uint64_t match_stride, uint32_t* d_dec, uint64_t dec_stride, uint32_t pieces, uint32_t strategy,
                                 uint32_t span_chunks, hipStream_t stream) {
