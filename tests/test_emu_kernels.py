@@ -515,6 +515,8 @@ def test_cost_parse_distance_slot_covers_every_distance(eng):
     for dist in range(1, 32769):
         want = code(dist)
         assert lib.zmi_emu_par_dist_code(dist) == want
-        for length in (0, 3, 255, 258, 511):
+        slot = want if want else 30   # (zmi_emu_par_slot_of_code, checked below for every code)
+        for length in ((0, 3, 255, 258, 511) if dist < 600 or dist % 251 == 0 else (0, 511)):   # (the length's top bit sits next to the distance)
             word = 0x41 | (length << 8) | ((dist - 1) << 17)
-            assert lib.zmi_emu_par_dq(word) == lib.zmi_emu_par_slot_of_code(want), (dist, length)
+            assert lib.zmi_emu_par_dq(word) == slot, (dist, length)
+    assert [lib.zmi_emu_par_slot_of_code(c) for c in range(30)] == [30] + list(range(1, 30))
