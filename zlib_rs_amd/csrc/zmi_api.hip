@@ -517,12 +517,14 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     if (const char* hb = zmi_tune("ZMI_SPLIT_HDR")) ep.split_hdr_bits = (uint32_t)atoi(hb);
     if (const char* bt = zmi_tune("ZMI_BLOCK_TOKENS")) ep.block_tokens = (uint32_t)atoi(bt) >= 64u ? (uint32_t)atoi(bt) : 64u;
     // a launch of a few shards -- the 64 KiB segments of one deflate() call, a compress2() -- would be a few dozen encoder waves of
-    // 0.7 ... 1.8 ms each on 256 CUs (profiles/r05_stream_deflate_trace.txt): pieces of 16 KiB there, four waves per segment
-    // (a marker and a fresh block per 16 KiB: ~1 % of ratio, only where the chip would otherwise stand empty)
+    // 0.7 ... 1.8 ms each on 256 CUs (profiles/r05_stream_deflate_trace.txt): pieces of 8 KiB there, eight waves per segment
+    // (a marker and a fresh block per 8 KiB, only where the chip would otherwise stand empty: the 15 MiB stream of
+    // tools/gpu_stream_deflate_probe.py 2.3362 with 16 KiB pieces -- 0.2 ... 0.5 ms of encoder per 4 MiB call --, 2.3304 with 8 KiB,
+    // 2.3076 with 4 KiB)
     // (only for the segments of ONE stream -- chain mode: what a batch of independent shards compresses to does not depend on how
     // many of them a launch holds, tests/test_gpu_parity.py::test_host_batch_pipeline_on_gpu)
     const bool small_launch = chain_mode != 0u && (uint64_t)n * ((max_len + 65535u) / 65536u) < 512u;
-    if (small_launch) ep.block_span = 16384u;
+    if (small_launch) ep.block_span = 8192u;
     const char* span_env = zmi_tune("ZMI_BLOCK_SPAN");
     if (span_env && atoi(span_env) >= 64) ep.block_span = (uint32_t)atoi(span_env);
 
