@@ -13,8 +13,9 @@
  *   deflate()  consumes and buffers input; compressed data is produced when the caller flushes or finishes, and under
  *              Z_NO_FLUSH whenever 4 MiB have come in (the reference emits whenever its pending buffer fills,
  *              deflate.rs:2805-2826): a caller sees output as it goes and a stream holds a few MiB, not its input.
- *              The input is compressed in 64 KiB segments side by side -- one match-search workgroup and one
- *              encoder wave each, so a 4 MiB call is 64 workgroups on the chip -- that start byte aligned (the
+ *              The input is compressed in 64 KiB segments (32 KiB when a call brings less than 8 MiB) side by side --
+ *              one match-search workgroup and a few encoder waves each, so a 4 MiB call is 128 workgroups on the
+ *              chip -- that start byte aligned (the
  *              empty stored block of Z_SYNC_FLUSH, zlib-rs/src/deflate.rs:2733-2738) and keep the window: a
  *              segment matches into the 27 KiB in front of it, like a preset dictionary (deflate.rs:499-564).
  *              Across separate deflate() calls the last 32 KiB of input stay the window; only Z_FULL_FLUSH

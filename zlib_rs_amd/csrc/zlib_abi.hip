@@ -275,14 +275,20 @@ const char* abi_tune(const char* name) {
 // -- with the 1 MiB segments of rounds 1-4 it was 4, and the single-stream path ran at 1 % of the batch rate.  A segment sees the
 // 27 KiB in front of it (window carry-over), the encoder cut its pieces -- with the same marker behind each -- every 64 KiB
 // already, so the stream a caller gets is the same one; ZMI_ABI_SEGMENT (bytes, multiple of 64) overrides for tests
-size_t segment_bytes() {
+// A call that brings less than 8 MiB -- fewer than 128 such workgroups for 256 CUs -- takes 32 KiB segments: the match search of a
+// segment is one workgroup's latency (171 us for 64 KiB, of which hashing the 27 KiB carried over is the fixed part), and the
+// compressed bytes are the same size (4 MiB calls: 4.80 -> 5.20 GiB/s at ratio 2.3281 both; a 15.7 MB call, 240 segments of 64 KiB,
+// would lose 4 % to the doubled carry-over work: tools/gpu_stream_loop_probe.py).
+size_t segment_bytes(size_t call_bytes) {
     static size_t v = 0;
+    static bool fixed = false;
     if (!v) {
         const char* e = abi_tune("ZMI_ABI_SEGMENT");
         long n = e ? atol(e) : 0;
-        v = (n >= 64 && n <= (1 << 28)) ? ((size_t)n & ~(size_t)63) : ((size_t)64 << 10);
+        fixed = n >= 64 && n <= (1 << 28);
+        v = fixed ? ((size_t)n & ~(size_t)63) : ((size_t)64 << 10);
     }
-    return v;
+    return (!fixed && call_bytes < ((size_t)8 << 20)) ? v / 2 : v;
 }
 // deflate(Z_NO_FLUSH) compresses what is buffered once this much has come in (the reference emits whenever its pending buffer
 // fills, zlib-rs/src/deflate.rs:2805-2826 flush_pending): a zpipe.c-style caller sees output as it goes and the stream holds a
@@ -313,7 +319,7 @@ int gpu_deflate_segments(const uint8_t* in, size_t n, const uint8_t* hist, size_
     zmi_ctx* c = lease.ctx;
     hipStream_t hs = lease.stream;
     if (!c) return Z_MEM_ERROR;
-    const size_t kSegment = segment_bytes();
+    const size_t kSegment = segment_bytes(n);
     const uint32_t nseg = (uint32_t)((n + kSegment - 1) / kSegment);
     std::vector<uint64_t> off(nseg);
     std::vector<uint32_t> len(nseg);
