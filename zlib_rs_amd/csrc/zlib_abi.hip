@@ -796,9 +796,26 @@ void find_flush_points(const uint8_t* in, size_t n, std::vector<uint32_t>& seg) 
     if (seg.size() < 4u) seg.clear();
 }
 
-// Decode what is buffered, from the checkpoint.  Queues every new byte, moves the checkpoint to the last block
-// boundary reached, and changes the mode when the final block ended or the data is invalid.
-int inflate_attempt(InflateState* s, int stop_mode = 0) {   // stop_mode 1: decode one block, 2: only the next block header
+// n decoded bytes (n <= avail_out) go to the caller: the copy, the wrapper's running check, the window inflateGetDictionary shows
+void inf_deliver(z_streamp strm, InflateState* s, const uint8_t* p, size_t n) {
+    memcpy(strm->next_out, p, n);
+    if (s->verify && s->form == 1) s->check = host_adler32(s->check, p, n);
+    else if (s->verify && s->form == 2) s->check = host_crc32(s->check, p, n);
+    if (n >= 32768u) s->window.assign(p + (n - 32768u), p + n);
+    else {
+        s->window.insert(s->window.end(), p, p + n);
+        if (s->window.size() > 32768u) s->window.erase(s->window.begin(), s->window.end() - 32768);
+    }
+    strm->next_out += n;
+    strm->avail_out -= (uInt)n;
+    strm->total_out += n;
+    if (s->form > 0) strm->adler = s->check;
+}
+
+// Decode what is buffered, from the checkpoint.  Every new byte goes to the caller (`strm`, while nothing is queued in front of it
+// and the caller has room: one pass over the bytes instead of two -- a 4 MiB piece of a stream is 9 MiB of output) or into the queue,
+// the checkpoint moves to the last block boundary reached, and the mode changes when the final block ended or the data is invalid.
+int inflate_attempt(InflateState* s, int stop_mode = 0, z_streamp strm = nullptr) {   // stop_mode 1: decode one block, 2: only the next block header
     AbiLease lease;
     zmi_ctx* c = lease.ctx;
     if (!c) return Z_MEM_ERROR;
@@ -857,7 +874,15 @@ int inflate_attempt(InflateState* s, int stop_mode = 0) {   // stop_mode 1: deco
             continue;
         }
         if (eff > s->pend) {
-            s->out.insert(s->out.end(), s->tmp.begin() + s->pend, s->tmp.begin() + eff);
+            const uint8_t* fresh = s->tmp.data() + s->pend;
+            size_t nfresh = eff - s->pend;
+            if (strm && strm->avail_out && s->out_pos >= s->out.size()) {
+                const size_t direct = nfresh < strm->avail_out ? nfresh : strm->avail_out;
+                inf_deliver(strm, s, fresh, direct);
+                fresh += direct;
+                nfresh -= direct;
+            }
+            if (nfresh) s->out.insert(s->out.end(), fresh, fresh + nfresh);
             s->total += eff - s->pend;
         }
         if (st == Z_OK) {   // the final block ended `used` bytes in
@@ -968,7 +993,7 @@ int inflate_run(z_streamp strm, InflateState* s, int stop_mode = 0) {
         case IM_BLOCKS: {
             if (s->in.empty() || s->tried == s->in.size()) return Z_OK;
             if (s->out.size() - s->out_pos > queue_limit()) return Z_OK;
-            const int rc = inflate_attempt(s, stop_mode == 2 && s->hdr_seen ? 1 : stop_mode);
+            const int rc = inflate_attempt(s, stop_mode == 2 && s->hdr_seen ? 1 : stop_mode, strm);
             if (rc != Z_OK) return rc;
             if (s->mode == IM_BLOCKS || s->stop_state) return Z_OK;   // (a stop behind the final block comes before its trailer)
             break;
@@ -1007,20 +1032,8 @@ size_t inflate_drain(z_streamp strm, InflateState* s) {
     size_t n = s->out.size() > s->out_pos ? s->out.size() - s->out_pos : 0;
     if (n > strm->avail_out) n = strm->avail_out;
     if (n) {
-        const uint8_t* p = s->out.data() + s->out_pos;
-        memcpy(strm->next_out, p, n);
-        if (s->verify && s->form == 1) s->check = host_adler32(s->check, p, n);
-        else if (s->verify && s->form == 2) s->check = host_crc32(s->check, p, n);
-        if (n >= 32768u) s->window.assign(p + (n - 32768u), p + n);
-        else {
-            s->window.insert(s->window.end(), p, p + n);
-            if (s->window.size() > 32768u) s->window.erase(s->window.begin(), s->window.end() - 32768);
-        }
+        inf_deliver(strm, s, s->out.data() + s->out_pos, n);
         s->out_pos += n;
-        strm->next_out += n;
-        strm->avail_out -= (uInt)n;
-        strm->total_out += n;
-        if (s->form > 0) strm->adler = s->check;
     }
     if (s->out_pos >= s->out.size()) { s->out.clear(); s->out_pos = 0; }
     else if (s->out_pos > ((size_t)8 << 20)) { s->out.erase(s->out.begin(), s->out.begin() + s->out_pos); s->out_pos = 0; }
