@@ -122,9 +122,9 @@ __global__ void __launch_bounds__(BS_T) zmi_block_scan_kernel(const uint8_t* __r
                                                                uint32_t* __restrict__ pre, uint32_t pre_cap, uint32_t* __restrict__ pre_count) {
     const uint64_t g = (uint64_t)blockIdx.x * BS_T + threadIdx.x;
     const uint64_t p0 = g * 64u;
-    if (p0 >= 8ull * n) return;
+    const bool live = p0 < 8ull * n;   // (no early return: the wave hands its survivors in together, below)
     // 24 bytes behind the thread's first position: 64 positions + 74 header bits
-    const uint32_t b0 = (uint32_t)(p0 >> 3);
+    const uint32_t b0 = live ? (uint32_t)(p0 >> 3) : 0u;
     uint64_t q[3];
 #pragma unroll
     for (uint32_t k = 0; k < 3u; ++k) {
@@ -138,9 +138,10 @@ __global__ void __launch_bounds__(BS_T) zmi_block_scan_kernel(const uint8_t* __r
         }
         q[k] = v;
     }
+    uint64_t mine = 0ull;   // bit i: position p0 + i passed
     for (uint32_t i = 0; i < 64u; ++i) {
         const uint64_t pos = p0 + i;
-        if (pos < first_bit || pos + 17u + 12u > 8ull * n) continue;
+        if (!live || pos < first_bit || pos + 17u + 12u > 8ull * n) continue;
         // 128 bits starting at position i of the 192 loaded
         const uint64_t lo = i ? (q[0] >> i) | (q[1] << (64u - i)) : q[0];
         const uint64_t hi = i ? (q[1] >> i) | (q[2] << (64u - i)) : q[1];
@@ -157,8 +158,23 @@ __global__ void __launch_bounds__(BS_T) zmi_block_scan_kernel(const uint8_t* __r
             kraft += l ? (128u >> l) : 0u;
         }
         if (kraft != 128u) continue;
-        const uint32_t k = atomicAdd(pre_count, 1u);
-        if (k < pre_cap) pre[k] = (uint32_t)pos;
+        mine |= 1ull << i;
+    }
+    // One atomic per WAVE (4096 positions, ~8 survivors), not per survivor: some 100 000 atomic adds on this one word, one after the
+    // other at the L2, were most of what this kernel took (0.56 ms for a 6.6 MB stream).
+    const uint32_t c = (uint32_t)__popcll((unsigned long long)mine);
+    const uint32_t incl = zmi_wave_incl_scan(c);
+    const uint32_t total = zmi_readlane(incl, 63u);
+    if (total == 0u) return;   // (wave-uniform)
+    uint32_t base = 0u;
+    if (zmi_lane() == 0u) base = atomicAdd(pre_count, total);
+    base = zmi_readlane(base, 0u);
+    uint32_t k = base + incl - c;
+    while (mine) {
+        const uint32_t i = (uint32_t)__ffsll((unsigned long long)mine) - 1u;
+        mine &= mine - 1ull;
+        if (k < pre_cap) pre[k] = (uint32_t)(p0 + i);
+        ++k;
     }
 }
 

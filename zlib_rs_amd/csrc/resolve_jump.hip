@@ -127,7 +127,17 @@ __global__ void __launch_bounds__(256) zmi_jump_round_kernel(const uint32_t* __r
             ptr[tid + (uint64_t)it * gridDim.x * 256u] = pp[it];
             changed = changed || (pp[it] >= 0 && (pp[it] & JUMP_DONE) == 0);   // still on its way
         }
-    if (__ballot(changed) != 0ull && zmi_lane() == 0u) atomicOr(&flags[round], 1u);
+    // "this round changed something", one word for the whole launch: raised with a plain store once it has been seen clear (a quarter of
+    // a million waves each doing an atomic OR on this ONE address was what a busy round took its time for: ~0.87 ms of atomics in a
+    // row at the L2 for 15.7 M bytes, three such rounds per uncompress() of bench.py's stream -- profiles/r05_uncompress_trace.txt)
+    if (__ballot(changed) != 0ull && zmi_lane() == 0u) {
+#ifdef ZMI_EMU
+        flags[round] = 1u;
+#else
+        if (__hip_atomic_load(&flags[round], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)
+            __hip_atomic_store(&flags[round], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+    }
 }
 
 __global__ void __launch_bounds__(256) zmi_jump_gather_kernel(uint8_t* out, const uint64_t* __restrict__ out_off,
