@@ -280,15 +280,14 @@ const char* abi_tune(const char* name) {
 // compressed bytes are the same size (4 MiB calls: 4.80 -> 5.20 GiB/s at ratio 2.3281 both; a 15.7 MB call, 240 segments of 64 KiB,
 // would lose 4 % to the doubled carry-over work: tools/gpu_stream_loop_probe.py).
 size_t segment_bytes(size_t call_bytes) {
-    static size_t v = 0;
-    static bool fixed = false;
-    if (!v) {
+    struct Seg { size_t bytes; bool fixed; };
+    static const Seg g = [] {   // (read once, by whichever thread comes first)
         const char* e = abi_tune("ZMI_ABI_SEGMENT");
-        long n = e ? atol(e) : 0;
-        fixed = n >= 64 && n <= (1 << 28);
-        v = fixed ? ((size_t)n & ~(size_t)63) : ((size_t)64 << 10);
-    }
-    return (!fixed && call_bytes < ((size_t)8 << 20)) ? v / 2 : v;
+        const long n = e ? atol(e) : 0;
+        const bool fixed = n >= 64 && n <= (1 << 28);
+        return Seg{fixed ? ((size_t)n & ~(size_t)63) : ((size_t)64 << 10), fixed};
+    }();
+    return (!g.fixed && call_bytes < ((size_t)8 << 20)) ? g.bytes / 2 : g.bytes;
 }
 // deflate(Z_NO_FLUSH) compresses what is buffered once this much has come in (the reference emits whenever its pending buffer
 // fills, zlib-rs/src/deflate.rs:2805-2826 flush_pending): a zpipe.c-style caller sees output as it goes and the stream holds a
