@@ -781,8 +781,8 @@ def stream_abi_leg(level):
             "inflate_of_cpu_made_stream_GiB_s": len(data) / GIB / ti2, "uncompress_of_zlib_stream_GiB_s": len(data) / GIB / tu,
             "system_zlib_inflate_single_thread_GiB_s": len(data) / GIB / tz,
             "oracle_single_thread_GiB_s": len(data) / GIB / to, "oracle_ratio": len(data) / float(len(ocomp)),
-            "note": "one stream: deflate = segments of 64 KiB on the device, a launch per 4 MiB chunk handed in; inflate of a stream with flush points (this library's own: "
-                    "a marker every 64 KiB of input) = the pieces between the markers decoded side by side and stitched (zmi_inflate_split); "
+            "note": "one stream: deflate = segments of 32 KiB (64 KiB in a call of 8 MiB and more) on the device, encoder pieces of 8 KiB, a launch per 4 MiB chunk handed in; "
+                    "inflate of a stream with flush points (this library's own: a marker behind every piece) = the pieces between the markers decoded side by side and stitched (zmi_inflate_split); "
                     "a stream without them (the CPU's) = one workgroup of 16 waves, a pass covers at most one deflate block"}
 
 
