@@ -27,7 +27,8 @@ def timing(e):
 
 
 def main():
-    e = Engine(0)
+    sg = os.environ.get("PROBE_SCRATCH_GIB")   # the engine's scratch = one launch group (bench.py: 70 GiB = 16 865 shards)
+    e = Engine(0, scratch_bytes=int(float(sg) * 2**30) if sg else None)
     props = torch.cuda.get_device_properties(0)
     print("device", props.name, "CUs", props.multi_processor_count, "mem GiB", props.total_memory / 2**30)
     B = 1 << 20
@@ -44,7 +45,7 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t
             sums, cnts = timing(e)
-            ratio = S * B / float(olen.to(torch.int64).sum().item())
+            ratio = S * B / max(1.0, float(olen.to(torch.int64).sum().item()))
             print("deflate S=%d L%d: %.2f GiB/s wall  ratio %.3f  ms: checksum %.2f lz77 %.2f parse %.2f encode %.2f" %
                   (S, lvl, S * B / 2**30 / dt, ratio, sums[0], sums[1], sums[5], sums[2]))
             if hasattr(e.L, "zmi_enc_prof_read"):
