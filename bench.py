@@ -94,9 +94,55 @@ def cpu_baseline(shard_bytes, level, budget_s=10.0):
     except Exception:  # noqa: BLE001
         pass
     return {"value": n * shard_bytes / GIB / tall, "unit": "GiB/s", "cores": cores, "kind": "port", "system_zlib": secondary,
+            "zlib_rs": zlib_rs_probe(),
             "sample": "%d x %d B synthetic shards (classes 0-7), oracle zo_deflate level %d, %d POSIX threads, %.1f s"
                       % (n, shard_bytes, level, cores, tall),
             "single_thread_GiB_s": one, "ratio": n * shard_bytes / float(tot.value)}
+
+
+def zlib_rs_probe():
+    """SURVEY 8d's first preference for the CPU baseline is zlib-rs itself (libz-rs-sys-cdylib built offline by cargo on the box that
+    runs the bench).  That needs a Rust toolchain AND the reference's sources; this records what the box has, so that the question
+    is closed with evidence instead of an assumption."""
+    import platform
+    import shutil
+    host = platform.node() or "?"
+    try:
+        cargo, rustc = shutil.which("cargo"), shutil.which("rustc")
+        src = os.environ.get("ZLIB_RS_SRC", "")   # (a checkout of trifectatechfoundation/zlib-rs, if the operator has one on the box)
+        if not cargo or not rustc:
+            return {"cargo": "absent on %s" % host, "rustc": "absent" if not rustc else rustc, "built": False}
+        if not src or not os.path.isfile(os.path.join(src, "libz-rs-sys-cdylib", "Cargo.toml")):
+            return {"cargo": cargo, "rustc": rustc, "built": False,
+                    "why": "no zlib-rs sources on %s (set ZLIB_RS_SRC to a checkout; the bench never reads /root/reference)" % host}
+        import subprocess
+        import tempfile
+        tgt = tempfile.mkdtemp(prefix="zlib_rs_target_")
+        r = subprocess.run([cargo, "build", "--release", "--offline", "--manifest-path", os.path.join(src, "libz-rs-sys-cdylib", "Cargo.toml"),
+                            "--target-dir", tgt], capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            return {"cargo": cargo, "built": False, "why": r.stderr[-400:]}
+        so = [os.path.join(dp, f) for dp, _, fs in os.walk(tgt) for f in fs if f.startswith("libz_rs") and f.endswith(".so")]
+        if not so:
+            return {"cargo": cargo, "built": False, "why": "no shared library in the target directory"}
+        L = C.CDLL(so[0])
+        o = _oracle()
+        shards = [o.gen_shard(i, 1 << 20) for i in range(8)]
+        L.compressBound.restype = C.c_ulong
+        L.compressBound.argtypes = [C.c_ulong]
+        cap = int(L.compressBound(1 << 20))
+        dst = C.create_string_buffer(cap)
+        t0 = time.perf_counter()
+        csz = 0
+        for d in shards:
+            dl = C.c_ulong(cap)
+            assert L.compress2(dst, C.byref(dl), d, C.c_ulong(len(d)), 6) == 0
+            csz += dl.value
+        dt = time.perf_counter() - t0
+        return {"cargo": cargo, "built": True, "library": so[0], "single_thread_GiB_s": 8 * (1 << 20) / GIB / dt, "ratio": 8 * (1 << 20) / float(csz),
+                "sample": "8 x 1 MiB (classes 0-7), compress2(level 6), one thread"}
+    except Exception as ex:  # noqa: BLE001
+        return {"cargo": "probe failed on %s" % host, "why": repr(ex), "built": False}
 
 
 def oracle_members(n, shard_bytes, level, wrap, threads):
@@ -509,17 +555,19 @@ def main():
                                        "oracle_ratio_same_shards": ns * B / float(tot.value), "gpu_ratio_same_shards": ns * B / float(gsz),
                                        "oracle_GiB_s": ns * B / GIB / ts, "oracle_sample": "%d shards, %d threads" % (ns, min(cores, ns)),
                                        "check": "%d streams inflated on device, bit-exact" % vs}
-        # the levels in between (the reference's own sweep is 0 .. 9, zlib_benchmarks.json blogpost-compress): 1024 shards each, one
-        # timed launch, device round trip of every stream; no oracle figures (levels 1 / 6 / 9 have them)
+        # the levels in between (the reference's own sweep is 0 .. 9, zlib_benchmarks.json blogpost-compress): the same launch size as
+        # levels 1 and 9 (until round 5: 1024 shards, not comparable), one timed launch behind a warm-up of 1024 shards, device round
+        # trip of the streams; no oracle figures (levels 1 / 6 / 9 have them)
         for lvl in (2, 3, 4, 5, 7, 8):
-            wn = min(1024, SW)
-            for rep in range(2):   # (the first call warms the level's kernels up)
-                torch.cuda.synchronize()
-                timing(rep == 1)
-                ti = time.perf_counter()
-                e.deflate_batch(data, off[:wn].contiguous(), ln[:wn].contiguous(), B, level=lvl, wrap=WRAP_ZLIB, out=out2, out_len=olen, status=st)
-                torch.cuda.synchronize()
-                dt = time.perf_counter() - ti
+            wn = SW
+            e.deflate_batch(data, off[:min(1024, SW)].contiguous(), ln[:min(1024, SW)].contiguous(), B, level=lvl, wrap=WRAP_ZLIB, out=out2,
+                            out_len=olen, status=st)
+            torch.cuda.synchronize()
+            timing(True)
+            ti = time.perf_counter()
+            e.deflate_batch(data, off[:wn].contiguous(), ln[:wn].contiguous(), B, level=lvl, wrap=WRAP_ZLIB, out=out2, out_len=olen, status=st)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - ti
             lsums, lcnts = take_timing()
             timing(False)
             assert int((st[:wn] != 0).sum().item()) == 0
@@ -531,7 +579,7 @@ def main():
             assert int((bst[:vs] != 0).sum().item()) == 0 and torch.equal(back[:vs * B], data[:vs * B]), "level %d round trip failed" % lvl
             levels_obj["L%d" % lvl] = {"value": wn * B / GIB / dt, "unit": "GiB/s", "ratio": wn * B / float(csz), "shards": wn,
                                        "kernel_ms": {"lz77": lsums[1], "parse": lsums[5], "encode": lsums[2]},
-                                       "note": "one launch of %d shards (a launch of 16 384 runs ~1.2x faster)" % wn,
+                                       "note": "one launch of %d shards" % wn,
                                        "check": "%d streams inflated on device, bit-exact" % vs}
         del out2
         # ---- PCIe inclusive: host buffers in, host buffers out (zmi_deflate_batch, pipelined copies) ----
@@ -543,15 +591,17 @@ def main():
             h_out = np.empty(P * stride, dtype=np.uint8)
             h_olen = np.zeros(P, dtype=np.uint32)
             h_st = np.zeros(P, dtype=np.int32)
-            best = None
-            for _ in range(2):
+            def run_hdeflate():
                 ti = time.perf_counter()
                 rc = e.L.zmi_deflate_batch(e._ctx, h_in.ctypes.data, h_off.ctypes.data, h_len.ctypes.data, P, args.level, 0, 1,
                                            h_out.ctypes.data, stride, h_olen.ctypes.data, h_st.ctypes.data)
                 dt = time.perf_counter() - ti
                 assert rc == 0 and not h_st.any()
-                best = dt if best is None else min(best, dt)
-            pcie_obj = {"value": P * B / GIB / best, "unit": "GiB/s", "shards": P,
+                return dt, None
+            run_hdeflate()   # (staging buffers of this size)
+            best, best_sp, _ = _median_of(run_hdeflate)
+            pcie_obj = {"value": P * B / GIB / best, "unit": "GiB/s", "shards": P, "timing": "median of 5 calls", "spread": _rate(P * B, best, best_sp),
+                        "link": pcie_link_probe(torch, dev),
                         "path": "zmi_deflate_batch: pageable host memory -> pinned staging -> H2D -> kernels -> slab written to pinned host "
                                 "memory by the pack kernel -> scattered to the caller's slots; chunks pipelined over three slots",
                         "ratio": P * B / float(h_olen.astype(np.int64).sum())}
@@ -561,20 +611,22 @@ def main():
             o_cap = np.full(P, B, dtype=np.uint32)
             b_len = np.zeros(P, dtype=np.uint32)
             b_st = np.zeros(P, dtype=np.int32)
-            ibest = None
-            for _ in range(2):
+            def run_hinflate():
                 ti = time.perf_counter()
                 rc = e.L.zmi_inflate_batch(e._ctx, h_out.ctypes.data, c_off.ctypes.data, h_olen.ctypes.data, P, 1, h_back.ctypes.data,
                                            h_off.ctypes.data, o_cap.ctypes.data, b_len.ctypes.data, b_st.ctypes.data)
                 dt = time.perf_counter() - ti
                 assert rc == 0 and not b_st.any()
-                ibest = dt if ibest is None else min(ibest, dt)
+                return dt, None
+            run_hinflate()
+            ibest, ibest_sp, _ = _median_of(run_hinflate)
             assert np.array_equal(h_back, h_in), "host-buffer round trip differs"
             pcie_obj["inflate_GiB_s"] = P * B / GIB / ibest
+            pcie_obj["inflate_spread"] = _rate(P * B, ibest, ibest_sp)
             pcie_obj["inflate_path"] = ("zmi_inflate_batch: pageable host memory -> pinned staging -> H2D -> kernels -> the chunk's output region to "
                                         "pinned host memory (one DMA copy enqueued ahead when the chunks before it filled their capacity -- the "
-                                        "second of the two timed calls --, decoded bytes range by range through the pack kernel otherwise) -> "
-                                        "scattered to the caller's regions; best of two calls")
+                                        "calls after the first --, decoded bytes range by range through the pack kernel otherwise) -> "
+                                        "scattered to the caller's regions; median of 5 calls")
             pcie_obj["round_trip"] = "bit-exact"
             del h_in, h_out, h_back
     del back
@@ -663,6 +715,21 @@ def main():
     e.close()
 
 
+def _median_of(fn, runs=5):
+    """fn() -> (seconds, result): the median of `runs` timed calls with the spread beside it (a 2 ms single shot is
+    noise, and the documentation quoted the top of it) -> (median seconds, {"runs", "min_s", "max_s"}, last result)"""
+    ts, res = [], None
+    for _ in range(runs):
+        dt, res = fn()
+        ts.append(dt)
+    ts.sort()
+    return ts[len(ts) // 2], {"runs": runs, "min_s": ts[0], "max_s": ts[-1]}, res
+
+
+def _rate(nbytes, med, spread):
+    return {"median": nbytes / GIB / med, "min": nbytes / GIB / spread["max_s"], "max": nbytes / GIB / spread["min_s"], "runs": spread["runs"]}
+
+
 def _inflate_loop(H, lib, comp, wbits, expect_len, chunk=1 << 22):
     """the blogpost-uncompress.rs loop with the output written where it belongs (no Python-side copies inside the timed region):
     input in `chunk` pieces, room in `chunk` pieces; returns (seconds, rc, output bytes object)"""
@@ -734,20 +801,21 @@ def stream_abi_leg(level):
     data = b"".join(o.gen_shard(i, 1 << 20) for i in range(15))
     data += o.gen_shard(15, 1 << 20)[:total - len(data)]
     H.deflate_stream(lib, data[:1 << 20], level=level, wbits=31, chunk_in=1 << 20, chunk_out=1 << 20)   # first-use costs
-    td = None
-    for _ in range(2):
+    def run_deflate():
         dt, comp = _deflate_loop(H, lib, data, level, 31)
-        td = dt if td is None else min(td, dt)
-    td1 = None
-    for _ in range(2):   # the reference's driver itself: the whole input and Z_FINISH in one deflate() (blogpost-compress.rs:89-113)
-        dt, comp1 = _deflate_loop(H, lib, data, level, 31, chunk=len(data))
-        td1 = dt if td1 is None else min(td1, dt)
+        return dt, comp
+    td, td_sp, comp = _median_of(run_deflate)
+    def run_deflate_one():   # the reference's driver itself: the whole input and Z_FINISH in one deflate() (blogpost-compress.rs:89-113)
+        dt, c1 = _deflate_loop(H, lib, data, level, 31, chunk=len(data))
+        return dt, c1
+    td1, td1_sp, comp1 = _median_of(run_deflate_one)
     assert o.inflate(comp1, len(data), 2)[1] == data
-    ti = None
-    for _ in range(2):   # (the first pass pays for the staging buffers of this size)
+    def run_inflate_own():
         dt, rc, back, unused = _inflate_loop(H, lib, comp, 31, len(data))
-        ti = dt if ti is None else min(ti, dt)
         assert rc == 1 and back == data and unused == 0, "stream ABI round trip failed"
+        return dt, None
+    _inflate_loop(H, lib, comp, 31, len(data))   # (the first pass pays for the staging buffers of this size)
+    ti, ti_sp, _ = _median_of(run_inflate_own)
     rc, ocomp = o.deflate(data[:4 << 20], level, 2)
     t0 = time.perf_counter()
     rc, ocomp = o.deflate(data, level, 2)
@@ -755,31 +823,42 @@ def stream_abi_leg(level):
     assert o.inflate(comp, len(data), 2)[1] == data          # the oracle reads the GPU's stream
     # the same bytes as a stream of the CPU oracle (the reference's algorithm: blocks of 16 383 symbols, no flush points --
     # what an unmodified caller's inflate() meets most often), through inflate() and through one uncompress2()-style call
-    ti2 = None
-    for _ in range(2):
+    def run_inflate_cpu_made():
         dt, rc2, back2, unused2 = _inflate_loop(H, lib, ocomp, 31, len(data))
-        ti2 = dt if ti2 is None else min(ti2, dt)
         assert rc2 == 1 and back2 == data and unused2 == 0, "stream ABI inflate of the oracle's stream failed"
+        return dt, None
+    _inflate_loop(H, lib, ocomp, 31, len(data))
+    ti2, ti2_sp, _ = _median_of(run_inflate_cpu_made)
     import zlib
     zc = zlib.compress(data, level)
     dst = C.create_string_buffer(len(data))
     dl = C.c_ulong(len(data))
     lib.uncompress(dst, C.byref(dl), zc, len(zc))
-    dl = C.c_ulong(len(data))
-    t0 = time.perf_counter()
-    rc3 = lib.uncompress(dst, C.byref(dl), zc, len(zc))
-    tu = time.perf_counter() - t0
-    assert rc3 == 0 and dl.value == len(data) and dst.raw[:len(data)] == data
-    t0 = time.perf_counter()
-    zlib.decompress(zc)
-    tz = time.perf_counter() - t0
+    def run_uncompress():
+        dl = C.c_ulong(len(data))
+        t0 = time.perf_counter()
+        rc3 = lib.uncompress(dst, C.byref(dl), zc, len(zc))
+        dt = time.perf_counter() - t0
+        assert rc3 == 0 and dl.value == len(data)
+        return dt, None
+    tu, tu_sp, _ = _median_of(run_uncompress)
+    assert dst.raw[:len(data)] == data
+    def run_syszlib():
+        t0 = time.perf_counter()
+        zlib.decompress(zc)
+        return time.perf_counter() - t0, None
+    tz, tz_sp, _ = _median_of(run_syszlib, 3)
     sweep = chunk_sweep_leg(ocomp, len(data), _build.ABI_LIB)
     return {"input_bytes": len(data), "path": "deflateInit2_(level, gzip) + deflate() in 4 MiB chunks + inflate() back, one thread, host buffers",
             "chunk_sweep": sweep,
+            "timing": "every rate of this object is the median of 5 runs (system zlib: 3); the spread of the runs is under `spread`",
             "deflate_GiB_s": len(data) / GIB / td, "deflate_one_call_GiB_s": len(data) / GIB / td1, "ratio_one_call": len(data) / float(len(comp1)),
             "inflate_GiB_s": len(data) / GIB / ti, "ratio": len(data) / float(len(comp)),
             "inflate_of_cpu_made_stream_GiB_s": len(data) / GIB / ti2, "uncompress_of_zlib_stream_GiB_s": len(data) / GIB / tu,
             "system_zlib_inflate_single_thread_GiB_s": len(data) / GIB / tz,
+            "spread": {"deflate": _rate(len(data), td, td_sp), "deflate_one_call": _rate(len(data), td1, td1_sp),
+                       "inflate": _rate(len(data), ti, ti_sp), "inflate_of_cpu_made_stream": _rate(len(data), ti2, ti2_sp),
+                       "uncompress_of_zlib_stream": _rate(len(data), tu, tu_sp), "system_zlib_inflate": _rate(len(data), tz, tz_sp)},
             "oracle_single_thread_GiB_s": len(data) / GIB / to, "oracle_ratio": len(data) / float(len(ocomp)),
             "note": "one stream: deflate = segments of 32 KiB (64 KiB in a call of 8 MiB and more) on the device, encoder pieces of 8 KiB, a launch per 4 MiB chunk handed in; "
                     "inflate of a stream with flush points (this library's own: a marker behind every piece) = the pieces between the markers decoded side by side and stitched (zmi_inflate_split); "
@@ -807,6 +886,7 @@ def chunk_sweep_leg(gz_stream, out_len, abi_lib):
             env.pop("ZMI_INFLATE_DEFER", None)
             if defer:
                 env["ZMI_INFLATE_DEFER"] = defer
+                env["ZMI_TUNING"] = "1"   # (the override is honoured only with this set)
             r = subprocess.run([exe, lib, gz, str(out_len), "31"] + [str(c) for c in cs], capture_output=True, text=True, env=env, timeout=1800)
             assert r.returncode == 0, r.stderr
             res[name] = {ln.split()[0]: ln.split() for ln in r.stdout.strip().splitlines()}
@@ -865,6 +945,35 @@ def real_data_leg(e, torch, dev, B):
             g, orc, z = B / float(hl[i]), B / float(len(oc)), B / float(len(zlib.compress(blobs[i], lvl)))
             res.setdefault(name, {})["L%d" % lvl] = {"gpu": round(g, 4), "oracle": round(orc, 4), "system_zlib": round(z, 4), "gpu_over_oracle": round(g / orc, 4)}
     return res
+
+
+def pcie_link_probe(torch, dev, nbytes=1 << 30):
+    """what the link gives on this box (pinned host memory, one 1 GiB copy each way, and both ways at once): the ceiling of the
+    host-buffer legs -- a deflate call moves 1 B in and 1 / ratio B out per input byte"""
+    try:
+        h1 = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        h2 = torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+        d1 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        d2 = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        out = {}
+        for what in ("h2d", "d2h", "both"):
+            for rep in range(2):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                if what in ("h2d", "both"):
+                    with torch.cuda.stream(s1):
+                        d1.copy_(h1, non_blocking=True)
+                if what in ("d2h", "both"):
+                    with torch.cuda.stream(s2):
+                        h2.copy_(d2, non_blocking=True)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            out[what + "_GB_s"] = nbytes / 1e9 / dt
+        out["note"] = "pinned memory, 1 GiB per copy; `both`: each direction's rate while the other runs"
+        return out
+    except Exception as ex:   # (a box without enough pinnable memory: the legs still run)
+        return {"failed": repr(ex)}
 
 
 def memory_plan(torch, world, S, B, stride, scratch_gib, slab_gib, staging_gib):

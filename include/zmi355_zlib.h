@@ -20,6 +20,11 @@
  *              segment matches into the 27 KiB in front of it, like a preset dictionary (deflate.rs:499-564).
  *              Across separate deflate() calls the last 32 KiB of input stay the window; only Z_FULL_FLUSH
  *              forgets them (deflate.rs:2739-2752).
+ *              NOT byte-reproducible across call patterns: where the segments are cut and how large the encoder's pieces are
+ *              follows from how much input a call brings (32 / 64 KiB segments, 8 KiB pieces in a call of less than 512
+ *              segments), so the same input fed in different chunk sizes gives different -- equally valid -- compressed bytes
+ *              (sizes within ~1 % of each other).  The reference is deterministic in its input alone; callers that compare or
+ *              deduplicate compressed bytes must feed the same chunks.  The same calls always give the same bytes.
  *   inflate()  decodes as far as the input it is given allows, so the output of a flushed packet is there when the call
  *              returns.  The caller's input is taken a piece at a time and only while the decoder can use it; what a pause
  *              (much output queued, Z_NEED_DICT) leaves unread is handed back.  The device decodes from a checkpoint -- the
@@ -34,7 +39,7 @@
  *              spot are delivered before Z_DATA_ERROR, as the reference does; header, trailer and deflate-data errors
  *              carry the reference's messages ("invalid stored block lengths", "invalid distance too far back", ...:
  *              the decode kernel reports the cause, inflate.rs State::bad).
- *              ZMI_INFLATE_DEFER=BYTES in the environment (read once, default off) lets inflate(Z_NO_FLUSH) take small
+ *              ZMI_INFLATE_DEFER=BYTES in the environment (with ZMI_TUNING=1; read once, default off) lets inflate(Z_NO_FLUSH) take small
  *              pieces WITHOUT a device decode per call -- zlib's "output latency": the input is decoded once BYTES have come
  *              in, or when a call flushes, brings no input, brings less than the call before, or asks for a block stop.  A
  *              device decode costs a launch (~170 us) whatever it is given; a caller feeding 16-byte pieces needs this, a

@@ -342,5 +342,6 @@ print("deferral ok")
 ''' % os.path.join(zmi_ctypes.ROOT, "tests")
     env = dict(os.environ)
     env["ZMI_INFLATE_DEFER"] = "8192"
+    env["ZMI_TUNING"] = "1"
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "deferral ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -1053,6 +1053,21 @@ def misc_symbol_checks(lib, o):
         assert lib.deflate(C.byref(s), Z_FINISH) == Z_STREAM_END, cfg
         assert zlib.decompressobj(wbits).decompress(dst.raw[:cap - s.avail_out]) == raw, cfg
         assert lib.deflateEnd(C.byref(s)) == Z_OK
+    # ... and spelled out where the bound is tightest: incompressible input, levels 0 and 1, a window below 32 KiB --
+    # the `n + n / 32 + ...` branch at level 0 -- in the geometry a single call gets (segments of 32 KiB, encoder pieces of 8 KiB,
+    # a marker behind every piece)
+    for lvl in (0, 1):
+        for wbits in (9, 12, 14, -12, 9 + 16):
+            for n in (8191, 8192, 8193, 32768, 65536 + 17, 300000):
+                raw = os.urandom(n)
+                s = ZStream()
+                assert lib.deflateInit2_(C.byref(s), lvl, 8, wbits, 8, 0, ver, zs) == Z_OK
+                cap = lib.deflateBound(C.byref(s), n)
+                src, dst = C.create_string_buffer(raw, n), C.create_string_buffer(cap)
+                s.next_in, s.avail_in, s.next_out, s.avail_out = C.addressof(src), n, C.addressof(dst), cap
+                assert lib.deflate(C.byref(s), Z_FINISH) == Z_STREAM_END, (lvl, wbits, n)
+                assert zlib.decompressobj(wbits).decompress(dst.raw[:cap - s.avail_out]) == raw, (lvl, wbits, n)
+                assert lib.deflateEnd(C.byref(s)) == Z_OK
     # --- deflateBound follows the stream's wrapper (deflate.rs:3193-3287; test-libz-rs-sys deflate.rs:620-675): the gzip header
     # fields handed in with deflateSetHeader count, a preset dictionary adds the 4-byte DICTID, no stream = the zlib wrapper
     lib.deflateSetHeader.argtypes = [P, C.POINTER(GzHeader)]

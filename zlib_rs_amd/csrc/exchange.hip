@@ -189,18 +189,32 @@ extern "C" int zmi_exchange_sizes(zmi_comm* c, const uint32_t* d_sizes, uint32_t
     // Every rank must pass the SAME n_local (a job whose shard count does not divide by the world size pads the short ranks'
     // tables with zero sizes): a mismatch would be an all-gather with different counts -- a hang or a garbage table.  n_local = 0
     // on every rank is a no-op; on one rank only it is the same mismatch, so it takes part like any other value.
+    //  Everything that can fail on THIS rank alone -- argument checks, allocations, the copy of n_local -- happens and is
+    // waited for before the first collective: a rank that returned from here after its peers entered ncclAllGather would leave them
+    // blocked in it.  A failure behind that point (the collective itself, the read-back) leaves the communicator in an unknown
+    // state: the stream is drained, the error says so, and the caller is expected to zmi_comm_abort().
+    if (c->world > 64) return zx_fail(ZMI_E_ARG, "zmi_exchange_sizes: more than 64 ranks");
     zx_dev_guard g(c->device);
     if (c->world > 1) {   // one dword per rank in front of the table's all-gather: 4 * world bytes, checked on the host
         if (c->nl_dev == nullptr && hipMalloc((void**)&c->nl_dev, 4u * 65u) != hipSuccess) return zx_fail(ZMI_E_NOMEM, "zmi_exchange_sizes: hipMalloc");
         uint32_t mine = n_local;
-        std::vector<uint32_t> all((size_t)c->world);
-        if (c->world > 64) return zx_fail(ZMI_E_ARG, "zmi_exchange_sizes: more than 64 ranks");
-        if (hipMemcpyAsync(c->nl_dev + 64, &mine, 4u, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess)
-            return zx_fail(ZMI_E_HIP, "zmi_exchange_sizes: copy of n_local");
-        ZX_NCCL(g_rccl.AllGather(c->nl_dev + 64, c->nl_dev, 1, ZX_UINT32, c->comm, (hipStream_t)stream));
-        if (hipMemcpyAsync(all.data(), c->nl_dev, 4u * (size_t)c->world, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+        std::vector<uint32_t> all;
+        try { all.resize((size_t)c->world); } catch (...) { return zx_fail(ZMI_E_NOMEM, "zmi_exchange_sizes: host table"); }
+        if (hipMemcpyAsync(c->nl_dev + 64, &mine, 4u, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess ||
             hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
-            return zx_fail(ZMI_E_HIP, "zmi_exchange_sizes: read-back of the ranks' n_local");
+            return zx_fail(ZMI_E_HIP, "zmi_exchange_sizes: copy of n_local");
+        {
+            const int nr = g_rccl.AllGather(c->nl_dev + 64, c->nl_dev, 1, ZX_UINT32, c->comm, (hipStream_t)stream);
+            if (nr != 0) {
+                (void)hipStreamSynchronize((hipStream_t)stream);
+                return zx_fail(ZMI_E_RCCL, "zmi_exchange_sizes: all-gather of n_local failed (abort the communicator: zmi_comm_abort)", g_rccl.GetErrorString(nr));
+            }
+        }
+        if (hipMemcpyAsync(all.data(), c->nl_dev, 4u * (size_t)c->world, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+            hipStreamSynchronize((hipStream_t)stream) != hipSuccess) {
+            (void)hipStreamSynchronize((hipStream_t)stream);
+            return zx_fail(ZMI_E_HIP, "zmi_exchange_sizes: read-back of the ranks' n_local (abort the communicator: zmi_comm_abort)");
+        }
         for (int p = 0; p < c->world; ++p)
             if (all[(size_t)p] != n_local) return zx_fail(ZMI_E_ARG, "zmi_exchange_sizes: the ranks passed different n_local (pad with zero sizes)");
     }

@@ -93,7 +93,10 @@ static __device__ __forceinline__ uint32_t lz_ld_acq(uint32_t* p) {
 static __device__ __forceinline__ void lz_st_rel(uint32_t* p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-static __device__ __forceinline__ void lz_pause() { __builtin_amdgcn_s_sleep(4); }
+#ifndef LZ_PAUSE_N
+#define LZ_PAUSE_N 4
+#endif
+static __device__ __forceinline__ void lz_pause() { __builtin_amdgcn_s_sleep(LZ_PAUSE_N); }
 static __device__ __forceinline__ void lz_pause_short() { __builtin_amdgcn_s_sleep(1); }
 static __device__ __forceinline__ void lz_st_relaxed(uint32_t* p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

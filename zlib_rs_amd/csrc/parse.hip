@@ -150,6 +150,9 @@ struct ParA {
 static __device__ __forceinline__ ParA par_stage_a(const ParShared* S, uint32_t rowb, uint32_t extb, uint32_t lim, uint32_t w, int p) {
     ParA a;
     const uint32_t len = (w >> 8) & 0x1FFu;                 // (below 4: no match -- any cell will do, the price says no)
+#ifdef ZMI_EMU
+    if (len > 258u) abort();   // (plen2[] has 260 entries and lfreq[] 516 -- lz77.hip never writes a longer match; the CPU build checks)
+#endif
     a.plit = S->psym[w & 0xFFu];
     a.pd = S->pdq[par_dq(w)];
     a.pl2 = S->plen2[len];
@@ -288,9 +291,14 @@ __global__ void __launch_bounds__(64) zmi_parse_kernel(const uint32_t* __restric
         // 64 positions: `nxt` is where the next token starts; no pointer chase, the words are read again in ascending order).
         // Counted as they are -- a literal by its value, a match by its length and by the slot of its distance -- so that a position
         // costs some twenty instructions and no branch; par_prices folds the lengths into symbols.
-        // (every second chunk: the prices of chunks 2 i + 1 and 2 i + 2 come from the counts up to chunk 2 i -- half the scans for
-        // -0.04 ... -0.14 % of ratio, tools/parse_lab.py LAB_EVERY)
-        if (ch + 1u < c_end && ((ch - span * span_chunks) & 1u) == 0u) {
+        // (until round 5 every second chunk: half the scans for -0.04 ... -0.14 % of ratio, tools/parse_lab.py LAB_EVERY)
+        // (round 6: the first four chunks of a span, then every fourth -- the counts are cumulative over the span, so a later chunk
+        // moves the prices less: 19 scans per 64 chunks instead of 32, benchmark mix 2.2685 -> 2.2681, lcet10.txt 2.9208 -> 2.9205 on the
+        // CPU emulator; every fourth alone: 2.2674; the first 8 every second, then every eighth: 2.2676 -- profiles/r06_parse_scan_rule.txt)
+#ifndef PAR_SCAN_RULE
+#define PAR_SCAN_RULE(rel) ((rel) < 4u || ((rel) & 3u) == 0u)
+#endif
+        if (ch + 1u < c_end && PAR_SCAN_RULE(ch - span * span_chunks)) {
             uint32_t nxt = 0u;
             const uint32_t kend = pe > sb ? (pe - sb < 64u ? pe - sb : 64u) : 0u;   // positions of the strip inside its piece
 #pragma unroll 1

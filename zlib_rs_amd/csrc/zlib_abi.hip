@@ -748,7 +748,7 @@ size_t abi_limit(const char* name, size_t dflt) {
     return v > 0 ? (size_t)v : dflt;
 }
 size_t queue_limit() { return abi_limit("ZMI_ABI_QUEUE", (size_t)32 << 20); }
-// ZMI_INFLATE_DEFER=BYTES (a product setting, read once; default 0 = off): inflate(Z_NO_FLUSH) may take its input and decode
+// ZMI_INFLATE_DEFER=BYTES (with ZMI_TUNING=1; read once; default 0 = off): inflate(Z_NO_FLUSH) may take its input and decode
 // LATER, once BYTES have come in since the last decode -- what zlib calls output latency ("may introduce some output latency
 // (reading input without producing any output) except when forced to flush").  A device decode costs a launch and a round trip
 // (~170 us) whatever it is given, and restarts at the last block boundary: a caller feeding 16-byte pieces pays that a thousand
@@ -758,7 +758,9 @@ size_t queue_limit() { return abi_limit("ZMI_ABI_QUEUE", (size_t)32 << 20); }
 // a reader of concatenated streams in small pieces must leave it off.  A call decodes at once when it flushes, brings no input,
 // brings LESS than the call before (the last piece of a file), asks for a block stop, or the threshold is reached.
 size_t defer_bytes() {
-    static const size_t v = [] { const char* e = getenv("ZMI_INFLATE_DEFER"); const long long n = e ? atoll(e) : 0; return n > 0 ? (size_t)n : (size_t)0; }();
+    // (honoured only with ZMI_TUNING set, like every other override -- an inherited environment variable must not change
+    // what the ABI does for every consumer in the process)
+    static const size_t v = [] { const char* e = abi_tune("ZMI_INFLATE_DEFER"); const long long n = e ? atoll(e) : 0; return n > 0 ? (size_t)n : (size_t)0; }();
     return v;
 }
 size_t take_limit() { return abi_limit("ZMI_ABI_TAKE", (size_t)256 << 20); }
@@ -1168,8 +1170,11 @@ int deflateTune(z_streamp strm, int, int, int, int) { return dstate(strm) ? Z_OK
 z_size_t deflateBound_z(z_streamp strm, z_size_t sourceLen) {
     // bound (deflate.rs:3193-3287): the wrapper's length follows the stream (DICTID, the gzip header fields handed in with
     // deflateSetHeader), a window other than 32 KiB gets the conservative formula, the default configuration
-    // compress_bound_help (deflate.rs:2975-2991).  This engine's own overhead -- a 5-byte marker per 1 MiB segment,
-    // 5 bytes per 64 KiB stored block -- stays far inside the (n + 7) / 8 term (test: misc_symbol_checks).
+    // compress_bound_help (deflate.rs:2975-2991).  This engine's own overhead on incompressible input -- one call's input is cut
+    // into segments of 32 KiB (64 KiB in calls of 8 MiB and more) and encoder pieces of 8 KiB, every piece ends with the 5-byte
+    // marker, a stored block (5 bytes of header) holds at least 4096 bytes: some 10 bytes per 4 KiB, 0.25 % -- stays far inside the
+    // (n + 7) / 8 term, and inside the tightest branch too, `n + n / 32 + ...` (3.9 %) for level 0 with a window below 32 KiB
+    // (tests/zlib_abi_harness.py misc_symbol_checks: random configurations, and levels 0 / 1 x small windows x incompressible input).
     const z_size_t n = sourceLen;
     const z_size_t comp_len = n + ((n + 7) >> 3) + ((n + 63) >> 6) + 5;
     DeflateState* s = dstate(strm);

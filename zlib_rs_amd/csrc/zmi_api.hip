@@ -275,10 +275,12 @@ static const zmi_level_cfg kLevels[10] = {
     {3, 32, 8, 0, 8192},         // 2  (greedy)
     // 3 ... 9: the token choice is the cost parse's (csrc/parse.hip) -- `lazy` is not used there, what separates the levels is the
     // search: budget, and the length at which a walk is content (good)
-    {3, 32, 8, 4, 4096},         // 3
-    {3, 64, 16, 8, 4096},        // 4
-    {3, 128, 16, 16, 4096},      // 5  (= 4 in effect: both walks are content with 16 equal bytes; budget 4 with good 8 was measured as a
-                                 //     rung in between and is not one: 2.2359 against level 4's 2.2365 on 128 KiB shards, at level 6's search time)
+    // (round 6: four distinct rungs, as the reference's table has -- deflate/algorithm/mod.rs:72-76.  CPU emulator, 512 KiB inputs, benchmark
+    // mix / lcet10.txt: budget 2 = 2.2294 / 2.811, budget 3 good 8 = 2.2476 / 2.869, budget 3 good 16 = 2.2554 / 2.881, budget 4 = 2.2670 / 2.909;
+    // until round 5 levels 4 and 5 were one configuration and level 3 ran level 4's search)
+    {2, 32, 8, 4, 4096},         // 3
+    {3, 64, 8, 8, 4096},         // 4  (a walk is content with 8 equal bytes)
+    {3, 128, 16, 16, 4096},      // 5  (... with 16)
     {4, 128, 16, 32, 4096},      // 6  (good 32 -> 16 in round 4: lz77 138.7 -> 130.1 ms, ratio 2.2550 -> 2.2532, lcet10.txt -0.04 %)
     {6, 128, 16, 32, 4096},      // 7
     // 8, 9 (round 5): budgets 10 and 16 on the SHORT-budget kernel (the walk ends at the first candidate equal in 16 bytes, the wave
@@ -493,7 +495,7 @@ static int zmi_deflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     // waves outrun one producer: budget 5 measured 227 ms with two, 273 ms with one), 3 at level 1, whose searchers do so
     // little per position that even two producers set the pace (97.1 -> 95.2 ms per 16 Ki shards; at level 3 a third
     // producer already costs more as a missing searcher than it brings: 114.2 -> 120.5 ms)
-    lp.producers = L.chain > 8u ? 1u : (level == 1 ? 3u : 2u);   // (budgets 10 / 16: one producer measured 1-2 % ahead of two)
+    lp.producers = L.chain > 8u ? 1u : (L.chain <= 2u ? 3u : 2u);   // (budgets 10 / 16: one producer measured 1-2 % ahead of two)
     if (const char* pv = zmi_tune("ZMI_PRODUCERS")) lp.producers = (uint32_t)atoi(pv);
     lp.dbg = 0u;
     if (const char* dv = zmi_tune("ZMI_LZ_DBG")) lp.dbg = (uint32_t)atoi(dv);
