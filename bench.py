@@ -22,6 +22,7 @@ import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -279,6 +280,8 @@ def main():
     ap.add_argument("--no-stitch", action="store_true", help="skip the slab packing / exchange leg")
     ap.add_argument("--stitch-deadline", type=float, default=240.0, help="seconds the multi-GPU slab exchange may take before it is given up")
     ap.add_argument("--no-extras", action="store_true", help="skip the inflate / levels / PCIe legs (profiling runs)")
+    ap.add_argument("--stream-abi-only", action="store_true",
+                    help="run only the single-stream ABI leg (configs[0]) and print its JSON object: the full run starts this in a process of its own")
     ap.add_argument("--launch-check", action="store_true",
                     help="rendezvous only (gloo, no GPU work): every rank checks world == --gpus, rank 0 prints one JSON line")
     args = ap.parse_args()
@@ -294,6 +297,9 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python bench.py --gpus N starts them itself)"
                          % (args.gpus, world))
+    if args.stream_abi_only:
+        print(json.dumps(stream_abi_leg(args.level)))
+        return
     if args.launch_check:
         return launch_check(world, rank)
 
@@ -633,7 +639,16 @@ def main():
 
     stream_obj = real_obj = None
     if extras:
-        stream_obj = stream_abi_leg(args.level)
+        # In a process of its own: the single-stream calls of libz_mi355.so measured beside this process's 270 GiB of device tensors and
+        # its pinned staging read 1.0 - 1.2 GiB/s for inflate() where a fresh process reads 1.85 - 2.1 (gpurun_out/r06n, r06p): what a
+        # caller of the drop-in gets is the latter, and it is what reproduces from run to run.
+        child = subprocess.run([sys.executable, os.path.abspath(__file__), "--stream-abi-only", "--level", str(args.level)],
+                               capture_output=True, text=True, timeout=3000)
+        lines = [x for x in child.stdout.splitlines() if x.startswith("{")]
+        if child.returncode != 0 or not lines:
+            raise RuntimeError("stream ABI leg failed: " + child.stderr[-2000:])
+        stream_obj = json.loads(lines[-1])
+        stream_obj["process"] = "a process of its own (python bench.py --stream-abi-only)"
         real_obj = real_data_leg(e, torch, dev, B)
 
     if rank == 0:
@@ -698,11 +713,7 @@ def main():
             line["stream_abi"] = stream_obj
         if real_obj is not None:
             line["real_data"] = real_obj
-        if stitch_obj is not None:
-            line["stitch"] = stitch_obj
-            ov = stitch_obj.get("overlap") if isinstance(stitch_obj, dict) else None
-            if ov and not ov.get("failed"):   # N > 1: `value` is the compression alone; this one includes the all-gather of every slab
-                line["value_with_stitch"] = ov["value_with_stitch"]
+        attach_stitch(line, stitch_obj)
         if world == 1 and not args.no_cpu:
             cb = cpu_baseline(B, args.level)
             if cb is not None:
@@ -1016,6 +1027,18 @@ def stitch_leg(e, torch, out, olen, dev):
             "exchange": "none (one GPU): zmi_pack_slab_dev over all slots, three members of the slab inflated on the host"}
 
 
+def attach_stitch(line, stitch_obj):
+    """the stitch leg's object into the bench line; N > 1: `value` is the compression alone, value_with_stitch includes the all-gather
+    of every slab (tests/test_bench_multi_emu.py drives this, with_deadline and stitch_leg_multi with two ranks on the CPU build)"""
+    if stitch_obj is None:
+        return line
+    line["stitch"] = stitch_obj
+    ov = stitch_obj.get("overlap") if isinstance(stitch_obj, dict) else None
+    if ov and not ov.get("failed"):
+        line["value_with_stitch"] = ov["value_with_stitch"]
+    return line
+
+
 def with_deadline(fn, seconds):
     """run fn() in a thread (the ctypes calls release the GIL) and give up after `seconds`: -> fn's dict, or {"failed": True, ...}"""
     import threading
@@ -1035,7 +1058,7 @@ def with_deadline(fn, seconds):
     return box["res"]
 
 
-def stitch_leg_multi(e, dist, torch, out, olen, dev, world, rank, chunk_bytes=1 << 29, step=None, step_bytes=0, step_s=None):
+def stitch_leg_multi(e, dist, torch, out, olen, dev, world, rank, chunk_bytes=1 << 29, step=None, step_bytes=0, step_s=None, scatter_out=None):
     """N > 1: size tables -> plan -> slots packed into this rank's slab -> point-to-point slab exchange in rounds of 512 MiB
     with reused staging (8 slabs of ~29 GiB do not fit beside a 64 GiB working set; a real job scatters / writes out round by
     round, here the received chunks are counted and the first round is checked against sums the owners computed).
@@ -1079,6 +1102,14 @@ def stitch_leg_multi(e, dist, torch, out, olen, dev, world, rank, chunk_bytes=1 
             if lo == 0:
                 assert int(stage[p][:n].sum(dtype=torch.int64).item()) == int(sums[p].item()), "slab bytes of rank %d arrived damaged" % p
                 checked += 1
+        if scatter_out is not None:
+            # (small jobs, the tests: every slab fits one round -- the received slabs and this rank's own go to their places in the
+            # globally ordered output, the append loop of the reference's recipe, zlib-rs/src/deflate.rs:4145-4221)
+            assert lo == 0 and biggest <= chunk_bytes and int(scatter_out.numel()) >= totals[world]
+            for p in range(world):
+                src = slab if p == rank else stage[p]
+                e.copy_ranges(src, soff[p][:S].contiguous(), 0, table[p].contiguous(), out.stride(0), scatter_out, goff[p].contiguous())
+            torch.cuda.synchronize()
         lo += chunk_bytes
     torch.cuda.synchronize()
     ex_local = time.perf_counter() - t0

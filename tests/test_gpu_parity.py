@@ -83,7 +83,6 @@ def test_generator_matches_cpu_twin(engine):
         assert s == o.gen_shard(i, 1 << 16), "shard %d differs from the CPU generator" % i
 
 
-@pytest.mark.usefixtures("inf_selection")
 @pytest.mark.parametrize("level", [1, 6, 9])
 def test_deflate_roundtrip_full_size(engine, level):
     shards = _gen(engine, 16)
