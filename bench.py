@@ -662,7 +662,7 @@ def main():
         # (tools/prof_final.sh), recorded per launch in profiles/ and scaled to this run's launch size -- a replayed
         # figure, not measured in this run: traffic_source names the file it comes from
         traffic, traffic_source = None, None
-        for name in ("r05_traffic.json",):
+        for name in ("r06_traffic.json", "r05_traffic.json"):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", name)))
                 if tj.get("_csrc_sha16") != csrc_sha16():
