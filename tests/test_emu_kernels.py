@@ -499,6 +499,20 @@ def test_cost_parse_against_the_lazy_rule(eng, o, monkeypatch):
             assert a <= b * 1.02 + 8, (lvl, sizes)
 
 
+def test_levels_are_distinct_rungs(eng, o):
+    """the level table (csrc/zmi_api.hip kLevels; the reference's has a row per level, deflate/algorithm/mod.rs:69-82): levels 2 ... 7 give
+    strictly shrinking output on text and on the XML-like class -- until round 5 levels 4 and 5 were one configuration"""
+    blobs = [parity_checks.tile(dict(parity_checks.real_fixtures())["lcet10.txt"], 1 << 17), o.gen_shard(0, 1 << 17), o.gen_shard(3, 1 << 17)]
+    tot = {}
+    for lvl in (2, 3, 4, 5, 6, 7):
+        comp, st = eng.deflate(blobs, level=lvl, wrap=1)
+        assert st == [0] * len(blobs)
+        for b, c in zip(blobs, comp):
+            assert zlib.decompress(c) == b
+        tot[lvl] = sum(len(c) for c in comp)
+    assert tot[2] > tot[3] > tot[4] > tot[5] > tot[6] > tot[7], tot
+
+
 def test_cost_parse_distance_slot_covers_every_distance(eng):
     """parse.hip prices a distance through par_dq(): exponent and top mantissa bit of float(2 (dist - 1) + 1).  Every distance 1 ... 32768,
     under every value of the length bits next to it in the match word, must land in the slot of its RFC 1951 distance code."""
