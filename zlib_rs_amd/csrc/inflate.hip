@@ -605,13 +605,6 @@ static __device__ __forceinline__ InfLane inf_lane_decode(const InfShared* S, co
 // lane k at offset o: track map_k[o] is on it, and leaves at exit_k[track]" -- after which every lane knows its true first
 // token and the pass continues as for a dynamic block, with nothing to fix.
 // Cost: 8-10 bit-counting walks (~12 instructions a token against ~62 of the table walk) instead of a warm-up and the restart rounds.
-#ifdef ZMI_EMU_STATS
-static unsigned long long g_emu_inf_stats[16];   // 0 passes 1 lanes committed 2 fixed passes 3 fixed lanes 4 track walks 5 chain known 6 restarts
-extern "C" unsigned long long* zmi_emu_inf_stats() { return g_emu_inf_stats; }
-#define INF_STAT(i, v) (g_emu_inf_stats[i] += (v))
-#else
-#define INF_STAT(i, v) ((void)0)
-#endif
 struct InfFixedStep { uint32_t adv; uint32_t stop; };   // bits of the token at the low end of `lo` (>= 32 significant bits); stop: 1 invalid, 2 end of block
 static __device__ __forceinline__ InfFixedStep inf_fixed_step(uint32_t lo, uint32_t hi) {
     InfFixedStep R;
@@ -720,20 +713,8 @@ static __device__ __forceinline__ InfFixedMaps inf_fixed_tracks(const uint8_t* f
                 pos += T.adv;
             }
             quad_or(F.ex, t >> 2, code << (8u * (t & 3u)));
-            INF_STAT(4, 1);
         }
     }
-#ifdef ZMI_EMU_STATS
-    if (active) {   // distinct exits among this lane's tracks
-        uint32_t seen[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nd = 0;
-        for (uint32_t t = 1; t < 16u; ++t) {
-            const uint32_t e = (quad_pick(F.ex, t >> 2) >> (8u * (t & 3u))) & 0xFFu;
-            if (e == 0u && t > 1u) continue;
-            if (!((seen[e >> 5] >> (e & 31u)) & 1u)) { seen[e >> 5] |= 1u << (e & 31u); ++nd; }
-        }
-        INF_STAT(7, nd);
-    }
-#endif
     return F;
 }
 // the chain over the 64 lanes of a wave, entered at bit offset `off` of lane 0 (wave-uniform): *mine = the offset at which it
@@ -814,7 +795,6 @@ static __device__ __forceinline__ uint32_t inf_fast_pass(InfShared* S, const uin
         uint32_t fs = start;
         const uint32_t known = inf_fixed_sync(S->fb, p_rel, sub, &fs);
         if (lane < known) start = fs;
-        if (lane == 0) { INF_STAT(2, 1); INF_STAT(5, known); }
     } else {
         // (lane 0 rides along switched off: it must still hold a position inside the staged bytes, its reads happen; with
         // short sub-sequences the lowest lanes warm up from the pass's own first bit, which is a true token start)
@@ -839,7 +819,6 @@ static __device__ __forceinline__ uint32_t inf_fast_pass(InfShared* S, const uin
         // restart the wrong lanes where their neighbours ended (most fall into step inside their own sub-sequence, so
         // the next check usually finds everything consistent)
         if (wrong) start = below_exit;
-        if (lane == 0) INF_STAT(6, 1);
         const InfLane N = inf_lane_decode<false>(S, S->fb, start, boundary, wrong, nullptr, nullptr, 0u, 0u);
         if (wrong) R = N;
     }
@@ -852,7 +831,6 @@ static __device__ __forceinline__ uint32_t inf_fast_pass(InfShared* S, const uin
     const uint64_t badm = __ballot(bad);
     uint32_t commit = good;
     if (badm) { const uint32_t fb1 = (uint32_t)__ffsll((unsigned long long)badm) - 1u; commit = fb1 < commit ? fb1 : commit; }
-    if (lane == 0) { INF_STAT(0, 1); INF_STAT(1, commit); if (fixed_code) INF_STAT(3, commit); }
     if (commit == 0u) return 0u;
     // 3. write
     (void)inf_lane_decode<true>(S, S->fb, start, boundary, lane < commit, dst, bm32, base, R.nout);
