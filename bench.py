@@ -859,7 +859,8 @@ def stream_abi_leg(level):
         zlib.decompress(zc)
         return time.perf_counter() - t0, None
     tz, tz_sp, _ = _median_of(run_syszlib, 3)
-    sweep = chunk_sweep_leg(ocomp, len(data), _build.ABI_LIB)
+    small_len = 1 << 20   # (the default mode's 16- and 64-byte pieces: a 1 MiB stream, see chunk_sweep_leg)
+    sweep = chunk_sweep_leg(ocomp, len(data), _build.ABI_LIB, small=(o.deflate(data[:small_len], level, 2)[1], small_len))
     return {"input_bytes": len(data), "path": "deflateInit2_(level, gzip) + deflate() in 4 MiB chunks + inflate() back, one thread, host buffers",
             "chunk_sweep": sweep,
             "timing": "every rate of this object is the median of 5 runs (system zlib: 3); the spread of the runs is under `spread`",
@@ -876,7 +877,7 @@ def stream_abi_leg(level):
                     "a stream without them (the CPU's) = one workgroup of 16 waves, a pass covers at most one deflate block"}
 
 
-def chunk_sweep_leg(gz_stream, out_len, abi_lib):
+def chunk_sweep_leg(gz_stream, out_len, abi_lib, small=None):
     """The reference's own inflate benchmark (test-libz-rs-sys/examples/blogpost-uncompress.rs:6-44; zlib_benchmarks.json: input
     chunks 2^4 ... 2^24, the whole output buffer available, Z_NO_FLUSH): one CPU-made gzip stream through inflate() chunk by
     chunk, by tools/chunk_sweep.c (a C loop, compiled here with gcc), once bound to libz_mi355.so and once to the system's zlib."""
@@ -889,7 +890,7 @@ def chunk_sweep_leg(gz_stream, out_len, abi_lib):
         open(gz, "wb").write(gz_stream)
         res = {}
         # eager = the library's default: every inflate() decodes what it was given (a device launch per call: the pieces below
-        # 256 bytes would take minutes and are left out); deferred = ZMI_INFLATE_DEFER=1048576 (opt-in, include/zmi355_zlib.h)
+        # 256 bytes are measured on a shorter stream, below); deferred = ZMI_INFLATE_DEFER=1048576 (opt-in, include/zmi355_zlib.h)
         for name, lib, defer, cs in (("system_zlib", "libz.so.1", None, chunks), ("zmi_deferred", abi_lib, "1048576", chunks),
                                      ("zmi_eager", abi_lib, None, [c for c in chunks if c >= 256])):
             env = dict(os.environ)
@@ -901,6 +902,20 @@ def chunk_sweep_leg(gz_stream, out_len, abi_lib):
             r = subprocess.run([exe, lib, gz, str(out_len), "31"] + [str(c) for c in cs], capture_output=True, text=True, env=env, timeout=1800)
             assert r.returncode == 0, r.stderr
             res[name] = {ln.split()[0]: ln.split() for ln in r.stdout.strip().splitlines()}
+        # the default mode at 16- and 64-byte pieces: a decode is a device launch whatever it brings (~250 us; profiles/
+        # r06_eager_inflate_trace.txt), the 15.7 MB stream would take ten minutes -- measured on a 1 MiB stream of the same data
+        # (per byte the same work: the cost is per call), the system zlib on the same stream beside it
+        tiny = {}
+        if small is not None:
+            gz2 = os.path.join(td, "small.gz")
+            open(gz2, "wb").write(small[0])
+            for name, lib in (("system_zlib", "libz.so.1"), ("zmi_eager", abi_lib)):
+                env = dict(os.environ)
+                env["LD_LIBRARY_PATH"] = os.path.dirname(abi_lib) + ":" + env.get("LD_LIBRARY_PATH", "")
+                env.pop("ZMI_INFLATE_DEFER", None)
+                r = subprocess.run([exe, lib, gz2, str(small[1]), "31", "16", "64"], capture_output=True, text=True, env=env, timeout=1800)
+                assert r.returncode == 0, r.stderr
+                tiny[name] = {ln.split()[0]: ln.split() for ln in r.stdout.strip().splitlines()}
     rows = {}
     for c in chunks:
         b = res["system_zlib"][str(c)]
@@ -913,6 +928,11 @@ def chunk_sweep_leg(gz_stream, out_len, abi_lib):
             row[name + "_GiB_s"] = out_len / GIB / float(a[1])
             if name == "zmi_deferred":
                 row["polls"] = int(a[4])
+        if small is not None and str(c) in tiny.get("zmi_eager", {}):
+            a, b = tiny["zmi_eager"][str(c)], tiny["system_zlib"][str(c)]
+            assert int(a[2]) == small[1] == int(b[2]) and int(a[3]) == 1 and a[5] == b[5], ("chunk sweep (1 MiB stream): outputs differ", a, b)
+            row["zmi_eager_GiB_s"] = small[1] / GIB / float(a[1])
+            row["zmi_eager_measured_on"] = "a 1 MiB stream (system zlib on it: %.3f GiB/s)" % (small[1] / GIB / float(b[1]))
         rows[str(c)] = row
     return {"chunks": rows, "stream": "the oracle's gzip stream of the same %d bytes (no flush points)" % out_len,
             "modes": "zmi_eager: the default -- every inflate() call decodes what it brought (exact input accounting, the end of the "
