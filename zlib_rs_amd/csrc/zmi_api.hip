@@ -641,7 +641,12 @@ static int zmi_inflate_impl(zmi_ctx* c, const void* d_in, const uint64_t* d_in_o
     // streams plausibly hold, 64 MiB each, says the caller did not size it for this call, and the serial pass is the safer choice)
     // (callers that sized the limit from this call's capacities -- zmi_inflate_resume, the host-buffer batch -- are exact: one stream of
     // several hundred MiB keeps the jump pass)
-    bool jump = n <= 16u && out_limit <= (1ull << 30) && out_limit >= (256ull << 10) &&
+    // (round 6: ONE stream whose limit was sized for this call -- a streaming inflate() of the zlib ABI, zmi_inflate_resume -- takes the
+    // jump pass from 64 KiB on: its serial pass is one wave alone on the chip, 389 us for the ~40 KiB of an open block, against a dozen
+    // launches of a few microseconds; the reference's chunk sweep at 1 / 4 / 16 / 64 KiB pieces: 0.90 / 0.248 / 0.069 / 0.020 s ->
+    // 0.59 / 0.153 / 0.046 / 0.018 s for 4 MiB, profiles/r06_eager_inflate_trace.txt)
+    const uint64_t jump_min = (n == 1u && c->inf_limit_exact) ? (64ull << 10) : (256ull << 10);
+    bool jump = n <= 16u && out_limit <= (1ull << 30) && out_limit >= jump_min &&
                 (c->inf_limit_exact || out_limit <= (uint64_t)n * (64ull << 20) + (1ull << 20));
     if (!decode_only) {
     if (const char* jv = zmi_tune("ZMI_INF_JUMP")) jump = atoi(jv) != 0 && out_limit <= (1ull << 30);
