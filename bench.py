@@ -588,53 +588,27 @@ def main():
                                        "note": "one launch of %d shards" % wn,
                                        "check": "%d streams inflated on device, bit-exact" % vs}
         del out2
-        # ---- PCIe inclusive: host buffers in, host buffers out (zmi_deflate_batch, pipelined copies) ----
+        # ---- PCIe inclusive: host buffers in, host buffers out (zmi_deflate_batch / zmi_inflate_batch, pipelined copies) ----
+        # In a process of its own WITHOUT torch (tools/gpu_host_probe.py --json): libzmi355.so binds to whatever HIP runtime the process
+        # holds, and inside this process that is the one torch ships (ROCm 7.0), whose copies from and to host memory run 15-30 % below
+        # the system's (/opt/rocm, 7.2) -- 29.7 / 24.3 GiB/s here against 35-36 / 34 in a process that is not torch's
+        # (gpurun_out/r06z_bench.json, r06_hostprobe2.log).  A caller of the C ABI has the system's runtime.
         P = max(1, min(args.pcie_shards, S))
         if True:   # (a failing host-buffer leg fails the run: VERDICT r03 weak 1)
-            h_in = data[:P * B].cpu().numpy()
-            h_off = (np.arange(P, dtype=np.uint64) * B)
-            h_len = np.full(P, B, dtype=np.uint32)
-            h_out = np.empty(P * stride, dtype=np.uint8)
-            h_olen = np.zeros(P, dtype=np.uint32)
-            h_st = np.zeros(P, dtype=np.int32)
-            def run_hdeflate():
-                ti = time.perf_counter()
-                rc = e.L.zmi_deflate_batch(e._ctx, h_in.ctypes.data, h_off.ctypes.data, h_len.ctypes.data, P, args.level, 0, 1,
-                                           h_out.ctypes.data, stride, h_olen.ctypes.data, h_st.ctypes.data)
-                dt = time.perf_counter() - ti
-                assert rc == 0 and not h_st.any()
-                return dt, None
-            run_hdeflate()   # (staging buffers of this size)
-            best, best_sp, _ = _median_of(run_hdeflate)
-            pcie_obj = {"value": P * B / GIB / best, "unit": "GiB/s", "shards": P, "timing": "median of 5 calls", "spread": _rate(P * B, best, best_sp),
+            child = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_host_probe.py"), "--json", "--shards", str(P), "--level", str(args.level),
+                                    "--reps", "5"], capture_output=True, text=True, timeout=3000)
+            lines = [x for x in child.stdout.splitlines() if x.startswith("{")]
+            if child.returncode != 0 or not lines:
+                raise RuntimeError("host-buffer leg failed: " + child.stderr[-2000:])
+            hp = json.loads(lines[-1])
+            pcie_obj = {"value": hp["deflate"]["median"], "unit": "GiB/s", "shards": P, "timing": "median of 5 calls behind a warm-up call", "spread": hp["deflate"],
                         "link": pcie_link_probe(torch, dev),
                         "path": "zmi_deflate_batch: pageable host memory -> pinned staging -> H2D -> kernels -> slab written to pinned host "
                                 "memory by the pack kernel -> scattered to the caller's slots; chunks pipelined over three slots",
-                        "ratio": P * B / float(h_olen.astype(np.int64).sum())}
-            # ... and back: zmi_inflate_batch on the host copies of the streams just made
-            h_back = np.empty(P * B, dtype=np.uint8)
-            c_off = (np.arange(P, dtype=np.uint64) * stride)
-            o_cap = np.full(P, B, dtype=np.uint32)
-            b_len = np.zeros(P, dtype=np.uint32)
-            b_st = np.zeros(P, dtype=np.int32)
-            def run_hinflate():
-                ti = time.perf_counter()
-                rc = e.L.zmi_inflate_batch(e._ctx, h_out.ctypes.data, c_off.ctypes.data, h_olen.ctypes.data, P, 1, h_back.ctypes.data,
-                                           h_off.ctypes.data, o_cap.ctypes.data, b_len.ctypes.data, b_st.ctypes.data)
-                dt = time.perf_counter() - ti
-                assert rc == 0 and not b_st.any()
-                return dt, None
-            run_hinflate()
-            ibest, ibest_sp, _ = _median_of(run_hinflate)
-            assert np.array_equal(h_back, h_in), "host-buffer round trip differs"
-            pcie_obj["inflate_GiB_s"] = P * B / GIB / ibest
-            pcie_obj["inflate_spread"] = _rate(P * B, ibest, ibest_sp)
-            pcie_obj["inflate_path"] = ("zmi_inflate_batch: pageable host memory -> pinned staging -> H2D -> kernels -> the chunk's output region to "
-                                        "pinned host memory (one DMA copy enqueued ahead when the chunks before it filled their capacity -- the "
-                                        "calls after the first --, decoded bytes range by range through the pack kernel otherwise) -> "
-                                        "scattered to the caller's regions; median of 5 calls")
-            pcie_obj["round_trip"] = "bit-exact"
-            del h_in, h_out, h_back
+                        "ratio": hp["ratio"], "inflate_GiB_s": hp["inflate"]["median"], "inflate_spread": hp["inflate"],
+                        "inflate_path": "zmi_inflate_batch: pageable host memory -> pinned staging -> H2D -> kernels -> the chunk's output region to "
+                                        "pinned host memory -> scattered to the caller's regions; median of 5 calls",
+                        "round_trip": hp["round_trip"], "process": hp["process"]}
     del back
 
     stream_obj = real_obj = None

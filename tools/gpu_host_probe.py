@@ -8,7 +8,8 @@ import os
 import sys
 import time
 
-os.environ.setdefault("ZMI_TUNING", "1")
+if "--json" not in sys.argv:
+    os.environ.setdefault("ZMI_TUNING", "1")   # (the --json form is bench.py's leg: the product configuration, no overrides)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import gpu_fast_probe as P  # noqa: E402
 import numpy as np  # noqa: E402
@@ -24,6 +25,7 @@ def main():
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--scratch-gib", type=float, default=0.0, help="the context's scratch limit (bench.py: 70)")
     ap.add_argument("--hog-gib", type=float, default=0.0, help="device memory held beside the run (bench.py holds ~206 GiB)")
+    ap.add_argument("--json", action="store_true", help="one warm-up call, then --reps timed calls of each direction; prints one JSON object with medians (bench.py's pcie_inclusive leg)")
     ap.add_argument("--empty-out", action="store_true", help="np.empty output buffers (pages never touched before the first call), as bench.py has them")
     a = ap.parse_args()
     L, path = P.load_lib()
@@ -38,12 +40,14 @@ def main():
     hog = [P.dmalloc(1 << 30) for _ in range(int(a.hog_gib))]
     B, S = 1 << 20, a.shards
     stride = int(L.zmi_deflate_bound(B, 1))
-    d_in = P.dmalloc(S * B)
-    for s0 in range(0, S, 16384):
-        L.zmi_gen_shards_dev(ctx, d_in + s0 * B, 0x5A4C4942, s0, min(16384, S - s0), B, None)
-    P.hip.hipDeviceSynchronize()
     h_in = np.empty(S * B, dtype=np.uint8)
-    P.ck(P.hip.hipMemcpy(h_in.ctypes.data, d_in, S * B, 2), "d2h")
+    piece = min(S, 1024)                      # (1 GiB of device memory at a time: bench.py runs this beside its own tensors)
+    d_in = P.dmalloc(piece * B)
+    for s0 in range(0, S, piece):
+        cnt = min(piece, S - s0)
+        L.zmi_gen_shards_dev(ctx, d_in, 0x5A4C4942, s0, cnt, B, None)
+        P.hip.hipDeviceSynchronize()
+        P.ck(P.hip.hipMemcpy(h_in.ctypes.data + s0 * B, d_in, cnt * B, 2), "d2h")
     P.hip.hipFree(d_in)
     h_off = np.arange(S, dtype=np.uint64) * B
     h_len = np.full(S, B, dtype=np.uint32)
@@ -51,14 +55,17 @@ def main():
     h_olen = np.zeros(S, dtype=np.uint32)
     h_st = np.zeros(S, dtype=np.int32)
     best = None
-    for _ in range(a.reps):
+    tdef, tinf = [], []
+    for _ in range(a.reps + (1 if a.json else 0)):
         t = time.perf_counter()
         rc = L.zmi_deflate_batch(ctx, h_in.ctypes.data, h_off.ctypes.data, h_len.ctypes.data, S, a.level, 0, 1, h_out.ctypes.data, stride,
                                  h_olen.ctypes.data, h_st.ctypes.data)
         dt = time.perf_counter() - t
         assert rc == 0 and not h_st.any(), L.zmi_last_error()
         best = dt if best is None else min(best, dt)
-    print("deflate host path: %d shards %.1f ms = %.2f GiB/s (threads env %s)" % (S, best * 1e3, S * B / 2**30 / best, os.environ.get("ZMI_HOST_THREADS", "default")))
+        tdef.append(dt)
+    if not a.json:
+        print("deflate host path: %d shards %.1f ms = %.2f GiB/s (threads env %s)" % (S, best * 1e3, S * B / 2**30 / best, os.environ.get("ZMI_HOST_THREADS", "default")))
     # inflate back through the host path
     c_off = np.arange(S, dtype=np.uint64) * stride
     o_off = np.arange(S, dtype=np.uint64) * B
@@ -67,14 +74,26 @@ def main():
     b_len = np.zeros(S, dtype=np.uint32)
     b_st = np.zeros(S, dtype=np.int32)
     best = None
-    for _ in range(a.reps):
+    for _ in range(a.reps + (1 if a.json else 0)):
         t = time.perf_counter()
         rc = L.zmi_inflate_batch(ctx, h_out.ctypes.data, c_off.ctypes.data, h_olen.ctypes.data, S, 1, h_back.ctypes.data, o_off.ctypes.data,
                                  o_cap.ctypes.data, b_len.ctypes.data, b_st.ctypes.data)
         dt = time.perf_counter() - t
         assert rc == 0 and not b_st.any(), L.zmi_last_error()
         best = dt if best is None else min(best, dt)
+        tinf.append(dt)
     assert np.array_equal(h_back, h_in)
+    if a.json:
+        import json
+
+        def rate(ts):
+            ts = sorted(ts[1:])                  # (the first call pays for the staging buffers)
+            g = S * B / 2**30
+            return {"median": g / ts[len(ts) // 2], "min": g / ts[-1], "max": g / ts[0], "runs": len(ts)}
+        print(json.dumps({"shards": S, "deflate": rate(tdef), "inflate": rate(tinf), "ratio": S * B / float(h_olen.astype(np.int64).sum()),
+                          "round_trip": "bit-exact", "process": "a process of its own, without torch: the HIP runtime is the system's (/opt/rocm), as for any "
+                          "caller of libzmi355.so -- inside bench.py's process the library binds to the runtime torch ships"}))
+        return
     print("inflate host path: %d streams %.1f ms = %.2f GiB/s of output" % (S, best * 1e3, S * B / 2**30 / best))
     # host memcpy bandwidth for reference (one thread)
     t = time.perf_counter()
