@@ -259,6 +259,8 @@ def test_input_handback_after_a_paused_decode(monkeypatch, tmp_path):
     H.handback_checks(lib, oracle_lib.load(), tmp_path)
     monkeypatch.setenv("ZMI_ABI_ABSORB", "1000")     # the caller's input is taken in small pieces
     H.handback_checks(lib, oracle_lib.load(), tmp_path, size=60000)
+    assert H.multi_member_reader_checks(lib, oracle_lib.load(), member_bytes=(30000, 1, 20000), piece=8192) == 3   # Python's gzip reader loop
+    assert H.multi_member_reader_checks(lib, oracle_lib.load(), member_bytes=(9000, 7000, 100), piece=777) == 3
 
 
 def test_deflate_emits_as_input_arrives(monkeypatch):

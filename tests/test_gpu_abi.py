@@ -53,6 +53,14 @@ def test_inflate_hands_out_output_progressively_on_gpu():
     H.progressive_inflate_checks(lib, oracle_lib.load(rebuild=False).gen_shard(0, 2 << 20))
 
 
+@pytest.mark.usefixtures("inf_selection")
+def test_three_gzip_members_in_8k_pieces_through_the_default_mode_on_gpu():
+    from zlib_rs_amd import _build
+    lib = H.bind(C.CDLL(_build.ABI_LIB))
+    assert H.multi_member_reader_checks(lib, oracle_lib.load(rebuild=False)) == 3
+    assert H.multi_member_reader_checks(lib, oracle_lib.load(rebuild=False), member_bytes=(8192, 1, 300000), piece=1000) == 3
+
+
 def test_c_program_links_and_roundtrips(tmp_path):
     from zlib_rs_amd import _build
     exe = str(tmp_path / "abi_smoke")

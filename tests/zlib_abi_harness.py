@@ -1366,6 +1366,51 @@ def handback_checks(lib, o, tmpdir, size=150000):
     assert _gz_read_all(lib, path, chunk=1 << 20) == bytes(size) + data + second
 
 
+def multi_member_reader_checks(lib, o, member_bytes=(70000, 25000, 120000), piece=8192):
+    """the loop of Python's gzip reader (_GzipReader: read 8 KiB, decompress, at the end of a member carry `unused_data` into the next
+    one) on a file of three gzip members, through the DEFAULT mode of inflate(): every member ends in the call that delivers its last
+    byte, what that call did not consume begins exactly at the next member's magic, nothing is swallowed or lost."""
+    import gzip
+    members = [o.gen_shard(i, n) for i, n in enumerate(member_bytes)]
+    blob = b"".join(gzip.compress(m, 6) for m in members)
+    src = C.create_string_buffer(blob, len(blob))
+    obuf = C.create_string_buffer(1 << 18)
+    strm = ZStream()
+    assert lib.inflateInit2_(C.byref(strm), 31, lib.zlibVersion(), C.sizeof(ZStream)) == Z_OK
+    pos, got, outs, ends = 0, bytearray(), [], 0
+    pending = 0                                   # bytes of the last piece the finished member left behind (unused_data)
+    while True:
+        if pending == 0:
+            if pos >= len(blob):
+                break
+            n = min(piece, len(blob) - pos)
+            strm.next_in, strm.avail_in = C.addressof(src) + pos, n
+            pos += n
+        else:
+            strm.next_in, strm.avail_in = C.addressof(src) + pos - pending, pending
+            pending = 0
+        while True:
+            strm.next_out, strm.avail_out = C.addressof(obuf), len(obuf)
+            rc = lib.inflate(C.byref(strm), Z_NO_FLUSH)
+            got += obuf.raw[:len(obuf) - strm.avail_out]
+            assert rc in (Z_OK, Z_STREAM_END, Z_BUF_ERROR), rc
+            if rc == Z_STREAM_END:
+                ends += 1
+                outs.append(bytes(got))
+                got = bytearray()
+                pending = strm.avail_in
+                at = pos - pending
+                if at < len(blob):               # the unconsumed bytes start with the next member's header
+                    assert blob[at:at + 2] == b"\x1f\x8b", (ends, at, blob[at:at + 4])
+                assert lib.inflateReset(C.byref(strm)) == Z_OK
+                break
+            if strm.avail_in == 0 and strm.avail_out != 0:
+                break
+    assert lib.inflateEnd(C.byref(strm)) == Z_OK
+    assert ends == len(members) and outs == members, (ends, [len(x) for x in outs])
+    return ends
+
+
 def block_stop_checks(lib, syslib, data):
     """inflate(Z_BLOCK) / inflate(Z_TREES): the calls of the reference's tests (test-libz-rs-sys/src/inflate.rs:640-676 runs every
     stream through a Z_TREES loop, :2036-2078 logs avail_in / avail_out / data_type after every Z_BLOCK call and compares the
